@@ -1,0 +1,221 @@
+"""Synthetic EVP workloads: grid metrics, land mask, ice state and forcing
+given as functions of the extended-global cell index (I, J), so any rank can evaluate
+exactly its own blocks (ghost ring included) and every decomposition sees the same bytes.
+
+Grid: analytic lat-lon-like lengths HTN (north face) / HTE (east face); the derived
+metric terms use the formulas of source/ice_grid.F90:338-369 (tarea..cxm),
+:1436-1465 (dxu, dxt from HTN) and :1506-1541 (dyu, dyt from HTE).  Masks follow
+makemask, :1555-1625 (uvm = min of the four surrounding hm).
+
+Random parts come from an integer hash of (I, J, field) instead of a sequential PCG64
+stream, so that a rank never has to generate the whole 3600x2700 grid.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict
+
+import numpy as np
+
+from . import constants as C
+from .blocks import Decomp, to_blocks
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _hash01(I, J, salt: int, seed: int):
+    """Uniform [0,1) from a splitmix64-style mix of the global index."""
+    with np.errstate(over="ignore"):
+        x = (I.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ \
+            (J.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) ^ \
+            np.uint64((salt * 0x165667B19E3779F9 + seed * 0x27D4EB2F165667C5) & 0xFFFFFFFFFFFFFFFF)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+@dataclass
+class SynthCase:
+    nx: int
+    ny: int
+    ew_boundary: int = C.BND_CYCLIC
+    ns_boundary: int = C.BND_OPEN
+    seed: int = 20261003
+    land: str = "rows"         # "rows": 2 land rows top & bottom (rectgrid, ice_grid.F90:1248-1254); "continents": + ~30 % land
+    ice: str = "polar"         # "polar": ice where |lat| > ~55 deg;  "full": ice on every ocean cell
+    dt: float = 3600.0
+    ndte: int = 120
+    lat_s: float = -78.0
+    lat_n: float = 88.0
+
+    # ---- index helpers -------------------------------------------------------------
+    def _wrap(self, I):
+        if self.ew_boundary == C.BND_CYCLIC:
+            return (I - 1) % self.nx + 1
+        return I
+
+    def _inside(self, I, J):
+        ok = (J >= 1) & (J <= self.ny)
+        if self.ew_boundary != C.BND_CYCLIC:
+            ok = ok & (I >= 1) & (I <= self.nx)
+        return ok
+
+    def _latT(self, J):
+        return self.lat_s + (J - 0.5) * ((self.lat_n - self.lat_s) / self.ny)
+
+    def _latU(self, J):
+        return self.lat_s + J * ((self.lat_n - self.lat_s) / self.ny)
+
+    # ---- primary grid lengths (m) --------------------------------------------------
+    def HTN(self, I, J):
+        dx0 = 111.0e3 * 360.0 / self.nx
+        I, J = np.broadcast_arrays(I, J)
+        return dx0 * np.maximum(np.cos(np.deg2rad(self._latU(J))), 0.05) + 0.0 * I
+
+    def HTE(self, I, J):
+        dy0 = 111.0e3 * (self.lat_n - self.lat_s) / self.ny
+        I, J = np.broadcast_arrays(I, J)
+        Iw = self._wrap(I)
+        return dy0 * (1.0 + 0.1 * np.sin(2.0 * np.pi * Iw / self.nx) * np.cos(np.deg2rad(self._latT(J))))
+
+    # ---- masks ---------------------------------------------------------------------
+    def hm(self, I, J):
+        I, J = np.broadcast_arrays(I, J)
+        Iw = self._wrap(I)
+        ocean = self._inside(I, J)
+        ocean = ocean & (J > 2) & (J < self.ny - 1)
+        if self.land == "continents":
+            x = 2.0 * np.pi * Iw / self.nx
+            y = np.pi * J / self.ny
+            f = (np.sin(3.0 * x + 1.3) * np.cos(2.0 * y) + 0.6 * np.sin(5.0 * x - 0.7 + 2.0 * np.sin(3.0 * y))
+                 + 0.4 * np.cos(7.0 * y + x))
+            ocean = ocean & (f < 0.55)
+        return ocean.astype(np.float64)
+
+    def uvm(self, I, J):
+        I, J = np.broadcast_arrays(I, J)
+        v = np.minimum(np.minimum(self.hm(I, J), self.hm(I + 1, J)),
+                       np.minimum(self.hm(I, J + 1), self.hm(I + 1, J + 1)))
+        return np.where(self._inside(I, J), v, 0.0)
+
+    # ---- ice state / forcing -------------------------------------------------------
+    def _icy(self, I, J):
+        Iw = self._wrap(I)
+        ocean = self.hm(I, J) > 0.5
+        if self.ice == "full":
+            return ocean
+        edge = 55.0 + 5.0 * np.sin(2.0 * np.pi * 4.0 * Iw / self.nx)
+        return ocean & (np.abs(self._latT(J)) > edge)
+
+    def field(self, name: str, I, J):
+        I, J = np.broadcast_arrays(np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64))
+        Iw = self._wrap(I)
+        s = self.seed
+        HTN, HTE = self.HTN, self.HTE
+        if name == "dxt":
+            return 0.5 * (HTN(I, J) + HTN(I, J - 1))
+        if name == "dyt":
+            return 0.5 * (HTE(I, J) + HTE(I - 1, J))
+        if name == "dxu":
+            return 0.5 * (HTN(I, J) + HTN(I + 1, J))
+        if name == "dyu":
+            return 0.5 * (HTE(I, J) + HTE(I, J + 1))
+        if name == "tarea":
+            return self.field("dxt", I, J) * self.field("dyt", I, J)
+        if name == "uarea":
+            return self.field("dxu", I, J) * self.field("dyu", I, J)
+        if name == "tarear":
+            return 1.0 / self.field("tarea", I, J)
+        if name == "uarear":
+            return 1.0 / self.field("uarea", I, J)
+        if name == "tinyarea":
+            return C.puny * self.field("tarea", I, J)
+        if name == "dxhy":
+            return 0.5 * (HTE(I, J) - HTE(I - 1, J))
+        if name == "dyhx":
+            return 0.5 * (HTN(I, J) - HTN(I, J - 1))
+        if name == "cyp":
+            return 1.5 * HTE(I, J) - 0.5 * HTE(I - 1, J)
+        if name == "cxp":
+            return 1.5 * HTN(I, J) - 0.5 * HTN(I, J - 1)
+        if name == "cym":
+            return -(1.5 * HTE(I - 1, J) - 0.5 * HTE(I, J))
+        if name == "cxm":
+            return -(1.5 * HTN(I, J - 1) - 0.5 * HTN(I, J))
+        if name == "fcor":
+            return 2.0 * C.omega * np.sin(np.deg2rad(self._latU(J))) + 0.0 * I
+        if name == "tmask":
+            return (self.hm(I, J) > 0.5).astype(np.int32)
+        if name == "umask":
+            return (self.uvm(I, J) > 0.5).astype(np.int32)
+
+        icy = self._icy(I, J)
+        x = 2.0 * np.pi * Iw / self.nx
+        y = np.pi * J / self.ny
+        if name in ("aice", "aice_init"):
+            return np.where(icy, 0.6 + 0.4 * _hash01(Iw, J, 1, s), 0.0)
+        if name == "vice":
+            hi = 0.5 + 2.5 * _hash01(Iw, J, 2, s)
+            return np.where(icy, self.field("aice", I, J) * hi, 0.0)
+        if name == "vsno":
+            return np.where(icy, self.field("aice", I, J) * 0.3 * _hash01(Iw, J, 3, s), 0.0)
+        ins = self._inside(I, J)
+        if name == "uocn":
+            return np.where(ins, 0.05 * np.sin(3.0 * x + 0.4) * np.cos(4.0 * y) + 0.01 * (_hash01(Iw, J, 4, s) - 0.5), 0.0)
+        if name == "vocn":
+            return np.where(ins, 0.05 * np.cos(2.0 * x - 1.1) * np.sin(5.0 * y) + 0.01 * (_hash01(Iw, J, 5, s) - 0.5), 0.0)
+        if name == "strairxT":
+            return self.field("aice", I, J) * (0.1 * np.sin(2.0 * x + 3.0 * y) + 0.05 * (_hash01(Iw, J, 6, s) - 0.5))
+        if name == "strairyT":
+            return self.field("aice", I, J) * (0.1 * np.cos(3.0 * x - 2.0 * y) + 0.05 * (_hash01(Iw, J, 7, s) - 0.5))
+        if name == "ss_tltx":
+            return np.where(ins, 1.0e-6 * np.sin(4.0 * x + y), 0.0)
+        if name == "ss_tlty":
+            return np.where(ins, 1.0e-6 * np.cos(3.0 * x - y), 0.0)
+        if name == "Cdn_ocn":
+            return np.full(I.shape, C.dragio)
+        if name == "strength":   # Hibler (1979), ice_mechred.F90:2258-2265
+            a, v = self.field("aice", I, J), self.field("vice", I, J)
+            return C.Pstar * v * np.exp(-C.Cstar * (1.0 - a))
+        if name in ("strax", "stray"):   # ACCESS: wind stress already on the U grid
+            return self.field("strairxT" if name == "strax" else "strairyT", I, J)
+        raise KeyError(name)
+
+
+GRID_FIELDS = ["dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
+               "tarear", "uarear", "tinyarea", "tarea", "uarea", "fcor"]
+MASK_FIELDS = ["tmask", "umask"]
+INPUT_FIELDS = ["aice", "vice", "vsno", "aice_init", "strairxT", "strairyT", "strax", "stray",
+                "uocn", "vocn", "ss_tltx", "ss_tlty", "Cdn_ocn", "strength"]
+STRESS_FIELDS = [f"{k}_{c}" for k in ("stressp", "stressm", "stress12") for c in (1, 2, 3, 4)]
+STATE_FIELDS = ["uvel", "vvel"] + STRESS_FIELDS
+OUTPUT_FIELDS = ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx", "strinty",
+                 "strocnx", "strocny", "strocnxT", "strocnyT", "strairx", "strairy",
+                 "strtltx", "strtlty", "fm", "tmass", "aiu", "umass", "uvel_init", "vvel_init"]
+
+
+def make_block_fields(case: SynthCase, d: Decomp) -> Dict[str, np.ndarray]:
+    """All arrays evp(dt) touches, in block layout, for the local blocks of `d`.
+    Prognostic state starts at rest (init_evp, ice_dyn_shared.F90:133-172)."""
+    f: Dict[str, np.ndarray] = {}
+    for n in GRID_FIELDS + INPUT_FIELDS:
+        f[n] = to_blocks(d, lambda I, J, n=n: case.field(n, I, J))
+    for n in MASK_FIELDS:
+        f[n] = to_blocks(d, lambda I, J, n=n: case.field(n, I, J), dtype=np.int32)
+    shp = (d.nblocks, d.ny_block, d.nx_block)
+    for n in STATE_FIELDS + OUTPUT_FIELDS:
+        f[n] = np.zeros(shp, dtype=np.float64)
+    f["iceumask"] = np.zeros(shp, dtype=np.int32)
+    f["icetmask"] = np.zeros(shp, dtype=np.int32)
+    return f
+
+
+def global_min_dx(case: SynthCase) -> float:
+    """min(global_minval(dxt, tmask), global_minval(dyt, tmask)) of ice_dyn_shared.F90:221-223."""
+    I = np.arange(1, case.nx + 1)[None, :]
+    J = np.arange(1, case.ny + 1)[:, None]
+    m = case.field("tmask", I, J) > 0
+    if not m.any():
+        return 1.0
+    return float(min(case.field("dxt", I, J)[m].min(), case.field("dyt", I, J)[m].min()))

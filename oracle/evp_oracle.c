@@ -1,0 +1,673 @@
+/*
+ * oracle/evp_oracle.c -- CPU restatement of the CICE5 EVP dynamics path (plain C99).
+ *
+ * TEST INFRASTRUCTURE ONLY (see evp_oracle.h).  PARITY UNPINNED (see evp_oracle.h).
+ *
+ * Every routine follows the operation order of the Fortran it cites, with
+ * -ffp-contract=off so that no multiply-add is fused.  Fortran evaluates
+ * a + b + c as (a + b) + c and a*b*c as (a*b)*c; the C below is written the same way.
+ */
+#include "evp_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* Fortran (i,j) 1-based -> flat index of one (nx,ny) block */
+#define IX(i, j) ((size_t)((j)-1) * (size_t)nx + (size_t)((i)-1))
+
+/* ice_constants.F90:136-148 (drivers/auscom/ice_constants.F90:180-188) */
+static const double c0 = 0.0, c1 = 1.0, c2 = 2.0, c4 = 4.0;
+static const double p25 = 0.25, p5 = 0.5;
+#define P166 (1.0 / 6.0)
+#define P333 (1.0 / 3.0)
+#define P111 (1.0 / 9.0)
+#define P055 ((1.0 / 9.0) * 0.5)
+#define P027 (((1.0 / 9.0) * 0.5) * 0.5)
+#define P222 (2.0 / 9.0)
+static const double puny = 1.0e-11;
+static const double spval_dbl = 1.0e30;
+
+static double wall(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---------------------------------------------------------------------------
+ * set_evp_parameters  (source/ice_dyn_shared.F90:185-259)
+ * xmin = min(global_minval(dxt,tmask), global_minval(dyt,tmask)) is supplied.
+ * ------------------------------------------------------------------------- */
+void orc_set_evp_parameters(double dt, int32_t ndte, int32_t revised_evp, double xmin, orc_params *p) {
+    const double eyc = 0.36;                        /* :51 */
+    double dte = dt / (double)ndte;                 /* :209 */
+    p->dt = dt;
+    p->ndte = ndte;
+    p->revised_evp = revised_evp;
+    p->dtei = c1 / dte;                             /* :210 */
+    p->ecci = p25;                                  /* :214 */
+    double tdamp2 = c2 * eyc * dt;                  /* :217 */
+    p->dte2T = dte / tdamp2;                        /* :218 */
+    double Se = 0.86, xi = 5.5e-3;                  /* :226-227 */
+    double gamma = p25 * 1.e11 * dt;                /* :228 */
+    if (revised_evp) {                              /* :230-233 */
+        p->revp = c1;
+        p->arlx1i = c2 * xi / Se;
+        p->brlx = c2 * Se * xi * gamma / (xmin * xmin);
+    } else {                                        /* :239-242 */
+        p->revp = c0;
+        p->arlx1i = p->dte2T;
+        p->brlx = dt * p->dtei;
+    }
+    p->denom1 = c1 / (c1 + p->arlx1i);              /* :257 */
+}
+
+/* ---------------------------------------------------------------------------
+ * evp_prep1  (source/ice_dyn_shared.F90:270-365)
+ * ------------------------------------------------------------------------- */
+void orc_evp_prep1(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                   const double *aice, const double *vice, const double *vsno, const int32_t *tmask,
+                   const double *strairxT, const double *strairyT,
+                   double *strairx, double *strairy, double *tmass, int32_t *icetmask,
+                   const orc_params *p) {
+    unsigned char *tmphm = (unsigned char *)malloc((size_t)nx * ny);
+    for (int j = 1; j <= ny; j++)
+        for (int i = 1; i <= nx; i++) {
+            size_t k = IX(i, j);
+            if (tmask[k])                                               /* :322-326 */
+                tmass[k] = (p->rhoi * vice[k] + p->rhos * vsno[k]);
+            else
+                tmass[k] = c0;
+            tmphm[k] = tmask[k] && (aice[k] > p->a_min) && (tmass[k] > p->m_min); /* :331-332 */
+            strairx[k] = strairxT[k];                                   /* :339-340 */
+            strairy[k] = strairyT[k];
+            icetmask[k] = 0;                                            /* :345 */
+        }
+    for (int j = jlo; j <= jhi; j++)
+        for (int i = ilo; i <= ihi; i++) {                              /* :350-363 */
+            if (tmphm[IX(i - 1, j + 1)] || tmphm[IX(i, j + 1)] || tmphm[IX(i + 1, j + 1)] ||
+                tmphm[IX(i - 1, j)]     || tmphm[IX(i, j)]     || tmphm[IX(i + 1, j)] ||
+                tmphm[IX(i - 1, j - 1)] || tmphm[IX(i, j - 1)] || tmphm[IX(i + 1, j - 1)])
+                icetmask[IX(i, j)] = 1;
+            if (!tmask[IX(i, j)]) icetmask[IX(i, j)] = 0;
+        }
+    free(tmphm);
+}
+
+/* ---------------------------------------------------------------------------
+ * to_ugrid / to_tgrid, one block  (source/ice_grid.F90:1834-1878, 1924-1958)
+ * ------------------------------------------------------------------------- */
+void orc_to_ugrid_blk(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                      const double *work1, const double *tarea, const double *uarea, double *work2) {
+    for (size_t k = 0; k < (size_t)nx * ny; k++) work2[k] = c0;          /* :1853 */
+    for (int j = jlo; j <= jhi; j++)
+        for (int i = ilo; i <= ihi; i++)                                 /* :1865-1870 */
+            work2[IX(i, j)] = p25 *
+                (((work1[IX(i, j)] * tarea[IX(i, j)]
+                 + work1[IX(i + 1, j)] * tarea[IX(i + 1, j)])
+                 + work1[IX(i, j + 1)] * tarea[IX(i, j + 1)])
+                 + work1[IX(i + 1, j + 1)] * tarea[IX(i + 1, j + 1)])
+                / uarea[IX(i, j)];
+}
+
+void orc_to_tgrid_blk(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                      const double *work1, const double *tarea, const double *uarea, double *work2) {
+    (void)ny;
+    for (int j = jlo; j <= jhi; j++)
+        for (int i = ilo; i <= ihi; i++)                                 /* :1946-1952 */
+            work2[IX(i, j)] = p25 *
+                (((work1[IX(i, j)] * uarea[IX(i, j)]
+                 + work1[IX(i - 1, j)] * uarea[IX(i - 1, j)])
+                 + work1[IX(i, j - 1)] * uarea[IX(i, j - 1)])
+                 + work1[IX(i - 1, j - 1)] * uarea[IX(i - 1, j - 1)])
+                / tarea[IX(i, j)];
+}
+
+/* ---------------------------------------------------------------------------
+ * evp_prep2  (source/ice_dyn_shared.F90:377-614)
+ * ------------------------------------------------------------------------- */
+void orc_evp_prep2(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                   int32_t *icellt, int32_t *icellu,
+                   int32_t *indxti, int32_t *indxtj, int32_t *indxui, int32_t *indxuj,
+                   const double *aiu, const double *umass, double *umassdti, const double *fcor,
+                   const int32_t *umask, const double *uocn, const double *vocn,
+                   const double *strairx, const double *strairy,
+                   const double *ss_tltx, const double *ss_tlty,
+                   const int32_t *icetmask, int32_t *iceumask, double *fm, double dt,
+                   double *strtltx, double *strtlty, double *strocnx, double *strocny,
+                   double *strintx, double *strinty, double *waterx, double *watery,
+                   double *forcex, double *forcey,
+                   double *const stressp[4], double *const stressm[4], double *const stress12[4],
+                   double *uvel_init, double *vvel_init, double *uvel, double *vvel,
+                   const orc_params *p) {
+    for (int j = 1; j <= ny; j++)
+        for (int i = 1; i <= nx; i++) {                                  /* :484-520 */
+            size_t k = IX(i, j);
+            waterx[k] = c0; watery[k] = c0; forcex[k] = c0; forcey[k] = c0; umassdti[k] = c0;
+            if (p->revp == 1 || icetmask[k] == 0)
+                for (int c = 0; c < 4; c++) { stressp[c][k] = c0; stressm[c][k] = c0; stress12[c][k] = c0; }
+        }
+
+    int nt = 0;                                                          /* :528-537 */
+    for (int j = jlo; j <= jhi + 1; j++)
+        for (int i = ilo; i <= ihi + 1; i++)
+            if (icetmask[IX(i, j)] == 1) { indxti[nt] = i; indxtj[nt] = j; nt++; }
+    *icellt = nt;
+
+    int nu = 0;                                                          /* :545-577 */
+    for (int j = jlo; j <= jhi; j++)
+        for (int i = ilo; i <= ihi; i++) {
+            size_t k = IX(i, j);
+            int old = iceumask[k];
+            iceumask[k] = umask[k] && (aiu[k] > p->a_min) && (umass[k] > p->m_min);
+            if (iceumask[k]) {
+                indxui[nu] = i; indxuj[nu] = j; nu++;
+                if (!old) { uvel[k] = uocn[k]; vvel[k] = vocn[k]; }
+            } else {
+                uvel[k] = c0; vvel[k] = c0;
+                strintx[k] = c0; strinty[k] = c0; strocnx[k] = c0; strocny[k] = c0;
+            }
+            uvel_init[k] = uvel[k];
+            vvel_init[k] = vvel[k];
+        }
+    *icellu = nu;
+
+    for (int ij = 0; ij < nu; ij++) {                                    /* :583-612 */
+        size_t k = IX(indxui[ij], indxuj[ij]);
+        umassdti[k] = umass[k] / dt;
+        fm[k] = fcor[k] * umass[k];
+        double sg = copysign(c1, fm[k]);
+        waterx[k] = uocn[k] * p->cosw - vocn[k] * p->sinw * sg;
+        watery[k] = vocn[k] * p->cosw + uocn[k] * p->sinw * sg;
+        if (p->tilt_from_slope) {
+            strtltx[k] = -p->gravit * umass[k] * ss_tltx[k];
+            strtlty[k] = -p->gravit * umass[k] * ss_tlty[k];
+        } else {
+            strtltx[k] = -fm[k] * vocn[k];
+            strtlty[k] = fm[k] * uocn[k];
+        }
+        forcex[k] = strairx[k] + strtltx[k];
+        forcey[k] = strairy[k] + strtlty[k];
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * stress  (source/ice_dyn_evp.F90:520-849)
+ * str is (nx,ny,8): str[(c-1)*nx*ny + IX(i,j)]
+ * ------------------------------------------------------------------------- */
+void orc_stress(int nx, int ny, int ksub, int ndte, int icellt,
+                const int32_t *indxti, const int32_t *indxtj,
+                const double *uvel, const double *vvel,
+                const double *dxt, const double *dyt, const double *dxhy, const double *dyhx,
+                const double *cxp, const double *cyp, const double *cxm, const double *cym,
+                const double *tarear, const double *tinyarea, const double *strength,
+                double *const stressp[4], double *const stressm[4], double *const stress12[4],
+                double *shear, double *divu, double *prs_sig, double *rdg_conv, double *rdg_shear,
+                double *str, const orc_params *p) {
+    const size_t nn = (size_t)nx * ny;
+    const double ecci = p->ecci, arlx1i = p->arlx1i, denom1 = p->denom1;
+    double *stressp_1 = stressp[0], *stressp_2 = stressp[1], *stressp_3 = stressp[2], *stressp_4 = stressp[3];
+    double *stressm_1 = stressm[0], *stressm_2 = stressm[1], *stressm_3 = stressm[2], *stressm_4 = stressm[3];
+    double *stress12_1 = stress12[0], *stress12_2 = stress12[1], *stress12_3 = stress12[2], *stress12_4 = stress12[3];
+
+    memset(str, 0, 8 * nn * sizeof(double));                              /* :613 */
+
+    for (int ij = 0; ij < icellt; ij++) {
+        const int i = indxti[ij], j = indxtj[ij];
+        const size_t k = IX(i, j);
+        const double u_ij = uvel[IX(i, j)], u_mj = uvel[IX(i - 1, j)];
+        const double u_im = uvel[IX(i, j - 1)], u_mm = uvel[IX(i - 1, j - 1)];
+        const double v_ij = vvel[IX(i, j)], v_mj = vvel[IX(i - 1, j)];
+        const double v_im = vvel[IX(i, j - 1)], v_mm = vvel[IX(i - 1, j - 1)];
+        const double Cyp = cyp[k], Cxp = cxp[k], Cym = cym[k], Cxm = cxm[k], Dxt = dxt[k], Dyt = dyt[k];
+
+        /* :627-634 divergence */
+        double divune = Cyp * u_ij - Dyt * u_mj + Cxp * v_ij - Dxt * v_im;
+        double divunw = Cym * u_mj + Dyt * u_ij + Cxp * v_mj - Dxt * v_mm;
+        double divusw = Cym * u_mm + Dyt * u_im + Cxm * v_mm + Dxt * v_mj;
+        double divuse = Cyp * u_im - Dyt * u_mm + Cxm * v_im + Dxt * v_ij;
+        /* :637-644 tension */
+        double tensionne = -Cym * u_ij - Dyt * u_mj + Cxm * v_ij + Dxt * v_im;
+        double tensionnw = -Cyp * u_mj + Dyt * u_ij + Cxm * v_mj + Dxt * v_mm;
+        double tensionsw = -Cyp * u_mm + Dyt * u_im + Cxp * v_mm - Dxt * v_mj;
+        double tensionse = -Cym * u_im - Dyt * u_mm + Cxp * v_im - Dxt * v_ij;
+        /* :647-654 shearing */
+        double shearne = -Cym * v_ij - Dyt * v_mj - Cxm * u_ij - Dxt * u_im;
+        double shearnw = -Cyp * v_mj + Dyt * v_ij - Cxm * u_mj - Dxt * u_mm;
+        double shearsw = -Cyp * v_mm + Dyt * v_im - Cxp * u_mm + Dxt * u_mj;
+        double shearse = -Cym * v_im - Dyt * v_mm - Cxp * u_im + Dxt * u_ij;
+        /* :657-660 Delta */
+        double Deltane = sqrt(divune * divune + ecci * (tensionne * tensionne + shearne * shearne));
+        double Deltanw = sqrt(divunw * divunw + ecci * (tensionnw * tensionnw + shearnw * shearnw));
+        double Deltase = sqrt(divuse * divuse + ecci * (tensionse * tensionse + shearse * shearse));
+        double Deltasw = sqrt(divusw * divusw + ecci * (tensionsw * tensionsw + shearsw * shearsw));
+
+        if (ksub == ndte) {                                               /* :665-677 */
+            divu[k] = p25 * (divune + divunw + divuse + divusw) * tarear[k];
+            double tmp = p25 * (Deltane + Deltanw + Deltase + Deltasw) * tarear[k];
+            rdg_conv[k] = -fmin(divu[k], c0);
+            rdg_shear[k] = p5 * (tmp - fabs(divu[k]));
+            double ts = tensionne + tensionnw + tensionse + tensionsw;
+            double ss = shearne + shearnw + shearse + shearsw;
+            shear[k] = p25 * tarear[k] * sqrt(ts * ts + ss * ss);
+        }
+
+        /* :683-697 replacement pressure */
+        double c0ne = strength[k] / fmax(Deltane, tinyarea[k]);
+        double c0nw = strength[k] / fmax(Deltanw, tinyarea[k]);
+        double c0sw = strength[k] / fmax(Deltasw, tinyarea[k]);
+        double c0se = strength[k] / fmax(Deltase, tinyarea[k]);
+        prs_sig[k] = c0ne * Deltane;
+        double c1ne = c0ne * arlx1i, c1nw = c0nw * arlx1i, c1sw = c0sw * arlx1i, c1se = c0se * arlx1i;
+        c0ne = c1ne * ecci; c0nw = c1nw * ecci; c0sw = c1sw * ecci; c0se = c1se * ecci;
+
+        /* :704-721 the stresses */
+        stressp_1[k] = (stressp_1[k] + c1ne * (divune - Deltane)) * denom1;
+        stressp_2[k] = (stressp_2[k] + c1nw * (divunw - Deltanw)) * denom1;
+        stressp_3[k] = (stressp_3[k] + c1sw * (divusw - Deltasw)) * denom1;
+        stressp_4[k] = (stressp_4[k] + c1se * (divuse - Deltase)) * denom1;
+        stressm_1[k] = (stressm_1[k] + c0ne * tensionne) * denom1;
+        stressm_2[k] = (stressm_2[k] + c0nw * tensionnw) * denom1;
+        stressm_3[k] = (stressm_3[k] + c0sw * tensionsw) * denom1;
+        stressm_4[k] = (stressm_4[k] + c0se * tensionse) * denom1;
+        stress12_1[k] = (stress12_1[k] + c0ne * shearne * p5) * denom1;
+        stress12_2[k] = (stress12_2[k] + c0nw * shearnw * p5) * denom1;
+        stress12_3[k] = (stress12_3[k] + c0sw * shearsw * p5) * denom1;
+        stress12_4[k] = (stress12_4[k] + c0se * shearse * p5) * denom1;
+
+        /* :752-771 combinations */
+        double ssigpn = stressp_1[k] + stressp_2[k];
+        double ssigps = stressp_3[k] + stressp_4[k];
+        double ssigpe = stressp_1[k] + stressp_4[k];
+        double ssigpw = stressp_2[k] + stressp_3[k];
+        double ssigp1 = (stressp_1[k] + stressp_3[k]) * P055;
+        double ssigp2 = (stressp_2[k] + stressp_4[k]) * P055;
+        double ssigmn = stressm_1[k] + stressm_2[k];
+        double ssigms = stressm_3[k] + stressm_4[k];
+        double ssigme = stressm_1[k] + stressm_4[k];
+        double ssigmw = stressm_2[k] + stressm_3[k];
+        double ssigm1 = (stressm_1[k] + stressm_3[k]) * P055;
+        double ssigm2 = (stressm_2[k] + stressm_4[k]) * P055;
+        double ssig12n = stress12_1[k] + stress12_2[k];
+        double ssig12s = stress12_3[k] + stress12_4[k];
+        double ssig12e = stress12_1[k] + stress12_4[k];
+        double ssig12w = stress12_2[k] + stress12_3[k];
+        double ssig121 = (stress12_1[k] + stress12_3[k]) * P111;
+        double ssig122 = (stress12_2[k] + stress12_4[k]) * P111;
+        /* :773-790 */
+        double csigpne = P111 * stressp_1[k] + ssigp2 + P027 * stressp_3[k];
+        double csigpnw = P111 * stressp_2[k] + ssigp1 + P027 * stressp_4[k];
+        double csigpsw = P111 * stressp_3[k] + ssigp2 + P027 * stressp_1[k];
+        double csigpse = P111 * stressp_4[k] + ssigp1 + P027 * stressp_2[k];
+        double csigmne = P111 * stressm_1[k] + ssigm2 + P027 * stressm_3[k];
+        double csigmnw = P111 * stressm_2[k] + ssigm1 + P027 * stressm_4[k];
+        double csigmsw = P111 * stressm_3[k] + ssigm2 + P027 * stressm_1[k];
+        double csigmse = P111 * stressm_4[k] + ssigm1 + P027 * stressm_2[k];
+        double csig12ne = P222 * stress12_1[k] + ssig122 + P055 * stress12_3[k];
+        double csig12nw = P222 * stress12_2[k] + ssig121 + P055 * stress12_4[k];
+        double csig12sw = P222 * stress12_3[k] + ssig122 + P055 * stress12_1[k];
+        double csig12se = P222 * stress12_4[k] + ssig121 + P055 * stress12_2[k];
+        /* :792-795 */
+        double str12ew = p5 * Dxt * (P333 * ssig12e + P166 * ssig12w);
+        double str12we = p5 * Dxt * (P333 * ssig12w + P166 * ssig12e);
+        double str12ns = p5 * Dyt * (P333 * ssig12n + P166 * ssig12s);
+        double str12sn = p5 * Dyt * (P333 * ssig12s + P166 * ssig12n);
+
+        const double Dxhy = dxhy[k], Dyhx = dyhx[k];
+        /* :800-820 dF/dx */
+        double strp_tmp = p25 * Dyt * (P333 * ssigpn + P166 * ssigps);
+        double strm_tmp = p25 * Dyt * (P333 * ssigmn + P166 * ssigms);
+        str[0 * nn + k] = -strp_tmp - strm_tmp - str12ew + Dxhy * (-csigpne + csigmne) + Dyhx * csig12ne;
+        str[1 * nn + k] = strp_tmp + strm_tmp - str12we + Dxhy * (-csigpnw + csigmnw) + Dyhx * csig12nw;
+        strp_tmp = p25 * Dyt * (P333 * ssigps + P166 * ssigpn);
+        strm_tmp = p25 * Dyt * (P333 * ssigms + P166 * ssigmn);
+        str[2 * nn + k] = -strp_tmp - strm_tmp + str12ew + Dxhy * (-csigpse + csigmse) + Dyhx * csig12se;
+        str[3 * nn + k] = strp_tmp + strm_tmp + str12we + Dxhy * (-csigpsw + csigmsw) + Dyhx * csig12sw;
+        /* :825-845 dF/dy */
+        strp_tmp = p25 * Dxt * (P333 * ssigpe + P166 * ssigpw);
+        strm_tmp = p25 * Dxt * (P333 * ssigme + P166 * ssigmw);
+        str[4 * nn + k] = -strp_tmp + strm_tmp - str12ns - Dyhx * (csigpne + csigmne) + Dxhy * csig12ne;
+        str[5 * nn + k] = strp_tmp - strm_tmp - str12sn - Dyhx * (csigpse + csigmse) + Dxhy * csig12se;
+        strp_tmp = p25 * Dxt * (P333 * ssigpw + P166 * ssigpe);
+        strm_tmp = p25 * Dxt * (P333 * ssigmw + P166 * ssigme);
+        str[6 * nn + k] = -strp_tmp + strm_tmp + str12ns - Dyhx * (csigpnw + csigmnw) + Dxhy * csig12nw;
+        str[7 * nn + k] = strp_tmp - strm_tmp + str12sn - Dyhx * (csigpsw + csigmsw) + Dxhy * csig12sw;
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * stepu  (source/ice_dyn_shared.F90:623-748)
+ * ------------------------------------------------------------------------- */
+void orc_stepu(int nx, int ny, int icellu, const double *Cw,
+               const int32_t *indxui, const int32_t *indxuj,
+               const double *aiu, const double *str,
+               const double *uocn, const double *vocn, const double *waterx, const double *watery,
+               const double *forcex, const double *forcey, const double *umassdti, const double *fm,
+               const double *uarear, double *strocnx, double *strocny, double *strintx, double *strinty,
+               const double *uvel_init, const double *vvel_init, double *uvel, double *vvel,
+               const orc_params *p) {
+    const size_t nn = (size_t)nx * ny;
+    const double brlx = p->brlx, revp = p->revp, cosw = p->cosw, sinw = p->sinw, rhow = p->rhow;
+    for (int ij = 0; ij < icellu; ij++) {
+        const int i = indxui[ij], j = indxuj[ij];
+        const size_t k = IX(i, j);
+        double uold = uvel[k], vold = vvel[k];                            /* :704-705 */
+        double du = uocn[k] - uold, dv = vocn[k] - vold;
+        double vrel = aiu[k] * rhow * Cw[k] * sqrt(du * du + dv * dv);    /* :708-709 */
+        double taux = vrel * waterx[k];                                   /* :711-712 */
+        double tauy = vrel * watery[k];
+        double cca = (brlx + revp) * umassdti[k] + vrel * cosw;           /* :715 */
+        double ccb = fm[k] + copysign(c1, fm[k]) * vrel * sinw;           /* :720 */
+        double ab2 = cca * cca + ccb * ccb;                               /* :722 */
+        strintx[k] = uarear[k] *                                          /* :725-728 */
+            (((str[0 * nn + IX(i, j)] + str[1 * nn + IX(i + 1, j)]) + str[2 * nn + IX(i, j + 1)]) + str[3 * nn + IX(i + 1, j + 1)]);
+        strinty[k] = uarear[k] *
+            (((str[4 * nn + IX(i, j)] + str[5 * nn + IX(i, j + 1)]) + str[6 * nn + IX(i + 1, j)]) + str[7 * nn + IX(i + 1, j + 1)]);
+        double cc1 = strintx[k] + forcex[k] + taux + umassdti[k] * (brlx * uold + revp * uvel_init[k]); /* :731-734 */
+        double cc2 = strinty[k] + forcey[k] + tauy + umassdti[k] * (brlx * vold + revp * vvel_init[k]);
+        uvel[k] = (cca * cc1 + ccb * cc2) / ab2;                          /* :736-737 */
+        vvel[k] = (cca * cc2 - ccb * cc1) / ab2;
+        strocnx[k] = taux;                                                /* :743-744 */
+        strocny[k] = tauy;
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * evp_finish  (source/ice_dyn_shared.F90:757-844)
+ * ------------------------------------------------------------------------- */
+void orc_evp_finish(int nx, int ny, int icellu, const double *Cw,
+                    const int32_t *indxui, const int32_t *indxuj,
+                    const double *uvel, const double *vvel, const double *uocn, const double *vocn,
+                    const double *aiu, const double *fm,
+                    double *strocnx, double *strocny, double *strocnxT, double *strocnyT,
+                    const orc_params *p) {
+    for (size_t k = 0; k < (size_t)nx * ny; k++) { strocnxT[k] = c0; strocnyT[k] = c0; }  /* :806-811 */
+    for (int ij = 0; ij < icellu; ij++) {
+        const size_t k = IX(indxui[ij], indxuj[ij]);
+        double du = uocn[k] - uvel[k], dv = vocn[k] - vvel[k];
+        double vrel = p->rhow * Cw[k] * sqrt(du * du + dv * dv);          /* :818-819 */
+        vrel = vrel * aiu[k];                                             /* :827 */
+        double sg = copysign(c1, fm[k]);
+        strocnx[k] = vrel * (du * p->cosw - dv * p->sinw * sg);           /* :828-831 */
+        strocny[k] = vrel * (dv * p->cosw + du * p->sinw * sg);
+        strocnxT[k] = strocnx[k] / aiu[k];                                /* :840-841 */
+        strocnyT[k] = strocny[k] / aiu[k];
+    }
+}
+
+/* principal_stress  (source/ice_dyn_shared.F90:853-893) */
+void orc_principal_stress(int nx, int ny, const double *stressp_1, const double *stressm_1,
+                          const double *stress12_1, const double *prs_sig, double *sig1, double *sig2) {
+    for (size_t k = 0; k < (size_t)nx * ny; k++) {
+        if (prs_sig[k] > puny) {
+            double r = sqrt(stressm_1[k] * stressm_1[k] + c4 * (stress12_1[k] * stress12_1[k]));
+            sig1[k] = (p5 * (stressp_1[k] + r)) / prs_sig[k];
+            sig2[k] = (p5 * (stressp_1[k] - r)) / prs_sig[k];
+        } else {
+            sig1[k] = spval_dbl;
+            sig2[k] = spval_dbl;
+        }
+    }
+}
+
+/* Hibler (1979) strength, kstrength /= 1  (source/ice_mechred.F90:2258-2265; Pstar,Cstar :80-82) */
+void orc_strength_hibler(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                         const double *aice, const double *vice, double *strength) {
+    const double Pstar = 2.75e4, Cstar = 20.0;
+    (void)ny;
+    for (int j = jlo; j <= jhi; j++)
+        for (int i = ilo; i <= ihi; i++)
+            strength[IX(i, j)] = Pstar * vice[IX(i, j)] * exp(-Cstar * (c1 - aice[IX(i, j)]));
+}
+
+/* ---------------------------------------------------------------------------
+ * Halo updates.  Semantics of mpi/ice_boundary.F90 (ghost cells are first
+ * overwritten with `fill`, :1409-1416, :2625-2632), expressed through a global
+ * buffer: physical cells of all local blocks -> global array; every ghost cell
+ * then reads its global source.  E-W: cyclic wraps, open/closed have no source
+ * (ice_blocks.F90:455-480).  N-S: open/closed no source; tripole (u-fold) follows
+ * the copy-in/copy-out lists of serial/ice_boundary.F90:3717-3776 and the
+ * per-location offsets of :801-888:
+ *   buffer row 2 = physical row ny_global, row 1 = ny_global-1
+ *   center  : ghost(i,ny+1) = s*B(nx-i+1, row2)                 (top row untouched)
+ *   NEcorner: B(.,row2) symmetrised for i=1..nx/2-1 (:818-824); then
+ *             top(i,ny)   = s*B(nx-i, row2),  ghost(i,ny+1) = s*B(nx-i, row1),  index 0 -> nx
+ * ------------------------------------------------------------------------- */
+typedef struct { double *G; unsigned char *have; } gbuf;
+
+static int wrap_i(const orc_geom *g, int gi) {
+    if (gi < 1) return (g->ew_boundary == ORC_BND_CYCLIC) ? gi + g->nx_global : 0;
+    if (gi > g->nx_global) return (g->ew_boundary == ORC_BND_CYCLIC) ? gi - g->nx_global : 0;
+    return gi;
+}
+
+#define GIX(gi, gj) ((size_t)((gj)-1) * (size_t)g->nx_global + (size_t)((gi)-1))
+
+static void halo_generic(const orc_geom *g, double *a, const double *asrc, int loc, int kind, double fill,
+                         int stress_mode) {
+    const int nx = g->nx_block, ny = g->ny_block;
+    const int nxg = g->nx_global, nyg = g->ny_global;
+    const size_t nn = (size_t)nx * ny;
+    double *G = (double *)malloc(sizeof(double) * (size_t)nxg * nyg);
+    for (size_t k = 0; k < (size_t)nxg * nyg; k++) G[k] = fill;
+    for (int b = 0; b < g->nblocks; b++) {
+        const double *ab = asrc + (size_t)b * nn;
+        for (int j = g->jlo[b]; j <= g->jhi[b]; j++)
+            for (int i = g->ilo[b]; i <= g->ihi[b]; i++) {
+                int gi = g->iglob_lo[b] + (i - g->ilo[b]), gj = g->jglob_lo[b] + (j - g->jlo[b]);
+                G[GIX(gi, gj)] = ab[IX(i, j)];
+            }
+    }
+    const int tripole = (g->ns_boundary == ORC_BND_TRIPOLE);
+    const double s = (kind == ORC_KIND_VECTOR) ? -1.0 : 1.0;
+    double *top = NULL, *north = NULL;   /* 1-based global i */
+    if (tripole) {
+        top = (double *)malloc(sizeof(double) * (size_t)(nxg + 1));
+        north = (double *)malloc(sizeof(double) * (size_t)(nxg + 1));
+        double *row2 = (double *)malloc(sizeof(double) * (size_t)(nxg + 1));
+        for (int i = 1; i <= nxg; i++) row2[i] = G[GIX(i, nyg)];
+        if (loc == ORC_LOC_NECORNER && !stress_mode) {
+            for (int i = 1; i <= nxg / 2 - 1; i++) {                      /* serial/ice_boundary.F90:818-824 */
+                int id = nxg - i;
+                double x1 = row2[i], x2 = row2[id];
+                double xavg = 0.5 * (x1 + s * x2);
+                row2[i] = xavg;
+                row2[id] = s * xavg;
+            }
+            for (int i = 1; i <= nxg; i++) {
+                int is = nxg - i; if (is == 0) is = nxg;                  /* :874-876 */
+                top[i] = s * row2[is];
+                north[i] = s * G[GIX(is, nyg - 1)];
+            }
+        } else {
+            for (int i = 1; i <= nxg; i++) north[i] = s * row2[nxg - i + 1];
+        }
+        free(row2);
+    }
+    for (int b = 0; b < g->nblocks; b++) {
+        double *ab = a + (size_t)b * nn;
+        const int ilo = g->ilo[b], ihi = g->ihi[b], jlo = g->jlo[b], jhi = g->jhi[b];
+        const int top_block = tripole && (g->jglob_lo[b] + (jhi - jlo) == nyg);
+        for (int j = 1; j <= ny; j++)
+            for (int i = 1; i <= nx; i++) {
+                const int phys = (i >= ilo && i <= ihi && j >= jlo && j <= jhi);
+                int gi = wrap_i(g, g->iglob_lo[b] + (i - ilo));
+                int gj = g->jglob_lo[b] + (j - jlo);
+                if (stress_mode) {
+                    /* ice_HaloUpdate_stress: only the tripole north ghost row of array1 is written
+                       (serial/ice_boundary.F90:3330-3443); ghosts are NOT pre-filled. */
+                    if (top_block && j == jhi + 1 && i <= ihi + 1 && gi > 0) ab[IX(i, j)] = north[gi];
+                    continue;
+                }
+                if (phys) {
+                    if (top_block && j == jhi && loc == ORC_LOC_NECORNER) ab[IX(i, j)] = top[gi];
+                    continue;
+                }
+                double v = fill;
+                if (i > ihi + 1 || j > jhi + 1) { ab[IX(i, j)] = v; continue; }   /* padding */
+                if (gi > 0) {
+                    if (gj < 1) { if (g->ns_boundary == ORC_BND_CYCLIC) v = G[GIX(gi, gj + nyg)]; }
+                    else if (gj > nyg) {
+                        if (g->ns_boundary == ORC_BND_CYCLIC) v = G[GIX(gi, gj - nyg)];
+                        else if (tripole && gj == nyg + 1) v = north[gi];
+                    } else {
+                        v = G[GIX(gi, gj)];
+                        if (top_block && j == jhi && loc == ORC_LOC_NECORNER) v = top[gi];
+                    }
+                }
+                ab[IX(i, j)] = v;
+            }
+    }
+    free(G); free(top); free(north);
+}
+
+void orc_halo_r8(const orc_geom *g, double *a, int loc, int kind, double fill) {
+    halo_generic(g, a, a, loc, kind, fill, 0);
+}
+
+void orc_halo_stress(const orc_geom *g, double *a1, const double *a2) {
+    halo_generic(g, a1, a2, ORC_LOC_CENTER, ORC_KIND_SCALAR, 0.0, 1);
+}
+
+void orc_halo_i4(const orc_geom *g, int32_t *a, int32_t fill) {
+    /* integers in this path are 0/1 masks: exact in double */
+    size_t n = (size_t)g->nx_block * g->ny_block * g->nblocks;
+    double *t = (double *)malloc(n * sizeof(double));
+    for (size_t k = 0; k < n; k++) t[k] = (double)a[k];
+    halo_generic(g, t, t, ORC_LOC_CENTER, ORC_KIND_SCALAR, (double)fill, 0);
+    for (size_t k = 0; k < n; k++) a[k] = (int32_t)t[k];
+    free(t);
+}
+
+/* ---------------------------------------------------------------------------
+ * evp(dt)  (source/ice_dyn_evp.F90:68-510)
+ * ------------------------------------------------------------------------- */
+void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_override,
+             int64_t counts[2], double *loop_seconds) {
+    const int nx = g->nx_block, ny = g->ny_block, nb = g->nblocks;
+    const size_t nn = (size_t)nx * ny, tot = nn * nb;
+    double *waterx = calloc(tot, 8), *watery = calloc(tot, 8), *forcex = calloc(tot, 8), *forcey = calloc(tot, 8);
+    double *umassdti = calloc(tot, 8), *work1 = calloc(tot, 8);
+    int32_t *indxti = malloc(tot * 4), *indxtj = malloc(tot * 4), *indxui = malloc(tot * 4), *indxuj = malloc(tot * 4);
+    int32_t *icellt = calloc(nb, 4), *icellu = calloc(nb, 4);
+    double *sp[4], *sm[4], *s12[4];
+
+    for (int b = 0; b < nb; b++) {                                        /* :171-203 */
+        size_t o = (size_t)b * nn;
+        for (size_t k = 0; k < nn; k++) {
+            f->rdg_conv[o + k] = c0; f->rdg_shear[o + k] = c0; f->divu[o + k] = c0;
+            f->shear[o + k] = c0; f->prs_sig[o + k] = c0;
+        }
+        orc_evp_prep1(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b],
+                      f->aice + o, f->vice + o, f->vsno + o, f->tmask + o,
+                      f->strairxT + o, f->strairyT + o, f->strairx + o, f->strairy + o,
+                      f->tmass + o, f->icetmask + o, p);
+    }
+    orc_halo_i4(g, f->icetmask, 0);                                       /* :210-211 */
+
+    for (int b = 0; b < nb; b++) {                                        /* :218-219 */
+        size_t o = (size_t)b * nn;
+        orc_to_ugrid_blk(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], f->tmass + o, f->tarea + o, f->uarea + o, f->umass + o);
+        orc_to_ugrid_blk(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], f->aice_init + o, f->tarea + o, f->uarea + o, f->aiu + o);
+    }
+    if (p->wind_on_ugrid) {                                               /* :226-228 */
+        memcpy(f->strairx, f->strax, tot * 8);
+        memcpy(f->strairy, f->stray, tot * 8);
+    } else {                                                              /* :240-241, ice_grid.F90:1799-1823 */
+        double *w[2] = { f->strairx, f->strairy };
+        for (int c = 0; c < 2; c++) {
+            memcpy(work1, w[c], tot * 8);
+            orc_halo_r8(g, work1, ORC_LOC_CENTER, ORC_KIND_VECTOR, 0.0);
+            for (int b = 0; b < nb; b++) {
+                size_t o = (size_t)b * nn;
+                orc_to_ugrid_blk(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], work1 + o, f->tarea + o, f->uarea + o, w[c] + o);
+            }
+        }
+    }
+
+    for (int b = 0; b < nb; b++) {                                        /* :247-308 */
+        size_t o = (size_t)b * nn;
+        for (int c = 0; c < 4; c++) { sp[c] = f->stressp[c] + o; sm[c] = f->stressm[c] + o; s12[c] = f->stress12[c] + o; }
+        orc_evp_prep2(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], &icellt[b], &icellu[b],
+                      indxti + o, indxtj + o, indxui + o, indxuj + o,
+                      f->aiu + o, f->umass + o, umassdti + o, f->fcor + o, f->umask + o,
+                      f->uocn + o, f->vocn + o, f->strairx + o, f->strairy + o, f->ss_tltx + o, f->ss_tlty + o,
+                      f->icetmask + o, f->iceumask + o, f->fm + o, p->dt,
+                      f->strtltx + o, f->strtlty + o, f->strocnx + o, f->strocny + o,
+                      f->strintx + o, f->strinty + o, waterx + o, watery + o, forcex + o, forcey + o,
+                      sp, sm, s12, f->uvel_init + o, f->vvel_init + o, f->uvel + o, f->vvel + o, p);
+        /* ice_strength (:291-301) is an input here: f->strength already holds it on physical cells */
+    }
+    orc_halo_r8(g, f->strength, ORC_LOC_CENTER, ORC_KIND_SCALAR, 0.0);    /* :311-312 */
+    orc_halo_r8(g, f->uvel, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);      /* :314-315 (fld2 = u,v) */
+    orc_halo_r8(g, f->vvel, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);
+
+    int64_t nt = 0, nu = 0;
+    for (int b = 0; b < nb; b++) {
+        nu += icellu[b];
+        /* count physical T cells only (the N/E ghost T cells are redundant work) */
+        for (int ij = 0; ij < icellt[b]; ij++) {
+            size_t o = (size_t)b * nn + ij;
+            if (indxti[o] <= g->ihi[b] && indxtj[o] <= g->jhi[b]) nt++;
+        }
+    }
+    if (counts) { counts[0] = nt; counts[1] = nu; }
+
+    const int nsub = nsub_override > 0 ? nsub_override : p->ndte;
+    double t0 = wall();
+    for (int ksub = 1; ksub <= nsub; ksub++) {                            /* :336-410 */
+#pragma omp parallel
+        {
+            double *strtmp = (double *)malloc(8 * nn * sizeof(double));
+            double *tsp[4], *tsm[4], *ts12[4];
+#pragma omp for schedule(dynamic, 1)
+            for (int b = 0; b < nb; b++) {
+                size_t o = (size_t)b * nn;
+                for (int c = 0; c < 4; c++) { tsp[c] = f->stressp[c] + o; tsm[c] = f->stressm[c] + o; ts12[c] = f->stress12[c] + o; }
+                orc_stress(nx, ny, ksub, p->ndte, icellt[b], indxti + o, indxtj + o,
+                           f->uvel + o, f->vvel + o, f->dxt + o, f->dyt + o, f->dxhy + o, f->dyhx + o,
+                           f->cxp + o, f->cyp + o, f->cxm + o, f->cym + o, f->tarear + o, f->tinyarea + o,
+                           f->strength + o, tsp, tsm, ts12, f->shear + o, f->divu + o, f->prs_sig + o,
+                           f->rdg_conv + o, f->rdg_shear + o, strtmp, p);
+                orc_stepu(nx, ny, icellu[b], f->Cdn_ocn + o, indxui + o, indxuj + o, f->aiu + o, strtmp,
+                          f->uocn + o, f->vocn + o, waterx + o, watery + o, forcex + o, forcey + o,
+                          umassdti + o, f->fm + o, f->uarear + o, f->strocnx + o, f->strocny + o,
+                          f->strintx + o, f->strinty + o, f->uvel_init + o, f->vvel_init + o,
+                          f->uvel + o, f->vvel + o, p);
+            }
+            free(strtmp);
+        }
+        orc_halo_r8(g, f->uvel, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);  /* :392-400 */
+        orc_halo_r8(g, f->vvel, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);
+    }
+    if (loop_seconds) *loop_seconds = wall() - t0;
+
+    if (g->ns_boundary == ORC_BND_TRIPOLE) {                              /* :416-481 */
+        double **S[3] = { f->stressp, f->stressm, f->stress12 };
+        for (int t = 0; t < 3; t++) {
+            orc_halo_stress(g, S[t][0], S[t][2]);
+            orc_halo_stress(g, S[t][2], S[t][0]);
+            orc_halo_stress(g, S[t][1], S[t][3]);
+            orc_halo_stress(g, S[t][3], S[t][1]);
+        }
+    }
+
+    for (int b = 0; b < nb; b++) {                                        /* :487-503 */
+        size_t o = (size_t)b * nn;
+        orc_evp_finish(nx, ny, icellu[b], f->Cdn_ocn + o, indxui + o, indxuj + o, f->uvel + o, f->vvel + o,
+                       f->uocn + o, f->vocn + o, f->aiu + o, f->fm + o,
+                       f->strocnx + o, f->strocny + o, f->strocnxT + o, f->strocnyT + o, p);
+    }
+    double *w[2] = { f->strocnxT, f->strocnyT };                          /* :505-506, ice_grid.F90:1886-1910 */
+    for (int c = 0; c < 2; c++) {
+        memcpy(work1, w[c], tot * 8);
+        orc_halo_r8(g, work1, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);
+        for (int b = 0; b < nb; b++) {
+            size_t o = (size_t)b * nn;
+            orc_to_tgrid_blk(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], work1 + o, f->tarea + o, f->uarea + o, w[c] + o);
+        }
+    }
+
+    free(waterx); free(watery); free(forcex); free(forcey); free(umassdti); free(work1);
+    free(indxti); free(indxtj); free(indxui); free(indxuj); free(icellt); free(icellu);
+}

@@ -1,0 +1,151 @@
+/*
+ * oracle/evp_oracle.h -- CPU restatement of the CICE5 EVP dynamics path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (cice5_amd/, include/,
+ * fortran/) includes, links or calls this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may use it, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference (Fortran) cannot be built in this image without
+ * a stand-in for the netCDF Fortran module (source/ice_grid.F90:144,254,887 `use
+ * netcdf` unconditionally) and ships no tests / golden vectors.
+ * The only reference-produced numbers available are the init_evp printout
+ * recorded in SURVEY.md S8c (arlx=86.4, brlx=120, dte=30, tdamp=1296 for
+ * dt=3600, ndte=120), which tests/test_oracle.py checks.  Everything else is a
+ * line-by-line restatement of the Fortran, cited per function below.
+ *
+ * Array convention: every field is a Fortran-ordered block array
+ *   a(nx_block, ny_block, nblocks),  i fastest  (source/ice_state.F90:141-147)
+ * Fortran LOGICAL arrays (tmask, umask, iceumask) are int32 0/1 here.
+ * All indices in orc_geom are Fortran 1-based.
+ */
+#ifndef EVP_ORACLE_H
+#define EVP_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_BND_CYCLIC = 0, ORC_BND_OPEN = 1, ORC_BND_CLOSED = 2, ORC_BND_TRIPOLE = 3 };
+enum { ORC_LOC_CENTER = 1, ORC_LOC_NECORNER = 2 };        /* ice_constants.F90: field_loc_* */
+enum { ORC_KIND_SCALAR = 1, ORC_KIND_VECTOR = 2 };        /* ice_constants.F90: field_type_* */
+
+/* block decomposition as seen by one process (source/ice_blocks.F90:22-35) */
+typedef struct {
+    int32_t nx_global, ny_global;
+    int32_t nx_block, ny_block, nblocks;
+    int32_t ew_boundary, ns_boundary;
+    const int32_t *ilo, *ihi, *jlo, *jhi;   /* [nblocks] physical-domain bounds inside the block */
+    const int32_t *iglob_lo, *jglob_lo;     /* [nblocks] global (i,j) of cell (ilo,jlo) == this_block%i_glob(ilo), j_glob(jlo) */
+} orc_geom;
+
+/* scalars of source/ice_dyn_shared.F90:29-81 plus the constants evp uses */
+typedef struct {
+    double dt;
+    int32_t ndte;
+    int32_t revised_evp;
+    double revp, ecci, dtei, dte2T, denom1, arlx1i, brlx;
+    double cosw, sinw, dragio, rhow, rhoi, rhos, gravit;
+    double a_min, m_min;
+    int32_t tilt_from_slope;   /* 1: strtlt = -gravit*umass*ss_tlt (coupled / use_ocnslope), 0: geostrophic */
+    int32_t wind_on_ugrid;     /* 1: strairx/y := strax/stray (ACCESS, calc_strair=F), skip t2ugrid_vector */
+} orc_params;
+
+/* module-global state evp(dt) reads and writes */
+typedef struct {
+    /* grid (ice_grid.F90:48-77,112-117) */
+    const double *dxt, *dyt, *dxhy, *dyhx, *cxp, *cyp, *cxm, *cym;
+    const double *tarear, *uarear, *tinyarea, *tarea, *uarea, *fcor;
+    const int32_t *tmask, *umask;
+    /* inputs */
+    const double *aice, *vice, *vsno, *aice_init;
+    const double *strairxT, *strairyT, *strax, *stray;
+    const double *uocn, *vocn, *ss_tltx, *ss_tlty, *Cdn_ocn;
+    /* in/out */
+    double *strength;            /* in (already computed) */
+    double *uvel, *vvel;
+    double *stressp[4], *stressm[4], *stress12[4];
+    int32_t *iceumask;
+    /* out */
+    double *divu, *shear, *rdg_conv, *rdg_shear, *prs_sig;
+    double *strintx, *strinty, *strocnx, *strocny, *strocnxT, *strocnyT;
+    double *strairx, *strairy, *strtltx, *strtlty, *fm, *tmass;
+    double *aiu, *umass, *uvel_init, *vvel_init;
+    int32_t *icetmask;
+} orc_fields;
+
+void orc_set_evp_parameters(double dt, int32_t ndte, int32_t revised_evp, double xmin, orc_params *p);
+
+void orc_evp_prep1(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                   const double *aice, const double *vice, const double *vsno, const int32_t *tmask,
+                   const double *strairxT, const double *strairyT,
+                   double *strairx, double *strairy, double *tmass, int32_t *icetmask,
+                   const orc_params *p);
+
+void orc_to_ugrid_blk(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                      const double *work1, const double *tarea, const double *uarea, double *work2);
+void orc_to_tgrid_blk(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                      const double *work1, const double *tarea, const double *uarea, double *work2);
+
+void orc_evp_prep2(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                   int32_t *icellt, int32_t *icellu,
+                   int32_t *indxti, int32_t *indxtj, int32_t *indxui, int32_t *indxuj,
+                   const double *aiu, const double *umass, double *umassdti, const double *fcor,
+                   const int32_t *umask, const double *uocn, const double *vocn,
+                   const double *strairx, const double *strairy,
+                   const double *ss_tltx, const double *ss_tlty,
+                   const int32_t *icetmask, int32_t *iceumask, double *fm, double dt,
+                   double *strtltx, double *strtlty, double *strocnx, double *strocny,
+                   double *strintx, double *strinty, double *waterx, double *watery,
+                   double *forcex, double *forcey,
+                   double *const stressp[4], double *const stressm[4], double *const stress12[4],
+                   double *uvel_init, double *vvel_init, double *uvel, double *vvel,
+                   const orc_params *p);
+
+void orc_stress(int nx, int ny, int ksub, int ndte, int icellt,
+                const int32_t *indxti, const int32_t *indxtj,
+                const double *uvel, const double *vvel,
+                const double *dxt, const double *dyt, const double *dxhy, const double *dyhx,
+                const double *cxp, const double *cyp, const double *cxm, const double *cym,
+                const double *tarear, const double *tinyarea, const double *strength,
+                double *const stressp[4], double *const stressm[4], double *const stress12[4],
+                double *shear, double *divu, double *prs_sig, double *rdg_conv, double *rdg_shear,
+                double *str /* [8][ny][nx] */, const orc_params *p);
+
+void orc_stepu(int nx, int ny, int icellu, const double *Cw,
+               const int32_t *indxui, const int32_t *indxuj,
+               const double *aiu, const double *str,
+               const double *uocn, const double *vocn, const double *waterx, const double *watery,
+               const double *forcex, const double *forcey, const double *umassdti, const double *fm,
+               const double *uarear, double *strocnx, double *strocny, double *strintx, double *strinty,
+               const double *uvel_init, const double *vvel_init, double *uvel, double *vvel,
+               const orc_params *p);
+
+void orc_evp_finish(int nx, int ny, int icellu, const double *Cw,
+                    const int32_t *indxui, const int32_t *indxuj,
+                    const double *uvel, const double *vvel, const double *uocn, const double *vocn,
+                    const double *aiu, const double *fm,
+                    double *strocnx, double *strocny, double *strocnxT, double *strocnyT,
+                    const orc_params *p);
+
+void orc_principal_stress(int nx, int ny, const double *stressp_1, const double *stressm_1,
+                          const double *stress12_1, const double *prs_sig, double *sig1, double *sig2);
+
+void orc_strength_hibler(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                         const double *aice, const double *vice, double *strength);
+
+/* halo updates, MPI-backend semantics (ghost cells pre-filled with `fill`) */
+void orc_halo_r8(const orc_geom *g, double *a, int loc, int kind, double fill);
+void orc_halo_i4(const orc_geom *g, int32_t *a, int32_t fill);
+void orc_halo_stress(const orc_geom *g, double *a1, const double *a2);
+
+/* whole evp(dt): returns total active (icellt, icellu) over blocks through counts[2].
+   nsub_override > 0 runs that many subcycles instead of ndte (the "last subcycle"
+   diagnostics still fire on ksub == ndte only, as in the reference). */
+void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_override,
+             int64_t counts[2], double *loop_seconds /* wall time of the subcycle loop, may be NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

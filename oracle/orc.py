@@ -1,0 +1,141 @@
+"""ctypes front end of the CPU oracle (oracle/evp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the cice5_amd product path.
+PARITY UNPINNED (see oracle/evp_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libevp_oracle.so")
+
+c_i32p = ct.POINTER(ct.c_int32)
+c_f64p = ct.POINTER(ct.c_double)
+
+
+class OrcGeom(ct.Structure):
+    _fields_ = [("nx_global", ct.c_int32), ("ny_global", ct.c_int32),
+                ("nx_block", ct.c_int32), ("ny_block", ct.c_int32), ("nblocks", ct.c_int32),
+                ("ew_boundary", ct.c_int32), ("ns_boundary", ct.c_int32),
+                ("ilo", c_i32p), ("ihi", c_i32p), ("jlo", c_i32p), ("jhi", c_i32p),
+                ("iglob_lo", c_i32p), ("jglob_lo", c_i32p)]
+
+
+class OrcParams(ct.Structure):
+    _fields_ = [("dt", ct.c_double), ("ndte", ct.c_int32), ("revised_evp", ct.c_int32),
+                ("revp", ct.c_double), ("ecci", ct.c_double), ("dtei", ct.c_double), ("dte2T", ct.c_double),
+                ("denom1", ct.c_double), ("arlx1i", ct.c_double), ("brlx", ct.c_double),
+                ("cosw", ct.c_double), ("sinw", ct.c_double), ("dragio", ct.c_double),
+                ("rhow", ct.c_double), ("rhoi", ct.c_double), ("rhos", ct.c_double), ("gravit", ct.c_double),
+                ("a_min", ct.c_double), ("m_min", ct.c_double),
+                ("tilt_from_slope", ct.c_int32), ("wind_on_ugrid", ct.c_int32)]
+
+
+_F64_IN = ["dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
+           "tarear", "uarear", "tinyarea", "tarea", "uarea", "fcor"]
+_I32_IN = ["tmask", "umask"]
+_F64_IN2 = ["aice", "vice", "vsno", "aice_init", "strairxT", "strairyT", "strax", "stray",
+            "uocn", "vocn", "ss_tltx", "ss_tlty", "Cdn_ocn"]
+_F64_OUT = ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx", "strinty",
+            "strocnx", "strocny", "strocnxT", "strocnyT", "strairx", "strairy",
+            "strtltx", "strtlty", "fm", "tmass", "aiu", "umass", "uvel_init", "vvel_init"]
+
+
+class OrcFields(ct.Structure):
+    _fields_ = ([(n, c_f64p) for n in _F64_IN] + [(n, c_i32p) for n in _I32_IN] +
+                [(n, c_f64p) for n in _F64_IN2] +
+                [("strength", c_f64p), ("uvel", c_f64p), ("vvel", c_f64p),
+                 ("stressp", c_f64p * 4), ("stressm", c_f64p * 4), ("stress12", c_f64p * 4),
+                 ("iceumask", c_i32p)] +
+                [(n, c_f64p) for n in _F64_OUT] + [("icetmask", c_i32p)])
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "evp_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libevp_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ct.CDLL(_LIB_PATH)
+        _lib.orc_set_evp_parameters.argtypes = [ct.c_double, ct.c_int32, ct.c_int32, ct.c_double, ct.POINTER(OrcParams)]
+        _lib.orc_evp.argtypes = [ct.POINTER(OrcGeom), ct.POINTER(OrcParams), ct.POINTER(OrcFields), ct.c_int,
+                                 ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double)]
+        _lib.orc_halo_r8.argtypes = [ct.POINTER(OrcGeom), c_f64p, ct.c_int, ct.c_int, ct.c_double]
+        _lib.orc_halo_i4.argtypes = [ct.POINTER(OrcGeom), c_i32p, ct.c_int32]
+        _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
+        _lib.orc_principal_stress.argtypes = [ct.c_int, ct.c_int] + [c_f64p] * 6
+    return _lib
+
+
+def _p64(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_f64p)
+
+
+def _p32(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_i32p)
+
+
+def make_geom(d):
+    """d: cice5_amd.blocks.Decomp (duck-typed).  Returns (OrcGeom, keepalive)."""
+    ga = d.geom_arrays()
+    g = OrcGeom(d.nx_global, d.ny_global, d.nx_block, d.ny_block, d.nblocks, d.ew_boundary, d.ns_boundary,
+                _p32(ga["ilo"]), _p32(ga["ihi"]), _p32(ga["jlo"]), _p32(ga["jhi"]),
+                _p32(ga["iglob_lo"]), _p32(ga["jglob_lo"]))
+    return g, ga
+
+
+def make_params(dt: float, ndte: int, xmin: float, revised_evp: bool = False, cosw: float = 1.0, sinw: float = 0.0,
+                dragio: float = 0.00536, tilt_from_slope: bool = False, wind_on_ugrid: bool = False) -> OrcParams:
+    p = OrcParams()
+    lib().orc_set_evp_parameters(dt, ndte, int(revised_evp), xmin, ct.byref(p))
+    p.cosw, p.sinw, p.dragio = cosw, sinw, dragio
+    p.rhow, p.rhoi, p.rhos, p.gravit = 1026.0, 917.0, 330.0, 9.80616
+    p.a_min, p.m_min = 0.001, 0.01
+    p.tilt_from_slope, p.wind_on_ugrid = int(tilt_from_slope), int(wind_on_ugrid)
+    return p
+
+
+def make_fields(f: Dict[str, np.ndarray]) -> OrcFields:
+    o = OrcFields()
+    for n in _F64_IN + _F64_IN2 + _F64_OUT + ["strength", "uvel", "vvel"]:
+        setattr(o, n, _p64(f[n]))
+    for n in _I32_IN + ["iceumask", "icetmask"]:
+        setattr(o, n, _p32(f[n]))
+    for k in ("stressp", "stressm", "stress12"):
+        setattr(o, k, (c_f64p * 4)(*[_p64(f[f"{k}_{c}"]) for c in (1, 2, 3, 4)]))
+    return o
+
+
+def evp(d, params: OrcParams, f: Dict[str, np.ndarray], nsub: int = 0):
+    """Run the oracle's evp(dt) in place on the block-layout dict `f`.
+    Returns (icellt_phys, icellu, loop_seconds)."""
+    g, keep = make_geom(d)
+    of = make_fields(f)
+    counts = (ct.c_int64 * 2)()
+    secs = ct.c_double(0.0)
+    lib().orc_evp(ct.byref(g), ct.byref(params), ct.byref(of), int(nsub), counts, ct.byref(secs))
+    del keep
+    return int(counts[0]), int(counts[1]), float(secs.value)
+
+
+def halo_r8(d, a: np.ndarray, loc: int, kind: int, fill: float = 0.0):
+    g, keep = make_geom(d)
+    lib().orc_halo_r8(ct.byref(g), _p64(a), loc, kind, fill)
+    del keep
