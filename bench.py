@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- EVP subcycle throughput on N MI355X of one node.
+
+Metric (BASELINE.json): EVP subcycle cell-updates/s + % HBM roofline, 3600x2700, ndte=120.
+A step = one device-resident evp(dt): evp_prep1/2 + ndte x (fused stress+stepu kernel,
+velocity halo) + evp_finish, inputs already in HBM.  N > 1 shards the SAME grid into x-slabs
+(one ice_blocks block of 450x2700 per eighth of the grid), i.e. strong scaling, with the
+per-subcycle halo exchange over RCCL.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+ALG_BYTES_STRESS = 360      # 24 reads + 21 writes, fp64
+ALG_BYTES_STEPU = 232       # 23 reads + 6 writes
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", default="3600x2700")
+    ap.add_argument("--ndte", type=int, default=120)
+    ap.add_argument("--dt", type=float, default=450.0)
+    ap.add_argument("--ice", default="polar", choices=["polar", "full"])
+    ap.add_argument("--land", default="continents", choices=["continents", "rows"])
+    ap.add_argument("--ns", default="open", choices=["open", "tripole"])
+    ap.add_argument("--xblocks", type=int, default=8, help="blocks across x (one slab each at 8 GPUs)")
+    ap.add_argument("--yblocks", type=int, default=10, help="blocks across y")
+    ap.add_argument("--cpu-subcycles", type=int, default=6, help="subcycles of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per k_subcycle launch from a separate rocprofv3 --pmc pass (profiles/)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from cice5_amd import blocks, constants as C, dyn, evpk, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the EVP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    uid = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        box = [evpk.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, device=torch.device("cpu"))
+        uid = box[0]
+
+    nx, ny = (int(v) for v in a.grid.split("x"))
+    if nx % a.xblocks or a.xblocks % world or ny % a.yblocks:
+        raise SystemExit("grid / xblocks / yblocks / gpus do not divide")
+    bsx, bsy = nx // a.xblocks, ny // a.yblocks
+    case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[a.ns], land=a.land, ice=a.ice, dt=a.dt, ndte=a.ndte)
+    d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=a.ns)
+    t_gen = time.time()
+    f = synth.make_block_fields(case, d)
+    t_gen = time.time() - t_gen
+    # global_minval(dxt/dyt) of set_evp_parameters: local minimum, then MIN over ranks
+    xmin = dyn.local_min_dx(f, d)
+    if world > 1:
+        t = torch.tensor([xmin], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        xmin = float(t[0])
+
+    solver = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=local_rank, unique_id=uid)
+    solver.init_evp(a.dt)
+    ctx = solver.ctx
+    ctx.upload(f)                       # inputs resident in HBM from here on
+
+    def step():
+        ctx.prep()
+        ctx.subcycle(a.ndte)
+        ctx.finish()
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    loop_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        st = ctx.stats()                # HIP events around the ndte loop on the library's compute stream
+        loop_ms += st.loop_ms
+        launches += st.kernel_launches
+    fence()
+    dt_wall = time.perf_counter() - t0
+    st = ctx.stats()
+
+    vals = torch.tensor([dt_wall, float(st.icellt), float(st.icellu), loop_ms, float(launches)], dtype=torch.float64)
+    if world > 1:
+        tmax = vals[[0, 3]].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = vals[[1, 2, 4]].clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_wall, loop_ms = float(tmax[0]), float(tmax[1])
+        icellt, icellu, launches = float(tsum[0]), float(tsum[1]), float(tsum[2]) / world
+    else:
+        icellt, icellu = float(st.icellt), float(st.icellu)
+
+    n_active = 0.5 * (icellt + icellu)                  # one cell-update = one T stress + one U stepu update
+    updates = n_active * a.ndte * a.steps
+    value = updates / dt_wall
+    alg_bytes_launch = (ALG_BYTES_STRESS * icellt + ALG_BYTES_STEPU * icellu) / world   # per GPU per launch
+    kern_ms = loop_ms / max(launches, 1.0)              # average k_subcycle launch duration (event-bracketed loop / launches)
+    achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    out = {
+        "metric": "EVP subcycle cell-updates/sec", "value": value, "unit": "cell-updates/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_wall / a.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{nx}x{ny} ndte={a.ndte} ice={a.ice} land={a.land} ns={a.ns} "
+                               f"({a.xblocks * a.yblocks} ice_blocks blocks of {bsx}x{bsy}, x-slabs over {world} GPU)",
+                   "active_T_cells": int(icellt), "active_U_cells": int(icellu), "grid_cells": nx * ny,
+                   "grid_cell_updates_per_s": nx * ny * a.ndte * a.steps / dt_wall,
+                   "strips_per_launch_rank0": int(st.nstrips), "step": "prep + ndte x (stress+stepu, halo) + finish"},
+        "roofline": {"bound": "hbm", "kernel": "k_subcycle (fused stress+stepu)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": a.traffic_bytes, "alg_bytes_per_launch": alg_bytes_launch,
+                     "avg_launch_ms": kern_ms, "launches_timed": int(launches)},
+    }
+
+    if rank == 0 and world == 1 and a.cpu_subcycles > 0:
+        solver.init_evp(a.dt)          # the host arrays are still the uploaded inputs; state back at rest
+        out["cpu_baseline"] = cpu_baseline(d, f, a, xmin)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(d, f, a, xmin):
+    """The oracle (C restatement of the reference loop, OpenMP over blocks like the reference's
+    THRD build) on the host cores: the first few subcycles of the same workload, same blocks."""
+    from oracle import orc
+    p = orc.make_params(a.dt, a.ndte, xmin)
+    threads = orc._limit_threads()
+    nt, nu, secs = orc.evp(d, p, f, nsub=a.cpu_subcycles)
+    return {"value": 0.5 * (nt + nu) * a.cpu_subcycles / secs, "unit": "cell-updates/s", "cores": min(threads, d.nblocks),
+            "kind": "port",
+            "sample": f"first {a.cpu_subcycles} of {a.ndte} subcycles of the same {d.nx_global}x{d.ny_global} state "
+                      f"({d.nblocks} blocks of {d.block_size_x}x{d.block_size_y}, OpenMP over blocks: "
+                      f"stress + stepu + halo copies), {secs:.2f} s of CPU wall time"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,610 @@
+// evpk_api.hip -- host side of libevpk: the C ABI of include/evpk.h.
+//
+// Mirrors the control flow of subroutine evp (source/ice_dyn_evp.F90:68-510) on one HIP
+// stream: gather block arrays into the slab, evp_prep1 / to_ugrid / evp_prep2, halo
+// updates, ndte x (fused stress+stepu kernel, velocity halo), tripole stress fold,
+// evp_finish, u2tgrid, scatter back.  Multi-GPU: x-slabs on a ring, packed edge columns
+// exchanged with ncclSend/ncclRecv (RCCL over xGMI); the tripole fold all-gathers the two
+// top rows.  No CPU fallback exists: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/evpk.h"
+#include "evpk_internal.h"
+
+// single translation unit: the kernels are compiled together with the host API
+#include "evpk_kernels.hip"
+
+using namespace evpk;
+
+static thread_local std::string g_create_err;
+
+struct evpk_ctx {
+    Slab s{};
+    DevParams p{};
+    bool have_params = false, uploaded = false, prepped = false;
+    int nxb = 0, nyb = 0, nblocks = 0;
+    std::vector<BlockDesc> bd;
+    BlockDesc *d_bd = nullptr;
+    bool full_cover = true;
+    int ew = 0, ns = 0, rank = 0, nranks = 1, west = -1, east = -1, device = 0;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    double *stage = nullptr;   // nblocks*nyb*nxb doubles (also reused as int32)
+    size_t stage_n = 0;
+    // strips
+    int ncx = 0, nry = 0, R = 8, nstrips = 0;
+    unsigned char *d_flags = nullptr;
+    int *d_strips = nullptr;
+    unsigned long long *d_counts = nullptr;
+    long long icellt = 0, icellu = 0;
+    // exchange
+    int max_nf = NSTATE;
+    double *sendW = nullptr, *sendE = nullptr, *recvW = nullptr, *recvE = nullptr;
+    double *foldbuf = nullptr, *foldloc = nullptr, *foldall = nullptr;
+    int wmax = 0;
+    std::vector<int> slab_i0;   // nranks+1 global start columns
+    int *d_slab_i0 = nullptr;
+    int cur = 0, ksub = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;
+    float loop_ms = 0.f, kernel_ms = 0.f;
+    int kernel_launches = 0;
+    bool time_kernels = false;
+    std::string err;
+};
+
+#define FAIL(c, ...)                                   \
+    do {                                               \
+        char _b[512];                                  \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);         \
+        (c)->err = _b;                                 \
+        return 1;                                      \
+    } while (0)
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (call);                                                                  \
+        if (_e != hipSuccess) FAIL(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define NCCLCHK(c, call)                                                                         \
+    do {                                                                                         \
+        ncclResult_t _e = (call);                                                                \
+        if (_e != ncclSuccess) FAIL(c, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+static inline dim3 grid2d(const Slab &s, dim3 b) { return dim3((s.nxl + 2 + b.x - 1) / b.x, (s.nyl + 2 + b.y - 1) / b.y); }
+static const dim3 B2D(64, 4);
+
+extern "C" int evpk_slab_layout(int32_t nx_global, int32_t nranks, int32_t rank, int32_t ew_boundary,
+                                int32_t i0, int32_t i1, int32_t out[5]) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || i1 < i0 || i0 < 1 || i1 > nx_global) return 1;
+    int west = rank - 1, east = rank + 1;
+    if (west < 0) west = (ew_boundary == EVPK_BND_CYCLIC) ? nranks - 1 : -1;
+    if (east >= nranks) east = (ew_boundary == EVPK_BND_CYCLIC) ? 0 : -1;
+    if (nranks == 1) { west = east = (ew_boundary == EVPK_BND_CYCLIC) ? 0 : -1; }
+    out[0] = west; out[1] = east; out[2] = i0; out[3] = i1;
+    out[4] = (nx_global + nranks - 1) / nranks;
+    return 0;
+}
+
+extern "C" int evpk_get_unique_id(void *id) {
+    static_assert(sizeof(ncclUniqueId) <= EVPK_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return 1;
+    memset(id, 0, EVPK_UNIQUE_ID_BYTES);
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+extern "C" const char *evpk_last_error(const evpk_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+// ---- host<->device transfer of one field -------------------------------------------------
+template <typename T>
+static int upload_plane(evpk_ctx *c, const T *host, T *dev_plane) {
+    if (!host) return 0;
+    const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if (!c->full_cover)
+        HIPCHK(c, hipMemsetAsync(dev_plane, 0, (size_t)c->s.pitch * (c->s.nyl + 2) * sizeof(T), c->stream));
+    dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    hipLaunchKernelGGL(k_gather<T>, g, b, 0, c->stream, c->s, c->d_bd, c->nblocks, c->nxb, c->nyb, (const T *)c->stage, dev_plane);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int download_plane(evpk_ctx *c, T *host, const T *dev_plane, int mode) {
+    if (!host) return 0;
+    const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
+    // start from the caller's bytes so that untouched cells keep their values
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    hipLaunchKernelGGL(k_scatter<T>, g, b, 0, c->stream, c->s, c->d_bd, c->nblocks, c->nxb, c->nyb, dev_plane, (T *)c->stage, mode);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- halo update of nf consecutive planes starting at f ---------------------------------
+// fsrc_fold >= 0: ice_HaloUpdate_stress variant (only the tripole north ghost row of the
+// destination planes is written, from the top physical row of the source planes).
+static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1) {
+    Slab &s = c->s;
+    const int tx = 128;
+    const int gcol = (s.nxl + 2 + tx - 1) / tx, grow = (s.nyl + 2 + tx - 1) / tx;
+    const bool stress_mode = fsrc_fold >= 0;
+    if (nf > c->max_nf) FAIL(c, "halo: nf=%d exceeds buffer", nf);
+    if (c->ns == EVPK_BND_CYCLIC) FAIL(c, "ns_boundary_type cyclic is not supported");
+    // N-S
+    if (c->ns == EVPK_BND_TRIPOLE) {
+        if (!stress_mode) hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 0);
+        const int fp = stress_mode ? fsrc_fold : f;
+        if (c->nranks == 1) {
+            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, s, fp, nf, c->foldbuf, s.i0 - 1);
+        } else {
+            // pack own segment [nf][2][wmax], all-gather, re-pack into [nf][2][nxg]
+            HIPCHK(c, hipMemsetAsync(c->foldloc, 0, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax, c->stream));
+            Slab t = s; t.nxg = c->wmax;   // local segment addressed with gofs = 0
+            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, fp, nf, c->foldloc, 0);
+            const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
+            NCCLCHK(c, ncclAllGather(c->foldloc, c->foldall, seg, ncclDouble, c->comm, c->stream));
+            for (int r = 0; r < c->nranks; r++) {
+                const int w = c->slab_i0[r + 1] - c->slab_i0[r];
+                for (int q = 0; q < nf; q++)
+                    for (int rr = 0; rr < 2; rr++)
+                        HIPCHK(c, hipMemcpyAsync(c->foldbuf + ((size_t)q * 2 + rr) * s.nxg + (c->slab_i0[r] - 1),
+                                                 c->foldall + r * seg + ((size_t)q * 2 + rr) * c->wmax,
+                                                 sizeof(double) * w, hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+        hipLaunchKernelGGL(k_fold_apply, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->foldbuf,
+                           (necorner && !stress_mode) ? 1 : 0, (vector && !stress_mode) ? -1.0 : 1.0);
+        HIPCHK(c, hipGetLastError());
+        if (stress_mode) return 0;
+    } else {
+        hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 1);
+    }
+    // E-W over all rows (ghost rows included, which carries the corners)
+    if (c->nranks == 1) {
+        hipLaunchKernelGGL(k_halo_ew_local, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill);
+    } else {
+        const size_t cnt = (size_t)nf * (s.nyl + 2);
+        hipLaunchKernelGGL(k_ew_pack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->sendW, c->sendE);
+        NCCLCHK(c, ncclGroupStart());
+        if (c->west >= 0) NCCLCHK(c, ncclSend(c->sendW, cnt, ncclDouble, c->west, c->comm, c->stream));
+        if (c->east >= 0) NCCLCHK(c, ncclSend(c->sendE, cnt, ncclDouble, c->east, c->comm, c->stream));
+        if (c->east >= 0) NCCLCHK(c, ncclRecv(c->recvE, cnt, ncclDouble, c->east, c->comm, c->stream));
+        if (c->west >= 0) NCCLCHK(c, ncclRecv(c->recvW, cnt, ncclDouble, c->west, c->comm, c->stream));
+        NCCLCHK(c, ncclGroupEnd());
+        hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->recvW,
+                           (const double *)c->recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static void destroy_impl(evpk_ctx *c) {
+    if (!c) return;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
+                    c->d_strips, c->d_counts, c->sendW, c->sendE, c->recvW, c->recvE, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    for (auto e : c->kev) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int evpk_destroy(evpk_ctx *c) { destroy_impl(c); return 0; }
+
+static int create_impl(evpk_ctx *c, const evpk_geom *g) {
+    if (!g) FAIL(c, "geom is NULL");
+    if (g->nblocks < 1 || g->nx_block < 3 || g->ny_block < 3) FAIL(c, "bad block shape");
+    if (g->nranks < 1 || g->rank < 0 || g->rank >= g->nranks) FAIL(c, "bad rank/nranks");
+    if (g->ns_boundary == EVPK_BND_CYCLIC) FAIL(c, "ns_boundary_type cyclic is not supported");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(c, "no HIP device: libevpk has no CPU fallback");
+    if (g->device < 0 || g->device >= ndev) FAIL(c, "device %d out of range (%d devices)", g->device, ndev);
+    HIPCHK(c, hipSetDevice(g->device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, g->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, "device is %s, libevpk is built for gfx950 only", prop.gcnArchName);
+    c->device = g->device;
+    c->nxb = g->nx_block; c->nyb = g->ny_block; c->nblocks = g->nblocks;
+    c->ew = g->ew_boundary; c->ns = g->ns_boundary; c->rank = g->rank; c->nranks = g->nranks;
+
+    // slab = bounding rectangle of the local blocks
+    int i0 = 1 << 30, i1 = -1, j0 = 1 << 30, j1 = -1;
+    long long covered = 0;
+    c->bd.resize(g->nblocks);
+    for (int b = 0; b < g->nblocks; b++) {
+        BlockDesc d{g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], g->iglob_lo[b], g->jglob_lo[b]};
+        if (d.ilo < 2 || d.ihi > g->nx_block - 1 || d.ihi < d.ilo || d.jlo < 2 || d.jhi > g->ny_block - 1 || d.jhi < d.jlo)
+            FAIL(c, "block %d: bad ilo/ihi/jlo/jhi", b);
+        if (d.iglob_lo < 1 || d.jglob_lo < 1) FAIL(c, "block %d: bad global origin", b);
+        c->bd[b] = d;
+        i0 = std::min(i0, d.iglob_lo); i1 = std::max(i1, d.iglob_lo + d.ihi - d.ilo);
+        j0 = std::min(j0, d.jglob_lo); j1 = std::max(j1, d.jglob_lo + d.jhi - d.jlo);
+        covered += (long long)(d.ihi - d.ilo + 1) * (d.jhi - d.jlo + 1);
+    }
+    if (i1 > g->nx_global || j1 > g->ny_global) FAIL(c, "blocks exceed the global grid");
+    if (g->nranks > 1 && (j0 != 1 || j1 != g->ny_global))
+        FAIL(c, "multi-rank runs need x-slabs of whole columns (processor_shape slenderX1)");
+    if (g->nranks == 1 && (i0 != 1 || i1 != g->nx_global || j0 != 1 || j1 != g->ny_global)) {
+        // a single rank must see the whole domain, else its ghost ring has no source
+        FAIL(c, "single-rank context must cover the whole global grid (got i %d..%d, j %d..%d)", i0, i1, j0, j1);
+    }
+    Slab &s = c->s;
+    s.nxl = i1 - i0 + 1; s.nyl = j1 - j0 + 1; s.i0 = i0; s.j0 = j0; s.nxg = g->nx_global; s.nyg = g->ny_global;
+    if (g->ns_boundary == EVPK_BND_TRIPOLE && (s.nyl < 2 || (g->nx_global & 1))) FAIL(c, "tripole needs ny >= 2 and even nx_global");
+    c->full_cover = (covered == (long long)s.nxl * s.nyl);
+    s.pitch = ((C0 + s.nxl + 2 + 15) / 16) * 16;
+    s.fstride = (((size_t)s.pitch * (s.nyl + 2) + 64 + 15) / 16) * 16;   // +64: strips may read one lane past the row end
+
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+    HIPCHK(c, hipMalloc(&s.F, sizeof(double) * s.fstride * F_COUNT));
+    HIPCHK(c, hipMemsetAsync(s.F, 0, sizeof(double) * s.fstride * F_COUNT, c->stream));
+    HIPCHK(c, hipMalloc(&s.tmask, sizeof(int32_t) * s.fstride));
+    HIPCHK(c, hipMalloc(&s.umask, sizeof(int32_t) * s.fstride));
+    HIPCHK(c, hipMalloc(&s.iceumask, sizeof(int32_t) * s.fstride));
+    HIPCHK(c, hipMalloc(&s.cmask, s.fstride));
+    HIPCHK(c, hipMalloc(&s.tmphm, s.fstride));
+    HIPCHK(c, hipMemsetAsync(s.tmask, 0, sizeof(int32_t) * s.fstride, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.umask, 0, sizeof(int32_t) * s.fstride, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.iceumask, 0, sizeof(int32_t) * s.fstride, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.cmask, 0, s.fstride, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.tmphm, 0, s.fstride, c->stream));
+    HIPCHK(c, hipMalloc(&c->d_bd, sizeof(BlockDesc) * g->nblocks));
+    HIPCHK(c, hipMemcpyAsync(c->d_bd, c->bd.data(), sizeof(BlockDesc) * g->nblocks, hipMemcpyHostToDevice, c->stream));
+    c->stage_n = (size_t)g->nblocks * g->ny_block * g->nx_block;
+    HIPCHK(c, hipMalloc(&c->stage, sizeof(double) * c->stage_n));
+
+    // strips: 63 U columns x R U rows per wave.  Small slabs get short strips so that
+    // the chip still sees enough waves.
+    c->ncx = (s.nxl + 1 + STRIP_W - 1) / STRIP_W;
+    {
+        const char *e = getenv("EVPK_STRIP_ROWS");
+        int R = e ? atoi(e) : 0;
+        if (R <= 0) {
+            const long long cells = (long long)s.nxl * s.nyl;
+            R = cells >= 4000000 ? 16 : (cells >= 500000 ? 8 : 4);
+        }
+        c->R = std::max(1, std::min(R, 64));
+    }
+    c->nry = (s.nyl + 1 + c->R - 1) / c->R;
+    HIPCHK(c, hipMalloc(&c->d_flags, (size_t)c->ncx * c->nry));
+    HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * (size_t)c->ncx * c->nry));
+    HIPCHK(c, hipMalloc(&c->d_counts, sizeof(unsigned long long) * 2));
+
+    // neighbours on the slab ring
+    int lay[5];
+    evpk_slab_layout(g->nx_global, g->nranks, g->rank, g->ew_boundary, i0, i1, lay);
+    c->west = lay[0]; c->east = lay[1];
+    const size_t ebuf = sizeof(double) * (size_t)c->max_nf * (s.nyl + 2);
+    HIPCHK(c, hipMalloc(&c->sendW, ebuf)); HIPCHK(c, hipMalloc(&c->sendE, ebuf));
+    HIPCHK(c, hipMalloc(&c->recvW, ebuf)); HIPCHK(c, hipMalloc(&c->recvE, ebuf));
+    if (g->ns_boundary == EVPK_BND_TRIPOLE) {
+        HIPCHK(c, hipMalloc(&c->foldbuf, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg));
+        HIPCHK(c, hipMemsetAsync(c->foldbuf, 0, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg, c->stream));
+    }
+
+    if (g->nranks > 1) {
+        if (!g->unique_id) FAIL(c, "nranks > 1 needs unique_id");
+        ncclUniqueId u;
+        memcpy(&u, g->unique_id, sizeof(u));
+        NCCLCHK(c, ncclCommInitRank(&c->comm, g->nranks, u, g->rank));
+        // every rank learns all slab starts (for the tripole fold) : all-gather of i0
+        int *d_i0 = nullptr, *d_all = nullptr;
+        HIPCHK(c, hipMalloc(&d_i0, sizeof(int)));
+        HIPCHK(c, hipMalloc(&d_all, sizeof(int) * g->nranks));
+        HIPCHK(c, hipMemcpyAsync(d_i0, &i0, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        NCCLCHK(c, ncclAllGather(d_i0, d_all, 1, ncclInt32, c->comm, c->stream));
+        c->slab_i0.resize(g->nranks + 1);
+        HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * g->nranks, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(d_i0); hipFree(d_all);
+        c->slab_i0[g->nranks] = g->nx_global + 1;
+        c->wmax = 0;
+        for (int r = 0; r < g->nranks; r++) {
+            if (c->slab_i0[r + 1] <= c->slab_i0[r]) FAIL(c, "slabs are not ordered west to east by rank");
+            c->wmax = std::max(c->wmax, c->slab_i0[r + 1] - c->slab_i0[r]);
+        }
+        if (c->slab_i0[g->rank] != i0 || c->slab_i0[g->rank + 1] != i1 + 1) FAIL(c, "slabs do not tile the global x range");
+        if (g->ns_boundary == EVPK_BND_TRIPOLE) {
+            HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+            HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax * g->nranks));
+        }
+    } else {
+        c->slab_i0 = {1, g->nx_global + 1};
+        c->wmax = g->nx_global;
+    }
+
+    // time-invariant planes
+    struct { const double *h; int f; } gp[] = {
+        {g->dxt, F_DXT}, {g->dyt, F_DYT}, {g->dxhy, F_DXHY}, {g->dyhx, F_DYHX}, {g->cxp, F_CXP}, {g->cyp, F_CYP},
+        {g->cxm, F_CXM}, {g->cym, F_CYM}, {g->tinyarea, F_TINYAREA}, {g->tarear, F_TAREAR}, {g->tarea, F_TAREA},
+        {g->uarea, F_UAREA}, {g->uarear, F_UAREAR}, {g->fcor, F_FCOR}};
+    for (auto &e : gp) {
+        if (!e.h) FAIL(c, "a grid plane pointer is NULL");
+        if (upload_plane<double>(c, e.h, plane(s, e.f))) return 1;
+    }
+    if (!g->tmask || !g->umask) FAIL(c, "tmask/umask is NULL");
+    if (upload_plane<int32_t>(c, g->tmask, s.tmask)) return 1;
+    if (upload_plane<int32_t>(c, g->umask, s.umask)) return 1;
+    if (!c->full_cover) {
+        // cells of eliminated land blocks: give the areas a harmless non-zero value
+        // (they are divisors in to_ugrid / to_tgrid; the reference never visits them)
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const char *tk = getenv("EVPK_TIME_KERNELS");
+    c->time_kernels = tk && atoi(tk) != 0;
+    return 0;
+}
+
+extern "C" int evpk_create(const evpk_geom *g, evpk_ctx **out) {
+    if (!out) return 1;
+    *out = nullptr;
+    evpk_ctx *c = new evpk_ctx();
+    if (create_impl(c, g)) {
+        g_create_err = c->err;
+        destroy_impl(c);
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
+    if (!c || !p) return 1;
+    if (p->ndte < 1 || !(p->dt > 0.0)) FAIL(c, "bad dt/ndte");
+    DevParams &d = c->p;
+    d.dt = p->dt; d.ndte = p->ndte; d.revp = p->revp; d.ecci = p->ecci; d.denom1 = p->denom1;
+    d.arlx1i = p->arlx1i; d.brlx = p->brlx; d.cosw = p->cosw; d.sinw = p->sinw;
+    d.rhow = p->rhow; d.rhoi = p->rhoi; d.rhos = p->rhos; d.gravit = p->gravit;
+    d.a_min = p->a_min; d.m_min = p->m_min;
+    d.tilt_from_slope = p->tilt_from_slope; d.wind_on_ugrid = p->wind_on_ugrid;
+    if ((p->revised_evp != 0) != (p->revp == 1.0)) FAIL(c, "revised_evp and revp disagree");
+    c->have_params = true;
+    return 0;
+}
+
+extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state *st) {
+    if (!c || !in || !st) return 1;
+    if (!c->have_params) FAIL(c, "evpk_set_params has not been called");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    struct { const double *h; int f; bool need; } ip[] = {
+        {in->aice, F_AICE, true}, {in->vice, F_VICE, true}, {in->vsno, F_VSNO, true}, {in->aice_init, F_AICE_INIT, true},
+        {in->uocn, F_UOCN, true}, {in->vocn, F_VOCN, true}, {in->Cdn_ocn, F_CW, true}, {in->strength, F_STRENGTH, true},
+        {in->ss_tltx, F_SSTLTX, c->p.tilt_from_slope != 0}, {in->ss_tlty, F_SSTLTY, c->p.tilt_from_slope != 0},
+        // wind: either T-grid stress (t2ugrid_vector) or U-grid stress (ACCESS); both land in STRAIRXT/YT
+        {c->p.wind_on_ugrid ? in->strax : in->strairxT, F_STRAIRXT, true},
+        {c->p.wind_on_ugrid ? in->stray : in->strairyT, F_STRAIRYT, true}};
+    for (auto &e : ip) {
+        if (!e.h) { if (e.need) FAIL(c, "a required input pointer is NULL"); continue; }
+        if (upload_plane<double>(c, e.h, plane(s, e.f))) return 1;
+    }
+    if (!st->uvel || !st->vvel || !st->iceumask) FAIL(c, "uvel/vvel/iceumask is NULL");
+    double *S0 = plane(s, F_STATE0);
+    if (upload_plane<double>(c, st->uvel, S0 + (size_t)S_U * s.fstride)) return 1;
+    if (upload_plane<double>(c, st->vvel, S0 + (size_t)S_V * s.fstride)) return 1;
+    for (int q = 0; q < 4; q++) {
+        if (!st->stressp[q] || !st->stressm[q] || !st->stress12[q]) FAIL(c, "a stress pointer is NULL");
+        if (upload_plane<double>(c, st->stressp[q], S0 + (size_t)(S_SP + q) * s.fstride)) return 1;
+        if (upload_plane<double>(c, st->stressm[q], S0 + (size_t)(S_SM + q) * s.fstride)) return 1;
+        if (upload_plane<double>(c, st->stress12[q], S0 + (size_t)(S_S12 + q) * s.fstride)) return 1;
+    }
+    if (upload_plane<int32_t>(c, st->iceumask, s.iceumask)) return 1;
+    // strintx/y, strocnx/y are inout in evp_prep2 (kept where iceumask stays true until the loop rewrites them)
+    if (st->strintx) upload_plane<double>(c, st->strintx, plane(s, F_STRINTX));
+    if (st->strinty) upload_plane<double>(c, st->strinty, plane(s, F_STRINTY));
+    if (st->strocnx) upload_plane<double>(c, st->strocnx, plane(s, F_STROCNX));
+    if (st->strocny) upload_plane<double>(c, st->strocny, plane(s, F_STROCNY));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cur = 0;
+    c->uploaded = true;
+    c->prepped = false;
+    return 0;
+}
+
+extern "C" int evpk_prep(evpk_ctx *c) {
+    if (!c) return 1;
+    if (!c->uploaded) FAIL(c, "evpk_upload has not been called");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const dim3 g2 = grid2d(s, B2D);
+    if (c->cur) {   // a previous loop left the state in buffer 1 (odd number of subcycles): prep works on buffer 0
+        HIPCHK(c, hipMemcpyAsync(plane(s, F_STATE0), plane(s, F_STATE1), sizeof(double) * s.fstride * NSTATE,
+                                 hipMemcpyDeviceToDevice, c->stream));
+        c->cur = 0;
+    }
+    // evp_prep1 + zero diagnostics (ice_dyn_evp.F90:171-203)
+    hipLaunchKernelGGL(k_prep1a, g2, B2D, 0, c->stream, s, c->p);
+    hipLaunchKernelGGL(k_prep1b, g2, B2D, 0, c->stream, s);
+    if (halo(c, F_ICETM, 1, false, false, 0.0)) return 1;                         // :210-211
+    // to_ugrid (:218-219)
+    hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_TMASS, (int)F_UMASS);
+    hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_AICE_INIT, (int)F_AIU);
+    if (!c->p.wind_on_ugrid) {                                                    // t2ugrid_vector (:240-241)
+        if (halo(c, F_STRAIRX, 2, false, true, 0.0)) return 1;
+        hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STRAIRX, (int)F_WORK1);
+        hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STRAIRY, (int)F_WORK2);
+        hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_WORK1, (int)F_STRAIRX);
+        hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_WORK2, (int)F_STRAIRY);
+    }
+    // evp_prep2 (:247-308); strength is an input (ice_strength, :291-301)
+    hipLaunchKernelGGL(k_prep2, g2, B2D, 0, c->stream, s, c->p);
+    if (halo(c, F_STRENGTH, 1, false, false, 0.0)) return 1;                      // :311-312
+    if (halo(c, F_STATE0 + S_U, 2, true, true, 0.0)) return 1;                    // :314-315
+    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)(F_STATE0 + S_U), (int)(F_STATE1 + S_U));
+    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)(F_STATE0 + S_V), (int)(F_STATE1 + S_V));
+    // active strips
+    hipLaunchKernelGGL(k_icetm_to_cmask, g2, B2D, 0, c->stream, s);
+    const int ns_tot = c->ncx * c->nry;
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 2, c->stream));
+    hipLaunchKernelGGL(k_strip_flags, dim3((ns_tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx, c->nry, c->R, c->d_flags, c->d_counts);
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned char> flags(ns_tot);
+    unsigned long long cnt[2];
+    HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags, ns_tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> list;
+    list.reserve(ns_tot);
+    for (int k = 0; k < ns_tot; k++) if (flags[k]) list.push_back(k);
+    c->nstrips = (int)list.size();
+    if (c->nstrips) HIPCHK(c, hipMemcpyAsync(c->d_strips, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->icellt = (long long)cnt[0];
+    c->icellu = (long long)cnt[1];
+    c->ksub = 0;
+    c->prepped = true;
+    return 0;
+}
+
+extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
+    if (!c) return 1;
+    if (!c->prepped) FAIL(c, "evpk_prep has not been called");
+    if (nsub < 0) FAIL(c, "nsub < 0");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool wrap = (c->nranks == 1 && c->ew == EVPK_BND_CYCLIC);
+    const bool need_halo = (c->nranks > 1) || (c->ns == EVPK_BND_TRIPOLE);
+    c->kernel_ms = 0.f;
+    c->kernel_launches = 0;
+    if (c->time_kernels) {
+        while ((int)c->kev.size() < 2 * nsub) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int n = 0; n < nsub; n++) {
+        c->ksub++;
+        SubArgs a;
+        a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
+        a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
+        a.strips = c->d_strips; a.nstrips = c->nstrips; a.ncx = c->ncx; a.R = c->R; a.cur = c->cur; a.wrap = wrap ? 1 : 0;
+        const bool last = (c->ksub == c->p.ndte);
+        const bool revp = (c->p.revp == 1.0);
+        if (c->nstrips > 0) {
+            const dim3 g((((c->nstrips + 3) / 4 + 7) / 8) * 8), b(256);   // multiple of 8: see the XCD remap in k_subcycle
+            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * n], c->stream));
+            if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, c->stream, a);
+            else if (last) hipLaunchKernelGGL((k_subcycle<true, false>), g, b, 0, c->stream, a);
+            else if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, a);
+            else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, a);
+            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * n + 1], c->stream));
+            c->kernel_launches++;
+        }
+        c->cur ^= 1;
+        if (need_halo) {                                                          // ice_dyn_evp.F90:392-400
+            if (halo(c, (c->cur ? F_STATE1 : F_STATE0) + S_U, 2, true, true, 0.0)) return 1;
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
+    if (c->time_kernels) {
+        for (int n = 0; n < c->kernel_launches; n++) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->kev[2 * n], c->kev[2 * n + 1]));
+            c->kernel_ms += ms;
+        }
+    }
+    return 0;
+}
+
+extern "C" int evpk_finish(evpk_ctx *c) {
+    if (!c) return 1;
+    if (!c->prepped) FAIL(c, "evpk_prep has not been called");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const dim3 g2 = grid2d(s, B2D);
+    const int SB = c->cur ? F_STATE1 : F_STATE0;
+    if (c->ns == EVPK_BND_TRIPOLE) {                                              // ice_dyn_evp.F90:454-479
+        const int base[3] = {S_SP, S_SM, S_S12};
+        for (int t = 0; t < 3; t++) {
+            const int b = SB + base[t];
+            if (halo(c, b + 0, 1, false, false, 0.0, b + 2)) return 1;
+            if (halo(c, b + 2, 1, false, false, 0.0, b + 0)) return 1;
+            if (halo(c, b + 1, 1, false, false, 0.0, b + 3)) return 1;
+            if (halo(c, b + 3, 1, false, false, 0.0, b + 1)) return 1;
+        }
+    }
+    hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
+    // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)
+    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STROCNXT, (int)F_WORK1);
+    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STROCNYT, (int)F_WORK2);
+    if (halo(c, F_WORK1, 2, true, true, 0.0)) return 1;
+    hipLaunchKernelGGL(k_to_tgrid, g2, B2D, 0, c->stream, s, (int)F_WORK1, (int)F_STROCNXT);
+    hipLaunchKernelGGL(k_to_tgrid, g2, B2D, 0, c->stream, s, (int)F_WORK2, (int)F_STROCNYT);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int evpk_sync(evpk_ctx *c) {
+    if (!c) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
+    if (!c || !st) return 1;
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double *S = plane(s, c->cur ? F_STATE1 : F_STATE0);
+    if (download_plane<double>(c, st->uvel, S + (size_t)S_U * s.fstride, MODE_ALL)) return 1;
+    if (download_plane<double>(c, st->vvel, S + (size_t)S_V * s.fstride, MODE_ALL)) return 1;
+    for (int q = 0; q < 4; q++) {
+        if (download_plane<double>(c, st->stressp[q], S + (size_t)(S_SP + q) * s.fstride, MODE_NE)) return 1;
+        if (download_plane<double>(c, st->stressm[q], S + (size_t)(S_SM + q) * s.fstride, MODE_NE)) return 1;
+        if (download_plane<double>(c, st->stress12[q], S + (size_t)(S_S12 + q) * s.fstride, MODE_NE)) return 1;
+    }
+    if (download_plane<int32_t>(c, st->iceumask, s.iceumask, MODE_PHYS)) return 1;
+    struct { double *h; int f; } op[] = {
+        {st->divu, F_DIVU}, {st->shear, F_SHEAR}, {st->rdg_conv, F_RDGCONV}, {st->rdg_shear, F_RDGSHEAR},
+        {st->prs_sig, F_PRSSIG}, {st->strintx, F_STRINTX}, {st->strinty, F_STRINTY}, {st->strocnx, F_STROCNX},
+        {st->strocny, F_STROCNY}, {st->strocnxT, F_STROCNXT}, {st->strocnyT, F_STROCNYT}, {st->strairx, F_STRAIRX},
+        {st->strairy, F_STRAIRY}, {st->strtltx, F_STRTLTX}, {st->strtlty, F_STRTLTY}, {st->fm, F_FM},
+        {st->tmass, F_TMASS}, {st->aiu, F_AIU}, {st->umass, F_UMASS}, {st->uvel_init, F_UVEL_INIT}, {st->vvel_init, F_VVEL_INIT}};
+    for (auto &e : op)
+        if (download_plane<double>(c, e.h, plane(s, e.f), MODE_PHYS)) return 1;
+    if (st->icetmask) {
+        // icetmask travels as a 0/1 double plane on the device; convert through the staging buffer
+        std::vector<double> tmp((size_t)c->nblocks * c->nyb * c->nxb, 0.0);
+        if (download_plane<double>(c, tmp.data(), plane(s, F_ICETM), MODE_ALL)) return 1;
+        for (size_t k = 0; k < tmp.size(); k++) st->icetmask[k] = (int32_t)tmp[k];
+    }
+    return 0;
+}
+
+extern "C" int evpk_run(evpk_ctx *c, const evpk_step_in *in, evpk_state *st) {
+    if (!c) return 1;
+    if (evpk_upload(c, in, st)) return 1;
+    if (evpk_prep(c)) return 1;
+    if (evpk_subcycle(c, c->p.ndte)) return 1;
+    if (evpk_finish(c)) return 1;
+    return evpk_download(c, st);
+}
+
+extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
+    if (!c || !o) return 1;
+    o->icellt = c->icellt; o->icellu = c->icellu;
+    o->ncell_slab = (int64_t)c->s.nxl * c->s.nyl;
+    o->nstrips = c->nstrips; o->nstrips_total = c->ncx * c->nry;
+    o->subcycles_done = c->ksub;
+    o->loop_ms = c->loop_ms; o->kernel_ms = c->kernel_ms; o->kernel_launches = c->kernel_launches;
+    return 0;
+}

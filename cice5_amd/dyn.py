@@ -1,0 +1,98 @@
+"""Host-side mirror of the reference's EVP module interface (same names and argument meaning):
+
+    ice_dyn_shared: set_evp_parameters(dt), init_evp(dt)      source/ice_dyn_shared.F90:99-259
+    ice_dyn_evp:    evp(dt)                                   source/ice_dyn_evp.F90:68
+
+The module-global arrays of ice_state / ice_flux / ice_grid are one dict of block-layout
+numpy arrays (`fields`), keyed by the reference's variable names.  All arithmetic of the
+path runs in libevpk (HIP); this file only computes the handful of scalars that
+set_evp_parameters derives on the host in the reference too.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import constants as C
+from . import evpk
+from .blocks import Decomp
+
+
+def set_evp_parameters(dt: float, ndte: int, revised_evp: bool, xmin: float, *,
+                       cosw: float = C.cosw, sinw: float = C.sinw,
+                       tilt_from_slope: bool = False, wind_on_ugrid: bool = False) -> evpk.Params:
+    """ice_dyn_shared.F90:185-259.  `xmin` = min(global_minval(dxt,tmask), global_minval(dyt,tmask)) (:221-223)."""
+    p = evpk.Params()
+    dte = dt / float(ndte)                       # :209
+    dtei = 1.0 / dte                             # :210
+    p.dt, p.ndte, p.revised_evp = dt, ndte, int(revised_evp)
+    p.ecci = 0.25                                # :214
+    tdamp2 = 2.0 * C.eyc * dt                    # :217
+    dte2T = dte / tdamp2                         # :218
+    Se, xi = 0.86, 5.5e-3                        # :226-227
+    gamma = 0.25 * 1.0e11 * dt                   # :228
+    if revised_evp:                              # :230-233
+        p.revp = 1.0
+        p.arlx1i = 2.0 * xi / Se
+        p.brlx = 2.0 * Se * xi * gamma / xmin ** 2
+    else:                                        # :239-242
+        p.revp = 0.0
+        p.arlx1i = dte2T
+        p.brlx = dt * dtei
+    p.denom1 = 1.0 / (1.0 + p.arlx1i)            # :257
+    p.cosw, p.sinw = cosw, sinw
+    p.rhow, p.rhoi, p.rhos, p.gravit = C.rhow, C.rhoi, C.rhos, C.gravit
+    p.a_min, p.m_min = C.a_min, C.m_min
+    p.tilt_from_slope, p.wind_on_ugrid = int(tilt_from_slope), int(wind_on_ugrid)
+    return p
+
+
+def local_min_dx(fields: Dict[str, np.ndarray], decomp: Decomp) -> float:
+    """This rank's contribution to global_minval(dxt/dyt, tmask) over physical cells."""
+    m = np.inf
+    for n, b in enumerate(decomp.local_blocks):
+        sl = (n, slice(b.jlo - 1, b.jhi), slice(b.ilo - 1, b.ihi))
+        mk = fields["tmask"][sl] > 0
+        if mk.any():
+            m = min(m, float(fields["dxt"][sl][mk].min()), float(fields["dyt"][sl][mk].min()))
+    return m
+
+
+class EvpDynamics:
+    """One rank's EVP solver.  Usage mirrors the reference call order:
+    `init_evp(dt)` once (CICE_InitMod.F90:103-104), then `evp(dt)` every dynamics step
+    (ice_step_mod.F90:1119)."""
+
+    def __init__(self, decomp: Decomp, fields: Dict[str, np.ndarray], *, ndte: int = 120, revised_evp: bool = False,
+                 device: int = 0, unique_id: Optional[bytes] = None, cosw: float = C.cosw, sinw: float = C.sinw,
+                 tilt_from_slope: bool = False, wind_on_ugrid: bool = False, xmin: Optional[float] = None):
+        self.decomp, self.fields = decomp, fields
+        self.ndte, self.revised_evp = ndte, revised_evp
+        self._opts = dict(cosw=cosw, sinw=sinw, tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
+        self._xmin = xmin
+        self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id)
+        self.params: Optional[evpk.Params] = None
+
+    def set_evp_parameters(self, dt: float):
+        xmin = self._xmin if self._xmin is not None else local_min_dx(self.fields, self.decomp)
+        self.params = set_evp_parameters(dt, self.ndte, self.revised_evp, xmin, **self._opts)
+        self.ctx.set_params(self.params)
+
+    def init_evp(self, dt: float):
+        """ice_dyn_shared.F90:99-174: parameters, then velocities / stresses / masks at rest."""
+        self.set_evp_parameters(dt)
+        f = self.fields
+        for n in ["uvel", "vvel", "divu", "shear", "rdg_conv", "rdg_shear"] + \
+                 [f"{k}_{c}" for k in ("stressp", "stressm", "stress12") for c in (1, 2, 3, 4)]:
+            f[n][...] = 0.0
+        f["iceumask"][...] = 0
+
+    def evp(self, dt: float):
+        """ice_dyn_evp.F90:68: one call of the dynamics, in place on `fields`."""
+        if self.params is None or self.params.dt != dt:
+            self.set_evp_parameters(dt)        # :153-154 ("needed only if dt changes during runtime")
+        self.ctx.run(self.fields)
+
+    def close(self):
+        self.ctx.close()

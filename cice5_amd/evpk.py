@@ -1,0 +1,231 @@
+"""ctypes binding of libevpk.so (include/evpk.h) -- the same C ABI the Fortran shim binds.
+
+No torch types cross this boundary: arrays are numpy block-layout buffers
+(nblocks, ny_block, nx_block), i.e. the reference's (nx_block, ny_block, max_blocks).
+There is no CPU fallback: loading fails loudly if the library is missing, and
+evpk_create fails if no gfx950 device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevpk.so")
+
+c_i32p = ct.POINTER(ct.c_int32)
+c_f64p = ct.POINTER(ct.c_double)
+
+UNIQUE_ID_BYTES = 128
+
+GEOM_F64 = ["dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
+            "tarear", "uarear", "tinyarea", "tarea", "uarea", "fcor"]
+STEP_IN_F64 = ["aice", "vice", "vsno", "aice_init", "strairxT", "strairyT", "strax", "stray",
+               "uocn", "vocn", "ss_tltx", "ss_tlty", "Cdn_ocn", "strength"]
+STATE_OUT_F64 = ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx", "strinty",
+                 "strocnx", "strocny", "strocnxT", "strocnyT", "strairx", "strairy",
+                 "strtltx", "strtlty", "fm", "tmass", "aiu", "umass", "uvel_init", "vvel_init"]
+
+
+class Geom(ct.Structure):
+    _fields_ = ([("nx_global", ct.c_int32), ("ny_global", ct.c_int32),
+                 ("nx_block", ct.c_int32), ("ny_block", ct.c_int32), ("nblocks", ct.c_int32),
+                 ("ew_boundary", ct.c_int32), ("ns_boundary", ct.c_int32),
+                 ("ilo", c_i32p), ("ihi", c_i32p), ("jlo", c_i32p), ("jhi", c_i32p),
+                 ("iglob_lo", c_i32p), ("jglob_lo", c_i32p),
+                 ("rank", ct.c_int32), ("nranks", ct.c_int32), ("device", ct.c_int32),
+                 ("unique_id", ct.c_void_p)] +
+                [(n, c_f64p) for n in GEOM_F64] + [("tmask", c_i32p), ("umask", c_i32p)])
+
+
+class Params(ct.Structure):
+    _fields_ = [("dt", ct.c_double), ("ndte", ct.c_int32), ("revised_evp", ct.c_int32),
+                ("revp", ct.c_double), ("ecci", ct.c_double), ("denom1", ct.c_double),
+                ("arlx1i", ct.c_double), ("brlx", ct.c_double),
+                ("cosw", ct.c_double), ("sinw", ct.c_double),
+                ("rhow", ct.c_double), ("rhoi", ct.c_double), ("rhos", ct.c_double), ("gravit", ct.c_double),
+                ("a_min", ct.c_double), ("m_min", ct.c_double),
+                ("tilt_from_slope", ct.c_int32), ("wind_on_ugrid", ct.c_int32)]
+
+
+class StepIn(ct.Structure):
+    _fields_ = [(n, c_f64p) for n in STEP_IN_F64]
+
+
+class State(ct.Structure):
+    _fields_ = ([("uvel", c_f64p), ("vvel", c_f64p),
+                 ("stressp", c_f64p * 4), ("stressm", c_f64p * 4), ("stress12", c_f64p * 4),
+                 ("iceumask", c_i32p)] +
+                [(n, c_f64p) for n in STATE_OUT_F64] + [("icetmask", c_i32p)])
+
+
+class Stats(ct.Structure):
+    _fields_ = [("icellt", ct.c_int64), ("icellu", ct.c_int64), ("ncell_slab", ct.c_int64),
+                ("nstrips", ct.c_int32), ("nstrips_total", ct.c_int32), ("subcycles_done", ct.c_int32),
+                ("loop_ms", ct.c_float), ("kernel_ms", ct.c_float), ("kernel_launches", ct.c_int32)]
+
+
+EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",
+           "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
+           "evpk_last_error", "evpk_slab_layout"]
+
+_lib = None
+
+
+class EvpkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libevpk.so; raises if it has not been built (python __graft_entry__.py / make -C cice5_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EvpkError(f"{LIB_PATH} not found: build it with `make -C cice5_amd/csrc` "
+                            "(there is no CPU fallback for the EVP kernels)")
+        L = ct.CDLL(LIB_PATH)
+        ctxp = ct.c_void_p
+        L.evpk_get_unique_id.argtypes = [ct.c_void_p]
+        L.evpk_create.argtypes = [ct.POINTER(Geom), ct.POINTER(ctxp)]
+        L.evpk_set_params.argtypes = [ctxp, ct.POINTER(Params)]
+        L.evpk_run.argtypes = [ctxp, ct.POINTER(StepIn), ct.POINTER(State)]
+        L.evpk_upload.argtypes = [ctxp, ct.POINTER(StepIn), ct.POINTER(State)]
+        L.evpk_prep.argtypes = [ctxp]
+        L.evpk_subcycle.argtypes = [ctxp, ct.c_int32]
+        L.evpk_finish.argtypes = [ctxp]
+        L.evpk_download.argtypes = [ctxp, ct.POINTER(State)]
+        L.evpk_sync.argtypes = [ctxp]
+        L.evpk_get_stats.argtypes = [ctxp, ct.POINTER(Stats)]
+        L.evpk_destroy.argtypes = [ctxp]
+        L.evpk_last_error.argtypes = [ctxp]
+        L.evpk_last_error.restype = ct.c_char_p
+        L.evpk_slab_layout.argtypes = [ct.c_int32] * 6 + [c_i32p]
+        for n in EXPORTS:
+            if n != "evpk_last_error":
+                getattr(L, n).restype = ct.c_int
+        _lib = L
+    return _lib
+
+
+def _p64(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    if a.dtype != np.float64 or not a.flags.c_contiguous:
+        raise TypeError("expected a C-contiguous float64 block array")
+    return a.ctypes.data_as(c_f64p)
+
+
+def _p32(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    if a.dtype != np.int32 or not a.flags.c_contiguous:
+        raise TypeError("expected a C-contiguous int32 block array")
+    return a.ctypes.data_as(c_i32p)
+
+
+def get_unique_id() -> bytes:
+    buf = ct.create_string_buffer(UNIQUE_ID_BYTES)
+    if lib().evpk_get_unique_id(buf):
+        raise EvpkError("evpk_get_unique_id failed")
+    return buf.raw
+
+
+def slab_layout(nx_global, nranks, rank, ew_boundary, i0, i1):
+    out = (ct.c_int32 * 5)()
+    if lib().evpk_slab_layout(nx_global, nranks, rank, ew_boundary, i0, i1, out):
+        raise EvpkError("evpk_slab_layout: bad arguments")
+    return dict(west=out[0], east=out[1], i0=out[2], i1=out[3], wmax=out[4])
+
+
+class Context:
+    """Owns one evpk_ctx (one GPU, one rank)."""
+
+    def __init__(self, decomp, fields: Dict[str, np.ndarray], device: int = 0, unique_id: Optional[bytes] = None):
+        L = lib()
+        self._L = L
+        self._ctx = ct.c_void_p()
+        ga = decomp.geom_arrays()
+        g = Geom()
+        g.nx_global, g.ny_global = decomp.nx_global, decomp.ny_global
+        g.nx_block, g.ny_block, g.nblocks = decomp.nx_block, decomp.ny_block, decomp.nblocks
+        g.ew_boundary, g.ns_boundary = decomp.ew_boundary, decomp.ns_boundary
+        for n in ("ilo", "ihi", "jlo", "jhi", "iglob_lo", "jglob_lo"):
+            setattr(g, n, _p32(ga[n]))
+        g.rank, g.nranks, g.device = decomp.rank, decomp.nprocs, device
+        self._uid = ct.create_string_buffer(unique_id, UNIQUE_ID_BYTES) if unique_id is not None else None
+        g.unique_id = ct.cast(self._uid, ct.c_void_p) if self._uid is not None else None
+        for n in GEOM_F64:
+            setattr(g, n, _p64(fields[n]))
+        g.tmask, g.umask = _p32(fields["tmask"]), _p32(fields["umask"])
+        if L.evpk_create(ct.byref(g), ct.byref(self._ctx)):
+            raise EvpkError("evpk_create: " + L.evpk_last_error(None).decode())
+        self.decomp = decomp
+
+    def _chk(self, rc, what):
+        if rc:
+            raise EvpkError(f"{what}: " + self._L.evpk_last_error(self._ctx).decode())
+
+    def set_params(self, p: Params):
+        self._chk(self._L.evpk_set_params(self._ctx, ct.byref(p)), "evpk_set_params")
+
+    @staticmethod
+    def _step_in(f) -> StepIn:
+        si = StepIn()
+        for n in STEP_IN_F64:
+            setattr(si, n, _p64(f.get(n)))
+        return si
+
+    @staticmethod
+    def _state(f) -> State:
+        st = State()
+        st.uvel, st.vvel = _p64(f["uvel"]), _p64(f["vvel"])
+        for k in ("stressp", "stressm", "stress12"):
+            setattr(st, k, (c_f64p * 4)(*[_p64(f[f"{k}_{c}"]) for c in (1, 2, 3, 4)]))
+        st.iceumask = _p32(f["iceumask"])
+        for n in STATE_OUT_F64:
+            setattr(st, n, _p64(f.get(n)))
+        st.icetmask = _p32(f.get("icetmask"))
+        return st
+
+    def run(self, f):
+        si, st = self._step_in(f), self._state(f)
+        self._chk(self._L.evpk_run(self._ctx, ct.byref(si), ct.byref(st)), "evpk_run")
+
+    def upload(self, f):
+        si, st = self._step_in(f), self._state(f)
+        self._chk(self._L.evpk_upload(self._ctx, ct.byref(si), ct.byref(st)), "evpk_upload")
+
+    def prep(self):
+        self._chk(self._L.evpk_prep(self._ctx), "evpk_prep")
+
+    def subcycle(self, nsub: int):
+        self._chk(self._L.evpk_subcycle(self._ctx, int(nsub)), "evpk_subcycle")
+
+    def finish(self):
+        self._chk(self._L.evpk_finish(self._ctx), "evpk_finish")
+
+    def download(self, f):
+        st = self._state(f)
+        self._chk(self._L.evpk_download(self._ctx, ct.byref(st)), "evpk_download")
+
+    def sync(self):
+        self._chk(self._L.evpk_sync(self._ctx), "evpk_sync")
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._chk(self._L.evpk_get_stats(self._ctx, ct.byref(s)), "evpk_get_stats")
+        return s
+
+    def close(self):
+        if self._ctx:
+            self._L.evpk_destroy(self._ctx)
+            self._ctx = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

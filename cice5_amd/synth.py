@@ -108,11 +108,35 @@ class SynthCase:
         edge = 55.0 + 5.0 * np.sin(2.0 * np.pi * 4.0 * Iw / self.nx)
         return ocean & (np.abs(self._latT(J)) > edge)
 
-    def field(self, name: str, I, J):
+    def field(self, name: str, I, J, cache=None):
+        """Field `name` on the index window (I, J).  `cache` (a dict) memoises sub-results between
+        calls on the SAME window, which make_block_fields uses to evaluate ~35 fields per block."""
+        if cache is not None:
+            if name in cache:
+                return cache[name]
+            cache[name] = r = self._field(name, I, J, cache)
+            return r
+        return self._field(name, I, J, None)
+
+    def _field(self, name: str, I, J, cache):
         I, J = np.broadcast_arrays(np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64))
+        _self_field = self.field
+        class _S:   # route nested lookups through the cache
+            field = staticmethod(lambda n, I_, J_: _self_field(n, I_, J_, cache))
+        if cache is not None:
+            def memo(key, fn):
+                if key not in cache:
+                    cache[key] = fn()
+                return cache[key]
+            HTN = lambda I_, J_: memo(("HTN", int(J_.flat[0]) - int(J.flat[0])), lambda: self.HTN(I_, J_))
+            HTE = lambda I_, J_: memo(("HTE", int(I_.flat[0]) - int(I.flat[0]), int(J_.flat[0]) - int(J.flat[0])), lambda: self.HTE(I_, J_))
+            return self._eval(name, I, J, _S, HTN, HTE, lambda: memo("_icy", lambda: self._icy(I, J)),
+                              lambda: memo("_hm", lambda: self.hm(I, J)), lambda: memo("_uvm", lambda: self.uvm(I, J)))
+        return self._eval(name, I, J, self, self.HTN, self.HTE, lambda: self._icy(I, J), lambda: self.hm(I, J), lambda: self.uvm(I, J))
+
+    def _eval(self, name, I, J, self_, HTN, HTE, icy_fn, hm_fn, uvm_fn):
         Iw = self._wrap(I)
         s = self.seed
-        HTN, HTE = self.HTN, self.HTE
         if name == "dxt":
             return 0.5 * (HTN(I, J) + HTN(I, J - 1))
         if name == "dyt":
@@ -122,15 +146,15 @@ class SynthCase:
         if name == "dyu":
             return 0.5 * (HTE(I, J) + HTE(I, J + 1))
         if name == "tarea":
-            return self.field("dxt", I, J) * self.field("dyt", I, J)
+            return self_.field("dxt", I, J) * self_.field("dyt", I, J)
         if name == "uarea":
-            return self.field("dxu", I, J) * self.field("dyu", I, J)
+            return self_.field("dxu", I, J) * self_.field("dyu", I, J)
         if name == "tarear":
-            return 1.0 / self.field("tarea", I, J)
+            return 1.0 / self_.field("tarea", I, J)
         if name == "uarear":
-            return 1.0 / self.field("uarea", I, J)
+            return 1.0 / self_.field("uarea", I, J)
         if name == "tinyarea":
-            return C.puny * self.field("tarea", I, J)
+            return C.puny * self_.field("tarea", I, J)
         if name == "dxhy":
             return 0.5 * (HTE(I, J) - HTE(I - 1, J))
         if name == "dyhx":
@@ -146,29 +170,29 @@ class SynthCase:
         if name == "fcor":
             return 2.0 * C.omega * np.sin(np.deg2rad(self._latU(J))) + 0.0 * I
         if name == "tmask":
-            return (self.hm(I, J) > 0.5).astype(np.int32)
+            return (hm_fn() > 0.5).astype(np.int32)
         if name == "umask":
-            return (self.uvm(I, J) > 0.5).astype(np.int32)
+            return (uvm_fn() > 0.5).astype(np.int32)
 
-        icy = self._icy(I, J)
+        icy = icy_fn()
         x = 2.0 * np.pi * Iw / self.nx
         y = np.pi * J / self.ny
         if name in ("aice", "aice_init"):
             return np.where(icy, 0.6 + 0.4 * _hash01(Iw, J, 1, s), 0.0)
         if name == "vice":
             hi = 0.5 + 2.5 * _hash01(Iw, J, 2, s)
-            return np.where(icy, self.field("aice", I, J) * hi, 0.0)
+            return np.where(icy, self_.field("aice", I, J) * hi, 0.0)
         if name == "vsno":
-            return np.where(icy, self.field("aice", I, J) * 0.3 * _hash01(Iw, J, 3, s), 0.0)
+            return np.where(icy, self_.field("aice", I, J) * 0.3 * _hash01(Iw, J, 3, s), 0.0)
         ins = self._inside(I, J)
         if name == "uocn":
             return np.where(ins, 0.05 * np.sin(3.0 * x + 0.4) * np.cos(4.0 * y) + 0.01 * (_hash01(Iw, J, 4, s) - 0.5), 0.0)
         if name == "vocn":
             return np.where(ins, 0.05 * np.cos(2.0 * x - 1.1) * np.sin(5.0 * y) + 0.01 * (_hash01(Iw, J, 5, s) - 0.5), 0.0)
         if name == "strairxT":
-            return self.field("aice", I, J) * (0.1 * np.sin(2.0 * x + 3.0 * y) + 0.05 * (_hash01(Iw, J, 6, s) - 0.5))
+            return self_.field("aice", I, J) * (0.1 * np.sin(2.0 * x + 3.0 * y) + 0.05 * (_hash01(Iw, J, 6, s) - 0.5))
         if name == "strairyT":
-            return self.field("aice", I, J) * (0.1 * np.cos(3.0 * x - 2.0 * y) + 0.05 * (_hash01(Iw, J, 7, s) - 0.5))
+            return self_.field("aice", I, J) * (0.1 * np.cos(3.0 * x - 2.0 * y) + 0.05 * (_hash01(Iw, J, 7, s) - 0.5))
         if name == "ss_tltx":
             return np.where(ins, 1.0e-6 * np.sin(4.0 * x + y), 0.0)
         if name == "ss_tlty":
@@ -176,10 +200,10 @@ class SynthCase:
         if name == "Cdn_ocn":
             return np.full(I.shape, C.dragio)
         if name == "strength":   # Hibler (1979), ice_mechred.F90:2258-2265
-            a, v = self.field("aice", I, J), self.field("vice", I, J)
+            a, v = self_.field("aice", I, J), self_.field("vice", I, J)
             return C.Pstar * v * np.exp(-C.Cstar * (1.0 - a))
         if name in ("strax", "stray"):   # ACCESS: wind stress already on the U grid
-            return self.field("strairxT" if name == "strax" else "strairyT", I, J)
+            return self_.field("strairxT" if name == "strax" else "strairyT", I, J)
         raise KeyError(name)
 
 
@@ -198,12 +222,19 @@ OUTPUT_FIELDS = ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx",
 def make_block_fields(case: SynthCase, d: Decomp) -> Dict[str, np.ndarray]:
     """All arrays evp(dt) touches, in block layout, for the local blocks of `d`.
     Prognostic state starts at rest (init_evp, ice_dyn_shared.F90:133-172)."""
+    from .blocks import block_index_windows
     f: Dict[str, np.ndarray] = {}
-    for n in GRID_FIELDS + INPUT_FIELDS:
-        f[n] = to_blocks(d, lambda I, J, n=n: case.field(n, I, J))
-    for n in MASK_FIELDS:
-        f[n] = to_blocks(d, lambda I, J, n=n: case.field(n, I, J), dtype=np.int32)
     shp = (d.nblocks, d.ny_block, d.nx_block)
+    for n in GRID_FIELDS + INPUT_FIELDS:
+        f[n] = np.zeros(shp, dtype=np.float64)
+    for n in MASK_FIELDS:
+        f[n] = np.zeros(shp, dtype=np.int32)
+    Iw, Jw = block_index_windows(d)
+    for b in range(d.nblocks):
+        I, J = np.broadcast_arrays(Iw[b][None, :], Jw[b][:, None])
+        cache: dict = {}
+        for n in GRID_FIELDS + INPUT_FIELDS + MASK_FIELDS:
+            f[n][b] = case.field(n, I, J, cache)
     for n in STATE_FIELDS + OUTPUT_FIELDS:
         f[n] = np.zeros(shp, dtype=np.float64)
     f["iceumask"] = np.zeros(shp, dtype=np.int32)

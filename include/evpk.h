@@ -1,0 +1,155 @@
+/*
+ * evpk.h -- C ABI of the MI355X EVP sea-ice dynamics solver (libevpk.so).
+ *
+ * This is the drop-in boundary for ONE path of COSIMA/cice5: the body of
+ *     subroutine evp(dt)                      source/ice_dyn_evp.F90:68-510
+ * i.e. evp_prep1/evp_prep2 (source/ice_dyn_shared.F90:270,377), the ndte-subcycled
+ * stress + stepu loop with its velocity halo update (ice_dyn_evp.F90:336-410,
+ * :520-849; ice_dyn_shared.F90:623-748), the tripole stress fold (:416-481),
+ * evp_finish (ice_dyn_shared.F90:757) and the T<->U averages around them
+ * (source/ice_grid.F90:1799-1958).  The reference has no FFI for this path: the
+ * boundary there is a Fortran module procedure plus module-global arrays
+ * (SURVEY.md S8b).  The entry points below are what a Fortran `ice_dyn_evp`
+ * replacement binds through ISO_C_BINDING (fortran/evpk_mod.F90, fortran/ice_dyn_evp.F90,
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every array is a caller-owned host buffer borrowed for
+ *    the duration of the call only.
+ *  - every field is the reference's block array  real(8) a(nx_block,ny_block,nblocks)
+ *    (ice_state.F90:141-147), i fastest, ghost cells included, blocks in local-ID order.
+ *    Fortran LOGICAL arrays (tmask, umask, iceumask) are passed as int32 0/1.
+ *  - all indices are Fortran 1-based.
+ *  - return 0 on success, non-zero on error; evpk_last_error() gives the text.  The
+ *    library never aborts the process (the Fortran shim maps non-zero to abort_ice,
+ *    mpi/ice_exit.F90:22).
+ *  - one host thread per context; a context owns its HIP streams and (nranks > 1) its
+ *    RCCL communicator.  There is no CPU fallback: without a usable gfx950 device
+ *    evpk_create fails.
+ */
+#ifndef EVPK_H
+#define EVPK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVPK_VERSION 1
+
+/* boundary types: ice_domain.F90 domain_nml ew_boundary_type / ns_boundary_type */
+enum { EVPK_BND_CYCLIC = 0, EVPK_BND_OPEN = 1, EVPK_BND_CLOSED = 2, EVPK_BND_TRIPOLE = 3 };
+
+#define EVPK_UNIQUE_ID_BYTES 128
+
+typedef struct evpk_ctx evpk_ctx;
+
+/* Replaces what evp() pulls from ice_blocks / ice_domain / ice_grid:
+ *   get_block(blocks_ice(iblk),iblk) -> ilo,ihi,jlo,jhi,i_glob,j_glob  (ice_blocks.F90:22-35, :788)
+ *   nblocks, ew/ns boundary types                                       (ice_domain.F90:41-66)
+ *   dxt..tinyarea, tarea, uarea, tmask, umask                           (ice_grid.F90:48-77,112-117)
+ *   fcor_blk                                                            (ice_dyn_shared.F90:83-84,150)
+ * Sharding: ranks own contiguous x-slabs of whole columns (processor_shape slenderX1,
+ * ice_distribution.F90:535); rank r's east neighbour is r+1 (cyclic if ew is cyclic). */
+typedef struct {
+    int32_t nx_global, ny_global;
+    int32_t nx_block, ny_block, nblocks;
+    int32_t ew_boundary, ns_boundary;
+    const int32_t *ilo, *ihi, *jlo, *jhi;      /* [nblocks] */
+    const int32_t *iglob_lo, *jglob_lo;        /* [nblocks] this_block%i_glob(ilo), %j_glob(jlo) */
+    int32_t rank, nranks;                      /* position in the ring of x-slabs */
+    int32_t device;                            /* HIP device ordinal */
+    const void *unique_id;                     /* EVPK_UNIQUE_ID_BYTES from evpk_get_unique_id (rank 0), NULL if nranks == 1 */
+    const double *dxt, *dyt, *dxhy, *dyhx, *cxp, *cyp, *cxm, *cym;
+    const double *tarear, *uarear, *tinyarea, *tarea, *uarea, *fcor;
+    const int32_t *tmask, *umask;
+} evpk_geom;
+
+/* Replaces the module scalars of ice_dyn_shared.F90:29-81 set by set_evp_parameters
+ * (:185-259) and the constants evp reads (ice_constants.F90; a_min, m_min :60-61). */
+typedef struct {
+    double dt;
+    int32_t ndte;
+    int32_t revised_evp;
+    double revp, ecci, denom1, arlx1i, brlx;
+    double cosw, sinw;                         /* AusCOM: namelist variables (ice_dyn_shared.F90:66-72) */
+    double rhow, rhoi, rhos, gravit;
+    double a_min, m_min;
+    int32_t tilt_from_slope;                   /* 1: strtlt = -gravit*umass*ss_tlt (:601-602 / use_ocnslope), 0: geostrophic (:598-599) */
+    int32_t wind_on_ugrid;                     /* 1: strairx/y := strax/stray (ice_dyn_evp.F90:226-228), 0: t2ugrid_vector (:240-241) */
+} evpk_params;
+
+/* Per-call inputs: what evp(dt) reads from ice_state / ice_flux / ice_atmo
+ * (ice_dyn_evp.F90:70-90).  `strength` is the result of ice_strength (:291-301),
+ * physical cells; the library does its halo update (:311).  NULL is allowed for
+ * ss_tltx/ss_tlty when tilt_from_slope == 0 and for strax/stray when wind_on_ugrid == 0. */
+typedef struct {
+    const double *aice, *vice, *vsno, *aice_init;
+    const double *strairxT, *strairyT, *strax, *stray;
+    const double *uocn, *vocn, *ss_tltx, *ss_tlty, *Cdn_ocn;
+    const double *strength;
+} evpk_step_in;
+
+/* In/out prognostic state and outputs: the arrays evp(dt) leaves modified.
+ * sigma order: stressp[0..3] = stressp_1..4 etc. (ice_flux.F90:93-97). Any output
+ * pointer may be NULL (skipped).  uvel/vvel are written on all cells (ghosts are
+ * halo-updated, ice_dyn_evp.F90:392-407); sigma on physical cells and the N/E ghost
+ * T-cells the reference computes (ice_dyn_shared.F90:528-537); the rest on physical cells. */
+typedef struct {
+    double *uvel, *vvel;
+    double *stressp[4], *stressm[4], *stress12[4];
+    int32_t *iceumask;
+    double *divu, *shear, *rdg_conv, *rdg_shear, *prs_sig;
+    double *strintx, *strinty, *strocnx, *strocny, *strocnxT, *strocnyT;
+    double *strairx, *strairy, *strtltx, *strtlty, *fm;
+    double *tmass;                             /* AusCOM: sicemass = tmass (ice_dyn_evp.F90:205-207) */
+    double *aiu, *umass, *uvel_init, *vvel_init;
+    int32_t *icetmask;
+} evpk_state;
+
+typedef struct {
+    int64_t icellt;          /* active T cells on physical cells of this rank (sum of icellt minus ghost duplicates) */
+    int64_t icellu;          /* active U cells of this rank */
+    int64_t ncell_slab;      /* physical cells of this rank */
+    int32_t nstrips;         /* wave strips launched per subcycle (active) */
+    int32_t nstrips_total;
+    int32_t subcycles_done;  /* since the last evpk_prep */
+    float loop_ms;           /* HIP-event time of the last evpk_subcycle call on the compute stream */
+    float kernel_ms;         /* HIP-event time summed over the stress+stepu kernel launches of that call */
+    int32_t kernel_launches;
+} evpk_stats;
+
+/* rank 0 creates the RCCL id; the host model broadcasts the bytes (MPI_Bcast in CICE,
+ * torch.distributed in bench.py) and every rank passes them to evpk_create. */
+int evpk_get_unique_id(void *id /* EVPK_UNIQUE_ID_BYTES */);
+
+int evpk_create(const evpk_geom *g, evpk_ctx **out);
+int evpk_set_params(evpk_ctx *c, const evpk_params *p);
+
+/* whole evp(dt): upload + prep + ndte subcycles + finish + download */
+int evpk_run(evpk_ctx *c, const evpk_step_in *in, evpk_state *st);
+
+/* the same in stages (bench.py times prep..finish with the data resident in HBM) */
+int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state *st);
+int evpk_prep(evpk_ctx *c);
+int evpk_subcycle(evpk_ctx *c, int32_t nsub);   /* advances ksub; the last-subcycle diagnostics fire at ksub == ndte */
+int evpk_finish(evpk_ctx *c);
+int evpk_download(evpk_ctx *c, evpk_state *st);
+int evpk_sync(evpk_ctx *c);
+
+int evpk_get_stats(evpk_ctx *c, evpk_stats *s);
+int evpk_destroy(evpk_ctx *c);
+const char *evpk_last_error(const evpk_ctx *c);  /* c may be NULL: error of the last failed evpk_create */
+
+/* Host-only description of this rank's halo exchange (no GPU needed): neighbours in the
+ * slab ring and the fold partner layout.  Used by the world_size-2 CPU tests.
+ *   out[0] = west rank (-1 none), out[1] = east rank (-1 none),
+ *   out[2] = first global column i0, out[3] = last global column i1,
+ *   out[4] = columns per rank used for the tripole all-gather (max slab width) */
+int evpk_slab_layout(int32_t nx_global, int32_t nranks, int32_t rank, int32_t ew_boundary,
+                     int32_t i0, int32_t i1, int32_t out[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -521,8 +521,15 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
     free(G); free(top); free(north);
 }
 
+/* Optional hook for multi-process CPU tests: after the local update (sources on other
+   ranks read as `fill`), the hook patches the ghost cells whose source lives elsewhere. */
+static orc_halo_cb g_halo_cb = NULL;
+static void *g_halo_cb_user = NULL;
+void orc_set_halo_callback(orc_halo_cb cb, void *user) { g_halo_cb = cb; g_halo_cb_user = user; }
+
 void orc_halo_r8(const orc_geom *g, double *a, int loc, int kind, double fill) {
     halo_generic(g, a, a, loc, kind, fill, 0);
+    if (g_halo_cb) g_halo_cb(a, loc, kind, fill, g_halo_cb_user);
 }
 
 void orc_halo_stress(const orc_geom *g, double *a1, const double *a2) {
@@ -534,7 +541,7 @@ void orc_halo_i4(const orc_geom *g, int32_t *a, int32_t fill) {
     size_t n = (size_t)g->nx_block * g->ny_block * g->nblocks;
     double *t = (double *)malloc(n * sizeof(double));
     for (size_t k = 0; k < n; k++) t[k] = (double)a[k];
-    halo_generic(g, t, t, ORC_LOC_CENTER, ORC_KIND_SCALAR, (double)fill, 0);
+    orc_halo_r8(g, t, ORC_LOC_CENTER, ORC_KIND_SCALAR, (double)fill);
     for (size_t k = 0; k < n; k++) a[k] = (int32_t)t[k];
     free(t);
 }

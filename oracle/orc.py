@@ -57,6 +57,9 @@ class OrcFields(ct.Structure):
                 [(n, c_f64p) for n in _F64_OUT] + [("icetmask", c_i32p)])
 
 
+HALO_CB = ct.CFUNCTYPE(None, c_f64p, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p)
+
+
 def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "evp_oracle.c")):
@@ -67,10 +70,24 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _limit_threads():
+    """OpenMP over blocks (as the reference's THRD build): use the cores this process may run on,
+    capped, and do not spin -- GPU boxes expose far more hardware threads than our share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, int(os.environ.get("EVP_ORACLE_THREADS", "16"))))
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    return int(os.environ["OMP_NUM_THREADS"])
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
+        _limit_threads()
         _lib = ct.CDLL(_LIB_PATH)
         _lib.orc_set_evp_parameters.argtypes = [ct.c_double, ct.c_int32, ct.c_int32, ct.c_double, ct.POINTER(OrcParams)]
         _lib.orc_evp.argtypes = [ct.POINTER(OrcGeom), ct.POINTER(OrcParams), ct.POINTER(OrcFields), ct.c_int,
@@ -79,6 +96,9 @@ def lib():
         _lib.orc_halo_i4.argtypes = [ct.POINTER(OrcGeom), c_i32p, ct.c_int32]
         _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
         _lib.orc_principal_stress.argtypes = [ct.c_int, ct.c_int] + [c_f64p] * 6
+        _lib.orc_set_halo_callback.argtypes = [HALO_CB, ct.c_void_p]
+        _lib.orc_stress.argtypes = ([ct.c_int] * 5 + [c_i32p] * 2 + [c_f64p] * 13 +
+                                    [ct.POINTER(c_f64p)] * 3 + [c_f64p] * 6 + [ct.POINTER(OrcParams)])
     return _lib
 
 
@@ -139,3 +159,31 @@ def halo_r8(d, a: np.ndarray, loc: int, kind: int, fill: float = 0.0):
     g, keep = make_geom(d)
     lib().orc_halo_r8(ct.byref(g), _p64(a), loc, kind, fill)
     del keep
+
+
+def set_halo_callback(fn):
+    """fn(array_view, loc, kind, fill) patches ghost cells in place; pass None to clear.
+    Returns the ctypes callback object, which the caller must keep alive."""
+    if fn is None:
+        lib().orc_set_halo_callback(ct.cast(None, HALO_CB), None)
+        return None
+    cb = HALO_CB(lambda a, loc, kind, fill, user: fn(a, loc, kind, fill))
+    lib().orc_set_halo_callback(cb, None)
+    return cb
+
+
+def stress_block(nx, ny, ksub, ndte, indxti, indxtj, arrs: Dict[str, np.ndarray], params: OrcParams):
+    """orc_stress on one (ny, nx) block; `arrs` holds uvel..strength, stressp_1.. and the outputs.
+    Returns str as an (8, ny, nx) array."""
+    L = lib()
+    strv = np.zeros((8, ny, nx))
+    sp = (c_f64p * 4)(*[_p64(arrs[f"stressp_{c}"]) for c in (1, 2, 3, 4)])
+    sm = (c_f64p * 4)(*[_p64(arrs[f"stressm_{c}"]) for c in (1, 2, 3, 4)])
+    s12 = (c_f64p * 4)(*[_p64(arrs[f"stress12_{c}"]) for c in (1, 2, 3, 4)])
+    L.orc_stress(nx, ny, ksub, ndte, len(indxti), _p32(indxti), _p32(indxtj),
+                 *[_p64(arrs[n]) for n in ("uvel", "vvel", "dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
+                                           "tarear", "tinyarea", "strength")],
+                 sp, sm, s12,
+                 *[_p64(arrs[n]) for n in ("shear", "divu", "prs_sig", "rdg_conv", "rdg_shear")],
+                 _p64(strv), ct.byref(params))
+    return strv

@@ -1,0 +1,118 @@
+"""CPU tests of the host side: block decomposition mirror, synthetic generator, and that the
+C-ABI library loads and exports every symbol include/evpk.h declares (no compute without a GPU)."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cice5_amd import blocks, constants as C, dyn, evpk, synth
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "evpk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(evpk_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 14
+    L = ct.CDLL(evpk.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in evpk.h but not exported by libevpk.so"
+    assert declared == set(evpk.EXPORTS)
+
+
+def test_struct_layouts_match_header_sizes():
+    # field counts of the ctypes mirrors == pointer/scalar counts of the C structs
+    assert ct.sizeof(evpk.Params) == 8 + 4 + 4 + 8 * 13 + 4 + 4
+    assert ct.sizeof(evpk.StepIn) == 8 * 14
+    assert ct.sizeof(evpk.State) == 8 * (2 + 12 + 1 + 21 + 1)
+    assert ct.sizeof(evpk.Geom) == 4 * 7 + 4 + 8 * 6 + 4 * 3 + 4 + 8 + 8 * 16
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    case = synth.SynthCase(nx=16, ny=12)
+    d = blocks.create_distrb_cart(16, 12, 16, 12)
+    f = synth.make_block_fields(case, d)
+    with pytest.raises(evpk.EvpkError, match="no CPU fallback"):
+        evpk.Context(d, f)
+
+
+def test_slab_layout_ring():
+    for n in (1, 2, 4, 8):
+        w = 3600 // n
+        for r in range(n):
+            lay = evpk.slab_layout(3600, n, r, C.BND_CYCLIC, r * w + 1, (r + 1) * w)
+            assert lay["west"] == (r - 1) % n and lay["east"] == (r + 1) % n and lay["wmax"] == w
+    lay = evpk.slab_layout(64, 4, 0, C.BND_OPEN, 1, 16)
+    assert lay["west"] == -1 and lay["east"] == 1
+    lay = evpk.slab_layout(64, 4, 3, C.BND_CLOSED, 49, 64)
+    assert lay["west"] == 2 and lay["east"] == -1
+
+
+def test_create_blocks_matches_reference_rules():
+    # ice_blocks.F90:148-150, 199-300
+    bl = blocks.create_blocks(100, 116, 25, 29, "cyclic", "open")
+    assert len(bl) == 16
+    b = bl[0]
+    assert (b.ilo, b.ihi, b.jlo, b.jhi) == (2, 26, 2, 30)
+    assert b.i_glob[0] == 100 and b.i_glob[1] == 1 and b.i_glob[-1] == 26      # cyclic west ghost
+    assert b.j_glob[0] == 1 and b.j_glob[1] == 1                                 # open south ghost: nghost-j+1
+    b = bl[3]
+    assert b.i_glob[-1] == 1 and b.iglob_lo == 76
+    b = bl[15]
+    assert b.j_glob[-1] == 2 * 116 - 117 + 1
+    # tripole: north ghost rows are flagged negative (:236-237), top blocks carry the flag (:167-172)
+    bl = blocks.create_blocks(48, 40, 12, 10, "cyclic", "tripole")
+    assert [b.tripole for b in bl] == [False] * 12 + [True] * 4
+    assert bl[-1].j_glob[-1] == -41
+    # padding: 100 = 3*32 + 4
+    bl = blocks.create_blocks(100, 116, 32, 40)
+    last = bl[3]
+    assert last.ihi == 5 and last.i_glob[last.ihi - 1] == 100 and last.i_glob[last.ihi + 1] == 0
+    assert bl[-1].jhi == 1 + 36
+
+
+def test_cartesian_distribution_slender_x1():
+    # ice_distribution.F90:603-640 with nprocsX = nprocs, nprocsY = 1
+    parts = [blocks.create_distrb_cart(3600, 2700, 450, 2700, nprocs=8, rank=r) for r in range(8)]
+    for r, d in enumerate(parts):
+        assert d.nblocks == 1 and d.slab() == (r * 450 + 1, (r + 1) * 450, 1, 2700)
+    parts = [blocks.create_distrb_cart(1440, 1080, 30, 27, nprocs=4, rank=r) for r in range(4)]
+    assert [d.nblocks for d in parts] == [12 * 40] * 4
+    assert parts[2].slab() == (721, 1080, 1, 1080)
+    # land-block elimination
+    work = np.ones(48 * 40, dtype=int); work[5] = 0
+    d = blocks.create_distrb_cart(1440, 1080, 30, 27, nprocs=1, rank=0, work_per_block=work)
+    assert d.nblocks == 48 * 40 - 1 and d.block_location[5] == 0
+
+
+def test_synth_fields_are_decomposition_independent():
+    case = synth.SynthCase(nx=60, ny=44, land="continents")
+    d1 = blocks.create_distrb_cart(60, 44, 60, 44)
+    d2 = blocks.create_distrb_cart(60, 44, 15, 11)
+    f1, f2 = synth.make_block_fields(case, d1), synth.make_block_fields(case, d2)
+    for n in ("dxt", "cxm", "uarea", "aice", "uocn", "strength", "tmask", "umask"):
+        assert np.array_equal(blocks.gather_global(d1, f1[n]), blocks.gather_global(d2, f2[n])), n
+    # ghost cells of an interior block edge equal the neighbour's physical cells
+    a = f2["aice"]
+    assert np.array_equal(a[0, 1:-1, -1], a[1, 1:-1, 1])
+    # metric identities of ice_grid.F90:338-369
+    g = f1
+    assert np.array_equal(g["tinyarea"], C.puny * g["tarea"])
+    assert np.allclose(g["cyp"] + g["cym"], 4.0 * g["dxhy"], rtol=0, atol=1e-6)
+    frac_land = 1.0 - blocks.gather_global(d1, f1["tmask"]).mean()
+    assert 0.15 < frac_land < 0.6
+
+
+def test_host_set_evp_parameters_equals_oracle():
+    for rev in (False, True):
+        a = dyn.set_evp_parameters(1800.0, 120, rev, 12345.0)
+        b = orc.make_params(1800.0, 120, 12345.0, revised_evp=rev)
+        for n in ("revp", "ecci", "denom1", "arlx1i", "brlx"):
+            assert getattr(a, n) == getattr(b, n)

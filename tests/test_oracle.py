@@ -1,0 +1,212 @@
+"""CPU tests of the oracle (oracle/evp_oracle.c): the reference-produced pins that exist,
+decomposition invariance, analytic properties of stress/stepu, halo rules.
+
+The oracle is PARITY UNPINNED (see oracle/evp_oracle.h): the only numbers produced by the
+reference itself are the init_evp printout recorded in SURVEY.md S8c; the rest of this file
+checks properties that any correct restatement of the Fortran must have.
+"""
+import numpy as np
+import pytest
+
+from cice5_amd import blocks, constants as C, synth
+from oracle import orc
+from tests import util
+
+
+def test_init_evp_printout_pin():
+    # SURVEY.md S8c (reference run, gx3, dt=3600, ndte=120): "arlx, brlx 86.4 120.", "dte = 30.", "tdamp = 1296."
+    p = orc.make_params(3600.0, 120, xmin=1.0)
+    assert 1.0 / p.arlx1i == pytest.approx(86.4, rel=1e-15)
+    assert p.brlx == 120.0
+    assert 1.0 / p.dtei == 30.0
+    assert C.eyc * 3600.0 == pytest.approx(1296.0, rel=1e-15)      # "tdamp" as printed, ice_dyn_shared.F90:128
+    assert p.denom1 == 1.0 / (1.0 + p.arlx1i)
+    assert p.ecci == 0.25 and p.revp == 0.0
+
+
+def test_revised_evp_parameters():
+    # ice_dyn_shared.F90:226-233
+    xmin = 5000.0
+    p = orc.make_params(900.0, 240, xmin=xmin, revised_evp=True)
+    assert p.revp == 1.0
+    assert p.arlx1i == 2.0 * 5.5e-3 / 0.86
+    assert p.brlx == 2.0 * 0.86 * 5.5e-3 * (0.25 * 1.0e11 * 900.0) / xmin ** 2
+
+
+def _run(nx, ny, bsx, bsy, ndte=20, **kw):
+    case, d, f = util.make_case(nx, ny, bsx, bsy, **kw)
+    p = orc.make_params(3600.0, ndte, synth.global_min_dx(case))
+    counts = orc.evp(d, p, f)
+    return case, d, f, counts
+
+
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_decomposition_invariance(ns):
+    # the reference is bit-identical across block decompositions; so is the oracle
+    ref = None
+    for bs in [(48, 40), (12, 10), (24, 20), (16, 8)]:
+        case, d, f, (nt, nu, _) = _run(48, 40, *bs, ns=ns, land="continents")
+        g = {k: blocks.gather_global(d, f[k]) for k in ["uvel", "vvel", "divu", "strocnxT", "prs_sig"] + util.SIGMA}
+        if ref is None:
+            ref, ref_counts = g, (nt, nu)
+            assert nu > 100 and np.abs(g["uvel"]).max() > 1e-3
+        else:
+            assert (nt, nu) == ref_counts
+            for k in g:
+                assert np.array_equal(g[k], ref[k]), (bs, k)
+
+
+def test_rest_state_stays_at_rest():
+    # no wind, no current, no tilt: u = 0 is a fixed point (Delta = 0 -> replacement pressure term vanishes)
+    case, d, f = util.make_case(40, 36, 40, 36)
+    for n in ("strairxT", "strairyT", "uocn", "vocn"):
+        f[n][...] = 0.0
+    p = orc.make_params(3600.0, 10, synth.global_min_dx(case))
+    _, nu, _ = orc.evp(d, p, f)
+    assert nu > 0
+    assert not f["uvel"].any() and not f["vvel"].any()
+    # sigma_p relaxes towards -P/2*... with Delta=0: stressp = (0 + c1*(0-0))*denom1 = 0
+    for k in util.SIGMA:
+        assert not f[k].any()
+
+
+def _uniform_block(nx, ny, L):
+    a = {n: np.zeros((ny, nx)) for n in ["uvel", "vvel", "dxhy", "dyhx", "shear", "divu", "prs_sig", "rdg_conv",
+                                         "rdg_shear", "strength"] + util.SIGMA}
+    for n in ("dxt", "dyt", "cxp", "cyp"):
+        a[n] = np.full((ny, nx), L)
+    for n in ("cxm", "cym"):
+        a[n] = np.full((ny, nx), -L)          # cym = -(1.5*HTE - 0.5*HTE) on a uniform grid
+    a["tarear"] = np.full((ny, nx), 1.0 / (L * L))
+    a["tinyarea"] = np.full((ny, nx), C.puny * L * L)
+    return a
+
+
+def test_stress_linear_velocity_field():
+    # uniform Cartesian grid, u = a*x, v = b*y: divergence a+b, tension a-b, no shear (ice_dyn_evp.F90:627-677)
+    nx, ny, L = 12, 10, 1024.0
+    a = _uniform_block(nx, ny, L)
+    ca, cb = 2.0 ** -20, -(2.0 ** -21)
+    I, J = np.meshgrid(np.arange(1, nx + 1), np.arange(1, ny + 1))
+    a["uvel"][...] = ca * I * L
+    a["vvel"][...] = cb * J * L
+    a["strength"][...] = 1.0e4
+    idx = [(i, j) for j in range(2, ny) for i in range(2, nx)]
+    ti = np.array([i for i, _ in idx], dtype=np.int32)
+    tj = np.array([j for _, j in idx], dtype=np.int32)
+    p = orc.make_params(3600.0, 1, 1.0)
+    strv = orc.stress_block(nx, ny, 1, 1, ti, tj, a, p)
+    inner = (slice(1, ny - 1), slice(1, nx - 1))
+    assert np.all(a["divu"][inner] == ca + cb)
+    assert np.all(a["shear"][inner] == abs(ca - cb))
+    delta = np.sqrt((ca + cb) ** 2 + 0.25 * (ca - cb) ** 2)
+    assert np.allclose(a["rdg_shear"][inner], 0.5 * (delta - abs(ca + cb)), rtol=1e-14)
+    assert np.all(a["rdg_conv"][inner] == -min(ca + cb, 0.0))
+    # replacement pressure: c0ne*Deltane = strength when Delta > tinyarea
+    assert np.allclose(a["prs_sig"][inner], 1.0e4, rtol=1e-15)
+    # all four corners see the same strain -> sigma_k equal; a uniform stress field has zero divergence:
+    assert np.array_equal(a["stressp_1"], a["stressp_3"]) and np.array_equal(a["stressm_2"], a["stressm_4"])
+    s = strv[:, 2:ny - 2, 2:nx - 2]
+    fx = s[0][:-1, :-1] + s[1][:-1, 1:] + s[2][1:, :-1] + s[3][1:, 1:]
+    fy = s[4][:-1, :-1] + s[5][1:, :-1] + s[6][:-1, 1:] + s[7][1:, 1:]
+    scale = np.abs(s).max()
+    assert np.abs(fx).max() <= 1e-12 * scale and np.abs(fy).max() <= 1e-12 * scale
+
+
+def test_stress_rigid_translation_has_no_strain():
+    nx, ny, L = 8, 8, 2048.0
+    a = _uniform_block(nx, ny, L)
+    a["uvel"][...] = 0.125
+    a["vvel"][...] = -0.25
+    a["strength"][...] = 5.0e3
+    ti = np.array([4], dtype=np.int32); tj = np.array([5], dtype=np.int32)
+    p = orc.make_params(3600.0, 1, 1.0)
+    strv = orc.stress_block(nx, ny, 1, 1, ti, tj, a, p)
+    assert a["divu"][4, 3] == 0.0 and a["shear"][4, 3] == 0.0
+    assert not strv.any() and not a["stressp_1"].any()
+
+
+def test_free_drift_balance():
+    # strength = 0: after many subcycles stepu settles where the momentum tendency vanishes:
+    # forcex + taux + fm*v - vrel*cosw*u = 0 (ice_dyn_shared.F90:715-737 with d/dt -> 0)
+    case, d, f = util.make_case(40, 36, 40, 36, ice="full")
+    f["strength"][...] = 0.0
+    p = orc.make_params(4.0e6, 2000, synth.global_min_dx(case))     # ~1600 inertial/drag time scales
+    orc.evp(d, p, f)
+    m = (f["iceumask"] > 0) & util.cell_mask(d, "phys")
+    u, v = f["uvel"][m], f["vvel"][m]
+    aiu, fm = f["aiu"][m], f["fm"][m]
+    du, dv = f["uocn"][m] - u, f["vocn"][m] - v
+    vrel = aiu * C.rhow * C.dragio * np.sqrt(du ** 2 + dv ** 2)
+    fx = f["strairx"][m] + f["strtltx"][m]
+    fy = f["strairy"][m] + f["strtlty"][m]
+    rx = fx + vrel * du + fm * v
+    ry = fy + vrel * dv - fm * u
+    scale = np.abs(fx).max() + np.abs(fy).max()
+    assert np.abs(rx).max() < 1e-6 * scale and np.abs(ry).max() < 1e-6 * scale
+
+
+def test_halo_cyclic_open():
+    d = blocks.create_distrb_cart(12, 8, 4, 4)
+    a = blocks.to_blocks(d, lambda I, J: 100.0 * J + I + 0.0 * (I * J))
+    a[~util.cell_mask(d, "phys")] = -7.0
+    orc.halo_r8(d, a, C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+    for n, b in enumerate(d.local_blocks):
+        for j in range(d.ny_block):
+            for i in range(d.nx_block):
+                gi = b.iglob_lo + (i + 1 - b.ilo)
+                gj = b.jglob_lo + (j + 1 - b.jlo)
+                gi = (gi - 1) % 12 + 1
+                exp = 100.0 * gj + gi if 1 <= gj <= 8 else 0.0
+                assert a[n, j, i] == exp, (n, i, j)
+
+
+def test_halo_tripole_rules():
+    nx, ny = 16, 6
+    d = blocks.create_distrb_cart(nx, ny, 8, 3, ns_boundary_type="tripole")
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((ny + 2, nx + 2))
+    # centre scalar: ghost(i, ny+1) = F(nx-i+1, ny), top row untouched  (serial/ice_boundary.F90:804-807, 3769-3776)
+    a = blocks.to_blocks(d, lambda I, J: G[np.clip(J, 0, ny + 1), (I - 1) % nx + 1] + 0.0 * (I * J))
+    ref = a.copy()
+    orc.halo_r8(d, a, C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+    for n, b in enumerate(d.local_blocks):
+        if not b.tripole:
+            continue
+        for i in range(d.nx_block):
+            gi = (b.iglob_lo + (i + 1 - b.ilo) - 1) % nx + 1
+            assert a[n, b.jhi, i] == G[ny, nx - gi + 1]
+        assert np.array_equal(a[n, b.jhi - 1, b.ilo - 1:b.ihi], ref[n, b.jhi - 1, b.ilo - 1:b.ihi])
+    # NE-corner vector: after one update the top row is anti-symmetric about the fold, and a second
+    # update changes nothing (the two poles i = nx/2 and nx hold 0, as on a real grid where they are land)
+    G2 = G.copy()
+    G2[ny, nx // 2] = 0.0
+    G2[ny, nx] = 0.0
+    u = blocks.to_blocks(d, lambda I, J: G2[np.clip(J, 0, ny + 1), (I - 1) % nx + 1] + 0.0 * (I * J))
+    orc.halo_r8(d, u, C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+    top = blocks.gather_global(d, u)[ny - 1]             # global row ny, index 0 = column 1
+    for i in range(1, nx // 2):
+        assert top[i - 1] == -top[nx - i - 1]
+        assert top[i - 1] == 0.5 * (G2[ny, i] - G2[ny, nx - i])
+    u2 = u.copy()
+    orc.halo_r8(d, u2, C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+    assert np.array_equal(u, u2)
+    # ghost(i, ny+1) = -F(nx-i, ny-1)
+    for n, b in enumerate(d.local_blocks):
+        if b.tripole:
+            for i in range(b.ilo - 1, b.ihi):
+                gi = b.iglob_lo + (i + 1 - b.ilo)
+                src = nx - gi if nx - gi >= 1 else nx
+                assert u[n, b.jhi, i] == -G2[ny - 1, src]
+
+
+def test_principal_stress():
+    import ctypes as ct
+    nx = ny = 4
+    sp = np.full((ny, nx), -3.0); sm = np.full((ny, nx), 4.0); s12 = np.full((ny, nx), 1.5)
+    prs = np.full((ny, nx), 2.0); prs[0, 0] = 0.0
+    s1 = np.zeros((ny, nx)); s2 = np.zeros((ny, nx))
+    orc.lib().orc_principal_stress(nx, ny, *[x.ctypes.data_as(orc.c_f64p) for x in (sp, sm, s12, prs, s1, s2)])
+    r = np.sqrt(16.0 + 4.0 * 2.25)
+    assert s1[1, 1] == (0.5 * (-3.0 + r)) / 2.0 and s2[1, 1] == (0.5 * (-3.0 - r)) / 2.0
+    assert s1[0, 0] == 1.0e30 and s2[0, 0] == 1.0e30      # spval_dbl where prs_sig <= puny

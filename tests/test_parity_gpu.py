@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path (libevpk through its C ABI) against the CPU oracle on the
+same bytes.  fp64, bit-exact: both sides evaluate the reference's operation order without
+FMA contraction, and gfx950's fp64 sqrt/divide are correctly rounded, so equality is demanded
+(signed zeros compare equal).  The oracle itself is PARITY UNPINNED (oracle/evp_oracle.h)."""
+import os
+
+import numpy as np
+import pytest
+
+from cice5_amd import blocks, constants as C, dyn, evpk, synth
+from oracle import orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(nx, ny, bsx, bsy, *, ndte=120, dt=3600.0, ncalls=1, revised_evp=False, cosw=1.0, sinw=0.0,
+          tilt_from_slope=False, wind_on_ugrid=False, ns="open", nsub=None, **kw):
+    case, d, f = util.make_case(nx, ny, bsx, bsy, ns=ns, **kw)
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(dt, ndte, xmin, revised_evp=revised_evp, cosw=cosw, sinw=sinw,
+                        tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
+    solver = dyn.EvpDynamics(d, fg, ndte=ndte, revised_evp=revised_evp, xmin=xmin, cosw=cosw, sinw=sinw,
+                             tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
+    solver.init_evp(dt)
+    # host mirror of set_evp_parameters must agree with the oracle's to the bit
+    for n in ("revp", "ecci", "denom1", "arlx1i", "brlx"):
+        assert getattr(solver.params, n) == getattr(p, n), n
+    for call in range(ncalls):
+        if call:   # next step: thermodynamics changed the ice a little, the wind turned
+            for ff in (fo, fg):
+                ff["aice"] *= 0.97
+                ff["vice"] *= 0.97
+                ff["strairxT"], ff["strairyT"] = ff["strairyT"].copy(), -ff["strairxT"]
+        nt, nu, _ = orc.evp(d, p, fo)
+        solver.evp(dt)
+        st = solver.ctx.stats()
+        assert (st.icellt, st.icellu) == (nt, nu)
+        bad = util.compare(d, fg, fo)
+        assert not bad, f"call {call}: {bad[:6]}"
+    assert nu > 0 and np.abs(fo["uvel"]).max() > 1e-3
+    solver.close()
+    return fo, fg
+
+
+def test_cfg1_gx3_one_block():
+    """BASELINE config 1 shape: gx3 100x116, one 102x118 block, ndte=120."""
+    _both(100, 116, 100, 116, land="continents")
+
+
+def test_cfg1_gx3_sixteen_blocks():
+    """same grid cut into 16 blocks of 25x29 (the reference's serial multi-block mode)."""
+    _both(100, 116, 25, 29, land="continents")
+
+
+def test_cfg2_gx1_one_block():
+    """BASELINE config 2: gx1 320x384, whole grid in one device block, ndte=120."""
+    _both(320, 384, 320, 384)
+
+
+def test_cfg2_gx1_full_ice():
+    _both(320, 384, 320, 384, ice="full", ndte=40)
+
+
+def test_cfg3_auscom_360x300_slender_blocks():
+    """BASELINE config 3: 360x300 in 24 blocks of 15x300 (bld/config.nci.auscom.360x300), land mask."""
+    _both(360, 300, 15, 300, land="continents")
+
+
+def test_cfg3_auscom_360x300_six_blocks():
+    """config.ubuntu.auscom.360x300: 6 blocks of 60x300."""
+    _both(360, 300, 60, 300, land="continents", ndte=60)
+
+
+def test_padded_blocks():
+    """block size that does not divide the grid (ice_blocks.F90:148-150 padding)."""
+    _both(100, 116, 32, 40, land="continents", ndte=30)
+
+
+def test_two_calls_warm_start():
+    """second evp() call starts from non-zero u, sigma and iceumask (new-ice / lost-ice branches of evp_prep2)."""
+    _both(100, 116, 25, 29, land="continents", ndte=40, ncalls=3)
+
+
+def test_revised_evp():
+    _both(100, 116, 50, 58, land="continents", revised_evp=True, ndte=60, ncalls=2)
+
+
+def test_turning_angle_and_slope_tilt():
+    """AusCOM namelist knobs: cosw/sinw (ice_dyn_shared.F90:66-72) and use_ocnslope (:604-608)."""
+    th = np.deg2rad(25.0)
+    _both(100, 116, 50, 58, land="continents", cosw=float(np.cos(th)), sinw=float(np.sin(th)),
+          tilt_from_slope=True, ndte=40)
+
+
+def test_wind_on_ugrid():
+    """ACCESS: strairx/y := strax/stray, no t2ugrid_vector (ice_dyn_evp.F90:226-228)."""
+    _both(100, 116, 50, 58, land="continents", wind_on_ugrid=True, ndte=40)
+
+
+def test_open_ew_boundary_not_cyclic():
+    case = synth.SynthCase(nx=64, ny=48, ew_boundary=C.BND_OPEN)
+    d = blocks.create_distrb_cart(64, 48, 16, 16, ew_boundary_type="open")
+    f = synth.make_block_fields(case, d)
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, 30, xmin)
+    orc.evp(d, p, fo)
+    s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    assert not util.compare(d, fg, fo)
+    s.close()
+
+
+@pytest.mark.parametrize("bs", [(48, 40), (12, 10), (24, 20)])
+def test_tripole_fold(bs):
+    """ns_boundary_type = 'tripole' (ACCESS-OM2): per-subcycle velocity fold with top-row symmetrisation
+    and the post-loop ice_HaloUpdate_stress pairs (ice_dyn_evp.F90:416-481)."""
+    _both(48, 40, *bs, ns="tripole", land="continents", ndte=60, ncalls=2)
+
+
+def test_strip_rows_do_not_matter():
+    """the wave-strip height is a pure scheduling choice: results are bit-identical for any R."""
+    case, d, f = util.make_case(320, 384, 320, 384)
+    xmin = synth.global_min_dx(case)
+    out = []
+    for R in ("2", "7", "32"):
+        os.environ["EVPK_STRIP_ROWS"] = R
+        g = util.clone(f)
+        s = dyn.EvpDynamics(d, g, ndte=24, xmin=xmin)
+        s.init_evp(3600.0)
+        s.evp(3600.0)
+        s.close()
+        out.append(g)
+    del os.environ["EVPK_STRIP_ROWS"]
+    for g in out[1:]:
+        assert not util.compare(d, g, out[0])
+
+
+def test_staged_api_equals_run():
+    """upload/prep/subcycle/finish/download == evpk_run; subcycles may be issued in pieces."""
+    case, d, f = util.make_case(100, 116, 25, 29, land="continents")
+    xmin = synth.global_min_dx(case)
+    a, b = util.clone(f), util.clone(f)
+    s = dyn.EvpDynamics(d, a, ndte=50, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    s.close()
+    s = dyn.EvpDynamics(d, b, ndte=50, xmin=xmin)
+    s.init_evp(3600.0)
+    s.ctx.upload(b); s.ctx.prep(); s.ctx.subcycle(17); s.ctx.subcycle(0); s.ctx.subcycle(33); s.ctx.finish(); s.ctx.download(b)
+    assert s.ctx.stats().subcycles_done == 50
+    s.close()
+    assert not util.compare(d, b, a)
+
+
+def test_errors_are_reported_not_fatal():
+    case, d, f = util.make_case(100, 116, 100, 116)
+    ctx = evpk.Context(d, f)
+    with pytest.raises(evpk.EvpkError, match="set_params"):
+        ctx.upload(f)
+    p = dyn.set_evp_parameters(3600.0, 120, False, 1.0)
+    ctx.set_params(p)
+    with pytest.raises(evpk.EvpkError, match="upload"):
+        ctx.prep()
+    g = dict(f); g["aice"] = None
+    with pytest.raises(evpk.EvpkError, match="NULL"):
+        ctx.upload(g)
+    ctx.close()
+    # a context that does not cover the whole grid on one rank is refused
+    d2 = blocks.create_distrb_cart(100, 116, 50, 116, nprocs=2, rank=0)
+    d2.nprocs = 1
+    f2 = synth.make_block_fields(case, d2)
+    with pytest.raises(evpk.EvpkError, match="whole global grid"):
+        evpk.Context(d2, f2)
+
+
+def test_full_size_3600x2700_properties():
+    """BASELINE headline grid on one GPU.  The oracle checks the first subcycles on the whole grid
+    bit for bit; then size-independent properties after more subcycles: finite fields, inactive cells
+    untouched, speeds bounded, and one more evp() on the result reproduces itself from a restart
+    (uvel/vvel/sigma/iceumask are the complete cross-step state, ice_restart_driver.F90:122-176)."""
+    nx, ny = 3600, 2700
+    case, d, f = util.make_case(nx, ny, 450, 2700, land="continents", dt=450.0)   # 8 blocks = the 8-GPU slabs
+    xmin = synth.global_min_dx(case)
+    fo = util.clone(f)
+    p = orc.make_params(450.0, 120, xmin)
+    nt, nu, _ = orc.evp(d, p, fo, nsub=3)
+    s = dyn.EvpDynamics(d, f, ndte=120, xmin=xmin)
+    s.init_evp(450.0)
+    g = util.clone(f)
+    s.fields = g
+    s.ctx.upload(g); s.ctx.prep(); s.ctx.subcycle(3); s.ctx.finish(); s.ctx.download(g)
+    st = s.ctx.stats()
+    assert (st.icellt, st.icellu) == (nt, nu)
+    bad = util.compare(d, g, fo, names=["uvel", "vvel", "strocnxT", "strocnyT", "aiu", "umass", "fm", "iceumask"] + util.SIGMA)
+    assert not bad, bad[:6]
+    del fo
+    # full evp
+    g = util.clone(f)
+    s.fields = g
+    s.evp(450.0)
+    phys = util.cell_mask(d, "phys")
+    for n in ["uvel", "vvel", "divu", "shear", "strintx", "strocnxT"] + util.SIGMA:
+        assert np.isfinite(g[n][phys]).all(), n
+    speed = np.hypot(g["uvel"], g["vvel"])[phys]
+    assert 0.01 < speed.max() < 3.0
+    off = phys & (g["iceumask"] == 0)
+    assert not g["uvel"][off].any() and not g["vvel"][off].any()
+    offT = phys & (g["icetmask"] == 0)
+    assert not g["stressp_1"][offT].any() and not g["divu"][offT].any()
+    # restart exactness: same inputs + the state just produced, through a NEW context, twice
+    h1, h2 = util.clone(g), util.clone(g)
+    s.fields = h1
+    s.evp(450.0)
+    s.close()
+    s2 = dyn.EvpDynamics(d, h2, ndte=120, xmin=xmin)
+    s2.set_evp_parameters(450.0)
+    s2.evp(450.0)
+    s2.close()
+    assert not util.compare(d, h1, h2)
