@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--ns", default="open", choices=["open", "tripole"])
     ap.add_argument("--xblocks", type=int, default=8, help="blocks across x (one slab each at 8 GPUs)")
     ap.add_argument("--yblocks", type=int, default=10, help="blocks across y")
-    ap.add_argument("--cpu-subcycles", type=int, default=6, help="subcycles of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-subcycles", type=int, default=120, help="subcycles of the CPU baseline sample (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_subcycle launch from a separate rocprofv3 --pmc pass (profiles/)")
     return ap.parse_args()
