@@ -64,6 +64,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the EVP path has no CPU fallback)")
+    if os.environ.get("EVPK_FORCE_DEVICE") is not None:      # debugging only: several ranks on one GPU
+        local_rank = int(os.environ["EVPK_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     uid = None
     if world > 1:

@@ -46,6 +46,7 @@ struct evpk_ctx {
     long long icellt = 0, icellu = 0;
     // exchange
     int max_nf = NSTATE;
+    double *sendbuf = nullptr, *recvbuf = nullptr;   // [W edge | E edge] and [from east | from west]
     double *sendW = nullptr, *sendE = nullptr, *recvW = nullptr, *recvE = nullptr;
     double *foldbuf = nullptr, *foldloc = nullptr, *foldall = nullptr;
     int wmax = 0;
@@ -57,6 +58,7 @@ struct evpk_ctx {
     float loop_ms = 0.f, kernel_ms = 0.f;
     int kernel_launches = 0;
     bool time_kernels = false;
+    bool force_exchange = false;   // EVPK_FORCE_EXCHANGE=1: single rank takes the multi-rank pack/exchange/unpack path (tests)
     std::string err;
 };
 
@@ -107,29 +109,49 @@ extern "C" int evpk_get_unique_id(void *id) {
 extern "C" const char *evpk_last_error(const evpk_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 // ---- host<->device transfer of one field -------------------------------------------------
-template <typename T>
-static int upload_plane(evpk_ctx *c, const T *host, T *dev_plane) {
+static int upload_f(evpk_ctx *c, const double *host, int f) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
-    if (!c->full_cover)
-        HIPCHK(c, hipMemsetAsync(dev_plane, 0, (size_t)c->s.pitch * (c->s.nyl + 2) * sizeof(T), c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!c->full_cover) hipLaunchKernelGGL(k_fill_plane, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, f, 0.0);
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    hipLaunchKernelGGL(k_gather<T>, g, b, 0, c->stream, c->s, c->d_bd, c->nblocks, c->nxb, c->nyb, (const T *)c->stage, dev_plane);
+    hipLaunchKernelGGL(k_gather_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, (const double *)c->stage, f);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
-template <typename T>
-static int download_plane(evpk_ctx *c, T *host, const T *dev_plane, int mode) {
+static int upload_m(evpk_ctx *c, const int32_t *host, int32_t *dev_plane) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    // start from the caller's bytes so that untouched cells keep their values
-    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (!c->full_cover) HIPCHK(c, hipMemsetAsync(dev_plane, 0, mask_elems(c->s) * sizeof(int32_t), c->stream));
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    hipLaunchKernelGGL(k_scatter<T>, g, b, 0, c->stream, c->s, c->d_bd, c->nblocks, c->nxb, c->nyb, dev_plane, (T *)c->stage, mode);
+    hipLaunchKernelGGL(k_gather_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, (const int32_t *)c->stage, dev_plane);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+// downloads start from the caller's bytes so that cells the reference leaves untouched keep their values
+static int download_f(evpk_ctx *c, double *host, int f, int mode) {
+    if (!host) return 0;
+    const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, c->stage, mode);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int mode) {
+    if (!host) return 0;
+    const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, (int32_t *)c->stage, mode);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -148,7 +170,7 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     if (c->ns == EVPK_BND_TRIPOLE) {
         if (!stress_mode) hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 0);
         const int fp = stress_mode ? fsrc_fold : f;
-        if (c->nranks == 1) {
+        if (c->nranks == 1 && !c->force_exchange) {
             hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, s, fp, nf, c->foldbuf, s.i0 - 1);
         } else {
             // pack own segment [nf][2][wmax], all-gather, re-pack into [nf][2][nxg]
@@ -156,7 +178,10 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
             Slab t = s; t.nxg = c->wmax;   // local segment addressed with gofs = 0
             hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, fp, nf, c->foldloc, 0);
             const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
-            NCCLCHK(c, ncclAllGather(c->foldloc, c->foldall, seg, ncclDouble, c->comm, c->stream));
+            if (c->nranks > 1)
+                NCCLCHK(c, ncclAllGather(c->foldloc, c->foldall, seg, ncclDouble, c->comm, c->stream));
+            else
+                HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
             for (int r = 0; r < c->nranks; r++) {
                 const int w = c->slab_i0[r + 1] - c->slab_i0[r];
                 for (int q = 0; q < nf; q++)
@@ -174,17 +199,34 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 1);
     }
     // E-W over all rows (ghost rows included, which carries the corners)
-    if (c->nranks == 1) {
+    if (c->nranks == 1 && !c->force_exchange) {
         hipLaunchKernelGGL(k_halo_ew_local, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill);
     } else {
+        // edge columns over all rows: sendbuf = [my W edge | my E edge], recvbuf = [east ghost | west ghost].
+        // The W edge goes to the west neighbour (it is their east ghost), the E edge to the east one.
         const size_t cnt = (size_t)nf * (s.nyl + 2);
+        c->sendW = c->sendbuf; c->sendE = c->sendbuf + cnt;
+        c->recvE = c->recvbuf; c->recvW = c->recvbuf + cnt;
         hipLaunchKernelGGL(k_ew_pack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->sendW, c->sendE);
-        NCCLCHK(c, ncclGroupStart());
-        if (c->west >= 0) NCCLCHK(c, ncclSend(c->sendW, cnt, ncclDouble, c->west, c->comm, c->stream));
-        if (c->east >= 0) NCCLCHK(c, ncclSend(c->sendE, cnt, ncclDouble, c->east, c->comm, c->stream));
-        if (c->east >= 0) NCCLCHK(c, ncclRecv(c->recvE, cnt, ncclDouble, c->east, c->comm, c->stream));
-        if (c->west >= 0) NCCLCHK(c, ncclRecv(c->recvW, cnt, ncclDouble, c->west, c->comm, c->stream));
-        NCCLCHK(c, ncclGroupEnd());
+        if (c->nranks == 1) {          // forced exchange with myself (cyclic): my W edge is my own east ghost
+            if (c->west >= 0) {
+                HIPCHK(c, hipMemcpyAsync(c->recvE, c->sendW, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->recvW, c->sendE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
+            }
+        } else if (c->west == c->east && c->west >= 0) {
+            // two ranks on a cyclic ring: one message each way carries both edges
+            NCCLCHK(c, ncclGroupStart());
+            NCCLCHK(c, ncclSend(c->sendbuf, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
+            NCCLCHK(c, ncclRecv(c->recvbuf, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
+            NCCLCHK(c, ncclGroupEnd());
+        } else {
+            NCCLCHK(c, ncclGroupStart());
+            if (c->west >= 0) NCCLCHK(c, ncclSend(c->sendW, cnt, ncclDouble, c->west, c->comm, c->stream));
+            if (c->east >= 0) NCCLCHK(c, ncclSend(c->sendE, cnt, ncclDouble, c->east, c->comm, c->stream));
+            if (c->east >= 0) NCCLCHK(c, ncclRecv(c->recvE, cnt, ncclDouble, c->east, c->comm, c->stream));
+            if (c->west >= 0) NCCLCHK(c, ncclRecv(c->recvW, cnt, ncclDouble, c->west, c->comm, c->stream));
+            NCCLCHK(c, ncclGroupEnd());
+        }
         hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->recvW,
                            (const double *)c->recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
     }
@@ -197,7 +239,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->sendW, c->sendE, c->recvW, c->recvE, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -249,24 +291,25 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     s.nxl = i1 - i0 + 1; s.nyl = j1 - j0 + 1; s.i0 = i0; s.j0 = j0; s.nxg = g->nx_global; s.nyg = g->ny_global;
     if (g->ns_boundary == EVPK_BND_TRIPOLE && (s.nyl < 2 || (g->nx_global & 1))) FAIL(c, "tripole needs ny >= 2 and even nx_global");
     c->full_cover = (covered == (long long)s.nxl * s.nyl);
-    s.pitch = ((C0 + s.nxl + 2 + 15) / 16) * 16;
-    s.fstride = (((size_t)s.pitch * (s.nyl + 2) + 64 + 15) / 16) * 16;   // +64: strips may read one lane past the row end
+    s.pitch = ((C0 + s.nxl + 2 + 7) / 8) * 8;
+    s.rstride = NP * s.pitch;
 
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
-    HIPCHK(c, hipMalloc(&s.F, sizeof(double) * s.fstride * F_COUNT));
-    HIPCHK(c, hipMemsetAsync(s.F, 0, sizeof(double) * s.fstride * F_COUNT, c->stream));
-    HIPCHK(c, hipMalloc(&s.tmask, sizeof(int32_t) * s.fstride));
-    HIPCHK(c, hipMalloc(&s.umask, sizeof(int32_t) * s.fstride));
-    HIPCHK(c, hipMalloc(&s.iceumask, sizeof(int32_t) * s.fstride));
-    HIPCHK(c, hipMalloc(&s.cmask, s.fstride));
-    HIPCHK(c, hipMalloc(&s.tmphm, s.fstride));
-    HIPCHK(c, hipMemsetAsync(s.tmask, 0, sizeof(int32_t) * s.fstride, c->stream));
-    HIPCHK(c, hipMemsetAsync(s.umask, 0, sizeof(int32_t) * s.fstride, c->stream));
-    HIPCHK(c, hipMemsetAsync(s.iceumask, 0, sizeof(int32_t) * s.fstride, c->stream));
-    HIPCHK(c, hipMemsetAsync(s.cmask, 0, s.fstride, c->stream));
-    HIPCHK(c, hipMemsetAsync(s.tmphm, 0, s.fstride, c->stream));
+    const size_t nd = slab_doubles(s), nm = mask_elems(s);
+    HIPCHK(c, hipMalloc(&s.F, sizeof(double) * nd));
+    HIPCHK(c, hipMemsetAsync(s.F, 0, sizeof(double) * nd, c->stream));
+    HIPCHK(c, hipMalloc(&s.tmask, sizeof(int32_t) * nm));
+    HIPCHK(c, hipMalloc(&s.umask, sizeof(int32_t) * nm));
+    HIPCHK(c, hipMalloc(&s.iceumask, sizeof(int32_t) * nm));
+    HIPCHK(c, hipMalloc(&s.cmask, nm));
+    HIPCHK(c, hipMalloc(&s.tmphm, nm));
+    HIPCHK(c, hipMemsetAsync(s.tmask, 0, sizeof(int32_t) * nm, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.umask, 0, sizeof(int32_t) * nm, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.iceumask, 0, sizeof(int32_t) * nm, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.cmask, 0, nm, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.tmphm, 0, nm, c->stream));
     HIPCHK(c, hipMalloc(&c->d_bd, sizeof(BlockDesc) * g->nblocks));
     HIPCHK(c, hipMemcpyAsync(c->d_bd, c->bd.data(), sizeof(BlockDesc) * g->nblocks, hipMemcpyHostToDevice, c->stream));
     c->stage_n = (size_t)g->nblocks * g->ny_block * g->nx_block;
@@ -293,9 +336,17 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     int lay[5];
     evpk_slab_layout(g->nx_global, g->nranks, g->rank, g->ew_boundary, i0, i1, lay);
     c->west = lay[0]; c->east = lay[1];
-    const size_t ebuf = sizeof(double) * (size_t)c->max_nf * (s.nyl + 2);
-    HIPCHK(c, hipMalloc(&c->sendW, ebuf)); HIPCHK(c, hipMalloc(&c->sendE, ebuf));
-    HIPCHK(c, hipMalloc(&c->recvW, ebuf)); HIPCHK(c, hipMalloc(&c->recvE, ebuf));
+    {
+        const char *fe = getenv("EVPK_FORCE_EXCHANGE");
+        c->force_exchange = fe && atoi(fe) != 0;
+    }
+    const size_t eslot = (size_t)c->max_nf * (s.nyl + 2);
+    HIPCHK(c, hipMalloc(&c->sendbuf, sizeof(double) * 2 * eslot));
+    HIPCHK(c, hipMalloc(&c->recvbuf, sizeof(double) * 2 * eslot));
+    HIPCHK(c, hipMemsetAsync(c->sendbuf, 0, sizeof(double) * 2 * eslot, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->recvbuf, 0, sizeof(double) * 2 * eslot, c->stream));
+    c->sendW = c->sendbuf; c->sendE = c->sendbuf + eslot;      // re-pointed per call: [W edge | E edge], nf*(nyl+2) each
+    c->recvE = c->recvbuf; c->recvW = c->recvbuf + eslot;      // [east ghost | west ghost]
     if (g->ns_boundary == EVPK_BND_TRIPOLE) {
         HIPCHK(c, hipMalloc(&c->foldbuf, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg));
         HIPCHK(c, hipMemsetAsync(c->foldbuf, 0, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg, c->stream));
@@ -330,6 +381,10 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     } else {
         c->slab_i0 = {1, g->nx_global + 1};
         c->wmax = g->nx_global;
+        if (c->force_exchange && g->ns_boundary == EVPK_BND_TRIPOLE) {
+            HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+            HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+        }
     }
 
     // time-invariant planes
@@ -339,11 +394,11 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         {g->uarea, F_UAREA}, {g->uarear, F_UAREAR}, {g->fcor, F_FCOR}};
     for (auto &e : gp) {
         if (!e.h) FAIL(c, "a grid plane pointer is NULL");
-        if (upload_plane<double>(c, e.h, plane(s, e.f))) return 1;
+        if (upload_f(c, e.h, e.f)) return 1;
     }
     if (!g->tmask || !g->umask) FAIL(c, "tmask/umask is NULL");
-    if (upload_plane<int32_t>(c, g->tmask, s.tmask)) return 1;
-    if (upload_plane<int32_t>(c, g->umask, s.umask)) return 1;
+    if (upload_m(c, g->tmask, s.tmask)) return 1;
+    if (upload_m(c, g->umask, s.umask)) return 1;
     if (!c->full_cover) {
         // cells of eliminated land blocks: give the areas a harmless non-zero value
         // (they are divisors in to_ugrid / to_tgrid; the reference never visits them)
@@ -395,24 +450,21 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
         {c->p.wind_on_ugrid ? in->stray : in->strairyT, F_STRAIRYT, true}};
     for (auto &e : ip) {
         if (!e.h) { if (e.need) FAIL(c, "a required input pointer is NULL"); continue; }
-        if (upload_plane<double>(c, e.h, plane(s, e.f))) return 1;
+        if (upload_f(c, e.h, e.f)) return 1;
     }
     if (!st->uvel || !st->vvel || !st->iceumask) FAIL(c, "uvel/vvel/iceumask is NULL");
-    double *S0 = plane(s, F_STATE0);
-    if (upload_plane<double>(c, st->uvel, S0 + (size_t)S_U * s.fstride)) return 1;
-    if (upload_plane<double>(c, st->vvel, S0 + (size_t)S_V * s.fstride)) return 1;
+    if (upload_f(c, st->uvel, F_STATE0 + S_U)) return 1;
+    if (upload_f(c, st->vvel, F_STATE0 + S_V)) return 1;
     for (int q = 0; q < 4; q++) {
         if (!st->stressp[q] || !st->stressm[q] || !st->stress12[q]) FAIL(c, "a stress pointer is NULL");
-        if (upload_plane<double>(c, st->stressp[q], S0 + (size_t)(S_SP + q) * s.fstride)) return 1;
-        if (upload_plane<double>(c, st->stressm[q], S0 + (size_t)(S_SM + q) * s.fstride)) return 1;
-        if (upload_plane<double>(c, st->stress12[q], S0 + (size_t)(S_S12 + q) * s.fstride)) return 1;
+        if (upload_f(c, st->stressp[q], F_STATE0 + S_SP + q)) return 1;
+        if (upload_f(c, st->stressm[q], F_STATE0 + S_SM + q)) return 1;
+        if (upload_f(c, st->stress12[q], F_STATE0 + S_S12 + q)) return 1;
     }
-    if (upload_plane<int32_t>(c, st->iceumask, s.iceumask)) return 1;
+    if (upload_m(c, st->iceumask, s.iceumask)) return 1;
     // strintx/y, strocnx/y are inout in evp_prep2 (kept where iceumask stays true until the loop rewrites them)
-    if (st->strintx) upload_plane<double>(c, st->strintx, plane(s, F_STRINTX));
-    if (st->strinty) upload_plane<double>(c, st->strinty, plane(s, F_STRINTY));
-    if (st->strocnx) upload_plane<double>(c, st->strocnx, plane(s, F_STROCNX));
-    if (st->strocny) upload_plane<double>(c, st->strocny, plane(s, F_STROCNY));
+    if (upload_f(c, st->strintx, F_STRINTX) || upload_f(c, st->strinty, F_STRINTY)) return 1;
+    if (upload_f(c, st->strocnx, F_STROCNX) || upload_f(c, st->strocny, F_STROCNY)) return 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cur = 0;
     c->uploaded = true;
@@ -427,8 +479,8 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     const dim3 g2 = grid2d(s, B2D);
     if (c->cur) {   // a previous loop left the state in buffer 1 (odd number of subcycles): prep works on buffer 0
-        HIPCHK(c, hipMemcpyAsync(plane(s, F_STATE0), plane(s, F_STATE1), sizeof(double) * s.fstride * NSTATE,
-                                 hipMemcpyDeviceToDevice, c->stream));
+        for (int q = 0; q < NSTATE; q++)
+            hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)(F_STATE1 + q), (int)(F_STATE0 + q));
         c->cur = 0;
     }
     // evp_prep1 + zero diagnostics (ice_dyn_evp.F90:171-203)
@@ -481,8 +533,8 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     if (nsub < 0) FAIL(c, "nsub < 0");
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
-    const bool wrap = (c->nranks == 1 && c->ew == EVPK_BND_CYCLIC);
-    const bool need_halo = (c->nranks > 1) || (c->ns == EVPK_BND_TRIPOLE);
+    const bool wrap = (c->nranks == 1 && c->ew == EVPK_BND_CYCLIC && !c->force_exchange);
+    const bool need_halo = (c->nranks > 1) || (c->ns == EVPK_BND_TRIPOLE) || c->force_exchange;
     c->kernel_ms = 0.f;
     c->kernel_launches = 0;
     if (c->time_kernels) {
@@ -564,15 +616,16 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
     if (!c || !st) return 1;
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
-    const double *S = plane(s, c->cur ? F_STATE1 : F_STATE0);
-    if (download_plane<double>(c, st->uvel, S + (size_t)S_U * s.fstride, MODE_ALL)) return 1;
-    if (download_plane<double>(c, st->vvel, S + (size_t)S_V * s.fstride, MODE_ALL)) return 1;
+    const int SB = c->cur ? F_STATE1 : F_STATE0;
+    if (download_f(c, st->uvel, SB + S_U, MODE_ALL)) return 1;
+    if (download_f(c, st->vvel, SB + S_V, MODE_ALL)) return 1;
+    const int smode = (c->ns == EVPK_BND_TRIPOLE) ? MODE_NE_FOLD : MODE_NE;
     for (int q = 0; q < 4; q++) {
-        if (download_plane<double>(c, st->stressp[q], S + (size_t)(S_SP + q) * s.fstride, MODE_NE)) return 1;
-        if (download_plane<double>(c, st->stressm[q], S + (size_t)(S_SM + q) * s.fstride, MODE_NE)) return 1;
-        if (download_plane<double>(c, st->stress12[q], S + (size_t)(S_S12 + q) * s.fstride, MODE_NE)) return 1;
+        if (download_f(c, st->stressp[q], SB + S_SP + q, smode)) return 1;
+        if (download_f(c, st->stressm[q], SB + S_SM + q, smode)) return 1;
+        if (download_f(c, st->stress12[q], SB + S_S12 + q, smode)) return 1;
     }
-    if (download_plane<int32_t>(c, st->iceumask, s.iceumask, MODE_PHYS)) return 1;
+    if (download_m(c, st->iceumask, s.iceumask, MODE_PHYS)) return 1;
     struct { double *h; int f; } op[] = {
         {st->divu, F_DIVU}, {st->shear, F_SHEAR}, {st->rdg_conv, F_RDGCONV}, {st->rdg_shear, F_RDGSHEAR},
         {st->prs_sig, F_PRSSIG}, {st->strintx, F_STRINTX}, {st->strinty, F_STRINTY}, {st->strocnx, F_STROCNX},
@@ -580,11 +633,11 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
         {st->strairy, F_STRAIRY}, {st->strtltx, F_STRTLTX}, {st->strtlty, F_STRTLTY}, {st->fm, F_FM},
         {st->tmass, F_TMASS}, {st->aiu, F_AIU}, {st->umass, F_UMASS}, {st->uvel_init, F_UVEL_INIT}, {st->vvel_init, F_VVEL_INIT}};
     for (auto &e : op)
-        if (download_plane<double>(c, e.h, plane(s, e.f), MODE_PHYS)) return 1;
+        if (download_f(c, e.h, e.f, MODE_PHYS)) return 1;
     if (st->icetmask) {
         // icetmask travels as a 0/1 double plane on the device; convert through the staging buffer
         std::vector<double> tmp((size_t)c->nblocks * c->nyb * c->nxb, 0.0);
-        if (download_plane<double>(c, tmp.data(), plane(s, F_ICETM), MODE_ALL)) return 1;
+        if (download_f(c, tmp.data(), F_ICETM, MODE_ALL)) return 1;
         for (size_t k = 0; k < tmp.size(); k++) st->icetmask[k] = (int32_t)tmp[k];
     }
     return 0;

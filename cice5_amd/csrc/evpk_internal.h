@@ -1,10 +1,17 @@
 // evpk_internal.h -- device data layout shared by the kernels and the host API of libevpk.
 //
 // HBM layout: every rank owns ONE slab = the bounding rectangle of its ice_blocks blocks
-// (nxl x nyl physical cells) plus one ghost ring, stored as SoA planes of fp64:
-//     F[field][row j = 0..nyl+1][col = 0..pitch-1],   cell (i,j) at  j*pitch + c0 + i
-// i = 0 is the west ghost column, i = 1..nxl physical, i = nxl+1 the east ghost column;
-// c0 = 15 puts i = 1 on a 128-byte boundary, pitch is a multiple of 16 doubles.
+// (nxl x nyl physical cells) plus one ghost ring.  fp64 fields are stored as PAIR planes
+// of double2, interleaved by row:
+//     F[row j = 0..nyl+1][pair p = 0..NP-1][col = 0..pitch-1] of double2 {field 2p, field 2p+1}
+// so cell (i,j) of field f sits at double index  2*((j*NP + f/2)*pitch + C0 + i) + f%2.
+//  * the two members of a pair are always consumed together by the hot kernel (cxp/cyp,
+//    u/v, stressp_1/2, ...): one 16-byte load per lane (dwordx4, 1 KiB per wave) fetches both;
+//  * all planes of one row are contiguous (~2 MB), so a wave marching north touches one
+//    or two pages per row instead of ~50 planes 78 MB apart (TLB reach, DRAM locality);
+//  * i = 0 is the west ghost column, i = 1..nxl physical, i = nxl+1 the east ghost column;
+//    C0 = 7 puts i = 1 on a 128-byte boundary, pitch is a multiple of 8 cells.
+// Integer / byte masks are separate planes with the same (pitch, C0) but no interleave.
 // The ice_blocks decomposition is the unit of host<->device transfer (gather/scatter
 // kernels) and of sharding over GPUs; inside a GPU the blocks are fused into the slab so
 // that no intra-device halo copies are needed in the subcycle loop.
@@ -15,28 +22,28 @@
 namespace evpk {
 
 enum Field : int {
-    // grid metrics (time invariant)
-    F_DXT, F_DYT, F_DXHY, F_DYHX, F_CXP, F_CYP, F_CXM, F_CYM, F_TINYAREA, F_TAREAR,
-    F_TAREA, F_UAREA, F_UAREAR, F_FCOR,
-    // per-call inputs
-    F_AICE, F_VICE, F_VSNO, F_AICE_INIT, F_STRAIRXT, F_STRAIRYT, F_UOCN, F_VOCN,
-    F_SSTLTX, F_SSTLTY, F_CW, F_STRENGTH,
-    // work arrays of evp() (ice_dyn_evp.F90:120-128) and derived per-call planes
-    F_TMASS, F_UMASS, F_AIU, F_STRAIRX, F_STRAIRY, F_STRTLTX, F_STRTLTY, F_FM,
-    F_WATERX, F_WATERY, F_FORCEX, F_FORCEY, F_UMASSDTI, F_VRELC, F_UVEL_INIT, F_VVEL_INIT,
-    F_WORK1, F_WORK2, F_ICETM,
-    // prognostic state, double buffered (buffer b at F_STATE0 + b*NSTATE)
+    // ---- hot planes, in pairs (even, odd) ----
+    F_CXP, F_CYP, F_CXM, F_CYM, F_DXT, F_DYT, F_DXHY, F_DYHX, F_TINYAREA, F_STRENGTH,
+    // prognostic state, double buffered: u, v, stressp_1..4, stressm_1..4, stress12_1..4
     F_STATE0,
     F_STATE1 = F_STATE0 + 14,
-    // outputs
-    F_DIVU = F_STATE1 + 14, F_SHEAR, F_RDGCONV, F_RDGSHEAR, F_PRSSIG, F_STRINTX, F_STRINTY,
+    F_VRELC = F_STATE1 + 14, F_UAREAR, F_UOCN, F_VOCN, F_WATERX, F_WATERY, F_FORCEX, F_FORCEY,
+    F_UMASSDTI, F_FM, F_UVEL_INIT, F_VVEL_INIT,
+    // ---- cold planes ----
+    F_TAREAR, F_TAREA, F_UAREA, F_FCOR,
+    F_AICE, F_VICE, F_VSNO, F_AICE_INIT, F_STRAIRXT, F_STRAIRYT, F_SSTLTX, F_SSTLTY, F_CW,
+    F_TMASS, F_UMASS, F_AIU, F_STRAIRX, F_STRAIRY, F_STRTLTX, F_STRTLTY,
+    F_WORK1, F_WORK2, F_ICETM,
+    F_DIVU, F_SHEAR, F_RDGCONV, F_RDGSHEAR, F_PRSSIG, F_STRINTX, F_STRINTY,
     F_STROCNX, F_STROCNY, F_STROCNXT, F_STROCNYT,
     F_COUNT
 };
 constexpr int NSTATE = 14;           // u, v, stressp_1..4, stressm_1..4, stress12_1..4
 constexpr int S_U = 0, S_V = 1, S_SP = 2, S_SM = 6, S_S12 = 10;
+constexpr int NP = (F_COUNT + 1) / 2;
+static_assert(F_STATE0 % 2 == 0 && F_VRELC % 2 == 0, "pairs must start on even field ids");
 
-constexpr int C0 = 15;               // column offset of the west ghost
+constexpr int C0 = 7;                // column offset of the west ghost (cells)
 constexpr int STRIP_W = 63;          // U columns per wave strip (64 T columns)
 
 // cmask bits
@@ -44,18 +51,24 @@ constexpr unsigned char CM_T = 1;    // icetmask == 1
 constexpr unsigned char CM_U = 2;    // iceumask
 
 struct Slab {
-    double *F;            // F_COUNT planes
-    size_t fstride;       // doubles per plane
+    double *F;            // pair planes, see above
     int nxl, nyl;         // physical cells
-    int pitch;            // doubles per row
+    int pitch;            // cells per row of one pair plane
+    int rstride;          // cells per row of all pair planes = NP * pitch
     int i0, j0;           // global index of local cell (1,1)
     int nxg, nyg;
-    int32_t *tmask, *umask, *iceumask;   // int planes, same indexing
-    unsigned char *cmask, *tmphm;        // byte planes, same indexing
+    int32_t *tmask, *umask, *iceumask;   // int planes, index mcell()
+    unsigned char *cmask, *tmphm;        // byte planes, index mcell()
 };
 
-__host__ __device__ inline size_t cell(const Slab &s, int i, int j) { return (size_t)j * s.pitch + C0 + i; }
-__host__ __device__ inline double *plane(const Slab &s, int f) { return s.F + (size_t)f * s.fstride; }
+// cell index inside pair plane 0; field f adds (f/2)*pitch
+__host__ __device__ inline size_t cell(const Slab &s, int i, int j) { return (size_t)j * s.rstride + C0 + i; }
+__host__ __device__ inline size_t mcell(const Slab &s, int i, int j) { return (size_t)j * s.pitch + C0 + i; }
+__host__ __device__ inline double &FD(const Slab &s, int f, size_t k) {
+    return s.F[(((size_t)(f >> 1)) * s.pitch + k) * 2 + (f & 1)];
+}
+__host__ __device__ inline size_t slab_doubles(const Slab &s) { return ((size_t)s.rstride * (s.nyl + 2) + 128) * 2; }
+__host__ __device__ inline size_t mask_elems(const Slab &s) { return (size_t)s.pitch * (s.nyl + 2) + 128; }
 
 struct DevParams {
     double dt, revp, ecci, denom1, arlx1i, brlx, cosw, sinw, rhow, rhoi, rhos, gravit, a_min, m_min;

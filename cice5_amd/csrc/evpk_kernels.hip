@@ -9,6 +9,7 @@
 // reference never reaches HBM: it lives in registers and moves between lanes with DPP/
 // bpermute shuffles.  u, v and the twelve sigma planes are double buffered (read buffer
 // `cur`, write buffer `cur^1`) so that redundant T cells on strip edges see old values.
+// All hot fields are read and written as double2 pairs (16 B per lane, see evpk_internal.h).
 #include "evpk_internal.h"
 
 namespace evpk {
@@ -16,10 +17,23 @@ namespace evpk {
 // ------------------------------------------------------------------------------------
 // gather / scatter between the reference's block layout and the slab
 // ------------------------------------------------------------------------------------
-enum { MODE_PHYS = 0, MODE_ALL = 1, MODE_NE = 2 };
+enum { MODE_PHYS = 0, MODE_ALL = 1, MODE_NE = 2, MODE_NE_FOLD = 3 };
 
-template <typename T>
-__global__ void k_gather(Slab s, const BlockDesc *bd, int nblocks, int nxb, int nyb, const T *src, T *dst) {
+// Which block cells feed the slab: every physical cell, plus ghost cells that land on the slab's
+// ghost ring -- but only from the block whose own columns (rows) the ring cell continues, so a
+// neighbouring block's corner ghost (which the reference may leave stale) never competes.
+__device__ __forceinline__ bool gather_take(const Slab &s, const BlockDesc &d, int i, int j, int si, int sj) {
+    const bool owncol = (i >= d.ilo && i <= d.ihi), ownrow = (j >= d.jlo && j <= d.jhi);
+    if (owncol && ownrow) return true;
+    if (i > d.ihi + 1 || j > d.jhi + 1) return false;                       // padding
+    const bool colok = owncol || si == 0 || si == s.nxl + 1;
+    const bool rowok = ownrow || sj == 0 || sj == s.nyl + 1;
+    const bool ring = (si == 0 || si == s.nxl + 1 || sj == 0 || sj == s.nyl + 1);
+    return ring && colok && rowok;
+}
+
+// double fields: destination / source is field f of the pair-interleaved slab
+__global__ void k_gather_f(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, int f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;   // 1-based block column
     const int j = blockIdx.y + 1;
     const int b = blockIdx.z;
@@ -28,14 +42,11 @@ __global__ void k_gather(Slab s, const BlockDesc *bd, int nblocks, int nxb, int 
     const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
     const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
     if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
-    const bool phys = (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
-    const bool ring = (si == 0 || si == s.nxl + 1 || sj == 0 || sj == s.nyl + 1);
-    if (!phys && !(ring && i <= d.ihi + 1 && j <= d.jhi + 1)) return;
-    dst[cell(s, si, sj)] = src[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)];
+    if (!gather_take(s, d, i, j, si, sj)) return;
+    FD(s, f, cell(s, si, sj)) = src[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)];
 }
 
-template <typename T>
-__global__ void k_scatter(Slab s, const BlockDesc *bd, int nblocks, int nxb, int nyb, const T *src, T *dst, int mode) {
+__global__ void k_gather_m(Slab s, const BlockDesc *bd, int nxb, int nyb, const int32_t *src, int32_t *dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y + 1;
     const int b = blockIdx.z;
@@ -44,43 +55,73 @@ __global__ void k_scatter(Slab s, const BlockDesc *bd, int nblocks, int nxb, int
     const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
     const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
     if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
-    if (i > d.ihi + 1 || j > d.jhi + 1) return;   // padding
-    bool take;
-    if (mode == MODE_ALL) take = true;
-    else if (mode == MODE_NE) take = (i >= d.ilo && j >= d.jlo);
-    else take = (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
-    if (!take) return;
-    dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = src[cell(s, si, sj)];
+    if (!gather_take(s, d, i, j, si, sj)) return;
+    dst[mcell(s, si, sj)] = src[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)];
 }
 
-template __global__ void k_gather<double>(Slab, const BlockDesc *, int, int, int, const double *, double *);
-template __global__ void k_gather<int32_t>(Slab, const BlockDesc *, int, int, int, const int32_t *, int32_t *);
-template __global__ void k_scatter<double>(Slab, const BlockDesc *, int, int, int, const double *, double *, int);
-template __global__ void k_scatter<int32_t>(Slab, const BlockDesc *, int, int, int, const int32_t *, int32_t *, int);
+__device__ __forceinline__ bool scatter_take(const Slab &s, const BlockDesc &d, int i, int j, int mode, int &si, int &sj) {
+    si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
+    sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return false;
+    if (i > d.ihi + 1 || j > d.jhi + 1) return false;   // padding
+    if (mode == MODE_ALL) return true;
+    if (mode == MODE_NE_FOLD && sj == s.nyl + 1) return true;              // ice_HaloUpdate_stress writes the whole north ghost row
+    if (mode == MODE_NE || mode == MODE_NE_FOLD) return (i >= d.ilo && j >= d.jlo);
+    return (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
+}
+
+__global__ void k_scatter_f(Slab s, const BlockDesc *bd, int nxb, int nyb, int f, double *dst, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    int si, sj;
+    if (!scatter_take(s, bd[b], i, j, mode, si, sj)) return;
+    dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = FD(s, f, cell(s, si, sj));
+}
+
+__global__ void k_scatter_m(Slab s, const BlockDesc *bd, int nxb, int nyb, const int32_t *src, int32_t *dst, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    int si, sj;
+    if (!scatter_take(s, bd[b], i, j, mode, si, sj)) return;
+    dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = src[mcell(s, si, sj)];
+}
+
+__global__ void k_fill_plane(Slab s, int f, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > s.nxl + 1 || j > s.nyl + 1) return;
+    FD(s, f, cell(s, i, j)) = v;
+}
 
 // all cells of the slab incl. ring: thread (i,j), i = 0..nxl+1, j = 0..nyl+1
 #define SLAB_IJ_ALL                                            \
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       \
     const int j = blockIdx.y * blockDim.y + threadIdx.y;       \
     if (i > s.nxl + 1 || j > s.nyl + 1) return;                \
-    const size_t k = cell(s, i, j);
+    const size_t k = cell(s, i, j);                            \
+    const size_t km = mcell(s, i, j);                          \
+    (void)km;
 
 // ------------------------------------------------------------------------------------
 // evp_prep1 (ice_dyn_shared.F90:270-365) on the slab
 // ------------------------------------------------------------------------------------
 __global__ void k_prep1a(Slab s, DevParams p) {
     SLAB_IJ_ALL
-    const double vice = plane(s, F_VICE)[k], vsno = plane(s, F_VSNO)[k], aice = plane(s, F_AICE)[k];
-    const bool tm = s.tmask[k] != 0;
+    const double vice = FD(s, F_VICE, k), vsno = FD(s, F_VSNO, k), aice = FD(s, F_AICE, k);
+    const bool tm = s.tmask[km] != 0;
     double tmass = 0.0;
     if (tm) tmass = (p.rhoi * vice + p.rhos * vsno);                              // :322-326
-    plane(s, F_TMASS)[k] = tmass;
-    s.tmphm[k] = (tm && (aice > p.a_min) && (tmass > p.m_min)) ? 1 : 0;           // :331-332
-    plane(s, F_STRAIRX)[k] = plane(s, F_STRAIRXT)[k];                             // :339-340
-    plane(s, F_STRAIRY)[k] = plane(s, F_STRAIRYT)[k];
+    FD(s, F_TMASS, k) = tmass;
+    s.tmphm[km] = (tm && (aice > p.a_min) && (tmass > p.m_min)) ? 1 : 0;           // :331-332
+    FD(s, F_STRAIRX, k) = FD(s, F_STRAIRXT, k);                             // :339-340
+    FD(s, F_STRAIRY, k) = FD(s, F_STRAIRYT, k);
     // evp(): zero the diagnostics (ice_dyn_evp.F90:174-182)
-    plane(s, F_RDGCONV)[k] = 0.0; plane(s, F_RDGSHEAR)[k] = 0.0; plane(s, F_DIVU)[k] = 0.0;
-    plane(s, F_SHEAR)[k] = 0.0; plane(s, F_PRSSIG)[k] = 0.0;
+    FD(s, F_RDGCONV, k) = 0.0; FD(s, F_RDGSHEAR, k) = 0.0; FD(s, F_DIVU, k) = 0.0;
+    FD(s, F_SHEAR, k) = 0.0; FD(s, F_PRSSIG, k) = 0.0;
 }
 
 __global__ void k_prep1b(Slab s) {
@@ -88,13 +129,13 @@ __global__ void k_prep1b(Slab s) {
     double m = 0.0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {                           // :350-363
         const unsigned char *t = s.tmphm;
-        bool any = t[cell(s, i - 1, j + 1)] | t[cell(s, i, j + 1)] | t[cell(s, i + 1, j + 1)] |
-                   t[cell(s, i - 1, j)] | t[k] | t[cell(s, i + 1, j)] |
-                   t[cell(s, i - 1, j - 1)] | t[cell(s, i, j - 1)] | t[cell(s, i + 1, j - 1)];
+        bool any = t[mcell(s, i - 1, j + 1)] | t[mcell(s, i, j + 1)] | t[mcell(s, i + 1, j + 1)] |
+                   t[mcell(s, i - 1, j)] | t[km] | t[mcell(s, i + 1, j)] |
+                   t[mcell(s, i - 1, j - 1)] | t[mcell(s, i, j - 1)] | t[mcell(s, i + 1, j - 1)];
         if (any) m = 1.0;
-        if (!s.tmask[k]) m = 0.0;
+        if (!s.tmask[km]) m = 0.0;
     }
-    plane(s, F_ICETM)[k] = m;
+    FD(s, F_ICETM, k) = m;
 }
 
 // to_ugrid (ice_grid.F90:1834-1878): dst = 0 outside the physical cells
@@ -102,26 +143,32 @@ __global__ void k_to_ugrid(Slab s, int fsrc, int fdst) {
     SLAB_IJ_ALL
     double r = 0.0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
-        const double *w = plane(s, fsrc), *ta = plane(s, F_TAREA);
         const size_t ke = cell(s, i + 1, j), kn = cell(s, i, j + 1), kne = cell(s, i + 1, j + 1);
-        r = 0.25 * (((w[k] * ta[k] + w[ke] * ta[ke]) + w[kn] * ta[kn]) + w[kne] * ta[kne]) / plane(s, F_UAREA)[k];
+#define W_(q) FD(s, fsrc, q)
+#define TA_(q) FD(s, F_TAREA, q)
+        r = 0.25 * (((W_(k) * TA_(k) + W_(ke) * TA_(ke)) + W_(kn) * TA_(kn)) + W_(kne) * TA_(kne)) / FD(s, F_UAREA, k);
+#undef W_
+#undef TA_
     }
-    plane(s, fdst)[k] = r;
+    FD(s, fdst, k) = r;
 }
 
 // to_tgrid (ice_grid.F90:1924-1958): only physical cells of dst are written
 __global__ void k_to_tgrid(Slab s, int fsrc, int fdst) {
     SLAB_IJ_ALL
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
-        const double *w = plane(s, fsrc), *ua = plane(s, F_UAREA);
         const size_t kw = cell(s, i - 1, j), ks = cell(s, i, j - 1), ksw = cell(s, i - 1, j - 1);
-        plane(s, fdst)[k] = 0.25 * (((w[k] * ua[k] + w[kw] * ua[kw]) + w[ks] * ua[ks]) + w[ksw] * ua[ksw]) / plane(s, F_TAREA)[k];
+#define W_(q) FD(s, fsrc, q)
+#define UA_(q) FD(s, F_UAREA, q)
+        FD(s, fdst, k) = 0.25 * (((W_(k) * UA_(k) + W_(kw) * UA_(kw)) + W_(ks) * UA_(ks)) + W_(ksw) * UA_(ksw)) / FD(s, F_TAREA, k);
+#undef W_
+#undef UA_
     }
 }
 
 __global__ void k_copy_plane(Slab s, int fsrc, int fdst) {
     SLAB_IJ_ALL
-    plane(s, fdst)[k] = plane(s, fsrc)[k];
+    FD(s, fdst, k) = FD(s, fsrc, k);
 }
 
 // ------------------------------------------------------------------------------------
@@ -131,62 +178,61 @@ __global__ void k_copy_plane(Slab s, int fsrc, int fdst) {
 // ------------------------------------------------------------------------------------
 __global__ void k_prep2(Slab s, DevParams p) {
     SLAB_IJ_ALL
-    const bool icet = plane(s, F_ICETM)[k] == 1.0;
-    double *S0 = plane(s, F_STATE0), *S1 = plane(s, F_STATE1);
+    const bool icet = FD(s, F_ICETM, k) == 1.0;
     double wx = 0.0, wy = 0.0, fx = 0.0, fy = 0.0, umdti = 0.0, vrelc = 0.0;      // :484-490
     if (p.revp == 1.0 || !icet) {                                                  // :492-518
 #pragma unroll
-        for (int c = S_SP; c < NSTATE; c++) S0[(size_t)c * s.fstride + k] = 0.0;
+        for (int c = S_SP; c < NSTATE; c++) FD(s, F_STATE0 + c, k) = 0.0;
     }
     unsigned char cm = icet ? CM_T : 0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {                            // :545-577
-        const double aiu = plane(s, F_AIU)[k], umass = plane(s, F_UMASS)[k];
-        const double uocn = plane(s, F_UOCN)[k], vocn = plane(s, F_VOCN)[k];
-        const bool old = s.iceumask[k] != 0;
-        const bool ium = (s.umask[k] != 0) && (aiu > p.a_min) && (umass > p.m_min);
-        s.iceumask[k] = ium ? 1 : 0;
-        double u = S0[(size_t)S_U * s.fstride + k], v = S0[(size_t)S_V * s.fstride + k];
+        const double aiu = FD(s, F_AIU, k), umass = FD(s, F_UMASS, k);
+        const double uocn = FD(s, F_UOCN, k), vocn = FD(s, F_VOCN, k);
+        const bool old = s.iceumask[km] != 0;
+        const bool ium = (s.umask[km] != 0) && (aiu > p.a_min) && (umass > p.m_min);
+        s.iceumask[km] = ium ? 1 : 0;
+        double u = FD(s, F_STATE0 + S_U, k), v = FD(s, F_STATE0 + S_V, k);
         if (ium) {
             if (!old) { u = uocn; v = vocn; }
             cm |= CM_U;
         } else {
             u = 0.0; v = 0.0;
-            plane(s, F_STRINTX)[k] = 0.0; plane(s, F_STRINTY)[k] = 0.0;
-            plane(s, F_STROCNX)[k] = 0.0; plane(s, F_STROCNY)[k] = 0.0;
+            FD(s, F_STRINTX, k) = 0.0; FD(s, F_STRINTY, k) = 0.0;
+            FD(s, F_STROCNX, k) = 0.0; FD(s, F_STROCNY, k) = 0.0;
         }
-        S0[(size_t)S_U * s.fstride + k] = u;
-        S0[(size_t)S_V * s.fstride + k] = v;
-        plane(s, F_UVEL_INIT)[k] = u;
-        plane(s, F_VVEL_INIT)[k] = v;
+        FD(s, F_STATE0 + S_U, k) = u;
+        FD(s, F_STATE0 + S_V, k) = v;
+        FD(s, F_UVEL_INIT, k) = u;
+        FD(s, F_VVEL_INIT, k) = v;
         if (ium) {                                                                 // :583-612
             umdti = umass / p.dt;
-            const double fm = plane(s, F_FCOR)[k] * umass;
-            plane(s, F_FM)[k] = fm;
+            const double fm = FD(s, F_FCOR, k) * umass;
+            FD(s, F_FM, k) = fm;
             const double sg = copysign(1.0, fm);
             wx = uocn * p.cosw - vocn * p.sinw * sg;
             wy = vocn * p.cosw + uocn * p.sinw * sg;
             double tx, ty;
             if (p.tilt_from_slope) {
-                tx = -p.gravit * umass * plane(s, F_SSTLTX)[k];
-                ty = -p.gravit * umass * plane(s, F_SSTLTY)[k];
+                tx = -p.gravit * umass * FD(s, F_SSTLTX, k);
+                ty = -p.gravit * umass * FD(s, F_SSTLTY, k);
             } else {
                 tx = -fm * vocn;
                 ty = fm * uocn;
             }
-            plane(s, F_STRTLTX)[k] = tx;
-            plane(s, F_STRTLTY)[k] = ty;
-            fx = plane(s, F_STRAIRX)[k] + tx;
-            fy = plane(s, F_STRAIRY)[k] + ty;
+            FD(s, F_STRTLTX, k) = tx;
+            FD(s, F_STRTLTY, k) = ty;
+            fx = FD(s, F_STRAIRX, k) + tx;
+            fy = FD(s, F_STRAIRY, k) + ty;
             // stepu: vrel = aiu*rhow*Cw*sqrt(..) evaluates (aiu*rhow)*Cw first (ice_dyn_shared.F90:708)
-            vrelc = aiu * p.rhow * plane(s, F_CW)[k];
+            vrelc = aiu * p.rhow * FD(s, F_CW, k);
         }
     }
-    plane(s, F_WATERX)[k] = wx; plane(s, F_WATERY)[k] = wy;
-    plane(s, F_FORCEX)[k] = fx; plane(s, F_FORCEY)[k] = fy;
-    plane(s, F_UMASSDTI)[k] = umdti; plane(s, F_VRELC)[k] = vrelc;
-    s.cmask[k] = cm;
+    FD(s, F_WATERX, k) = wx; FD(s, F_WATERY, k) = wy;
+    FD(s, F_FORCEX, k) = fx; FD(s, F_FORCEY, k) = fy;
+    FD(s, F_UMASSDTI, k) = umdti; FD(s, F_VRELC, k) = vrelc;
+    s.cmask[km] = cm;
 #pragma unroll
-    for (int c = 0; c < NSTATE; c++) S1[(size_t)c * s.fstride + k] = S0[(size_t)c * s.fstride + k];
+    for (int c = 0; c < NSTATE; c++) FD(s, F_STATE1 + c, k) = FD(s, F_STATE0 + c, k);
 }
 
 // ------------------------------------------------------------------------------------
@@ -198,9 +244,8 @@ __global__ void k_halo_ns_fill(Slab s, int f, int nf, double fill, int north_too
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > s.nxl + 1) return;
     for (int q = 0; q < nf; q++) {
-        double *a = plane(s, f + q);
-        a[cell(s, i, 0)] = fill;
-        if (north_too) a[cell(s, i, s.nyl + 1)] = fill;
+        FD(s, f + q, cell(s, i, 0)) = fill;
+        if (north_too) FD(s, f + q, cell(s, i, s.nyl + 1)) = fill;
     }
 }
 
@@ -209,9 +254,8 @@ __global__ void k_fold_pack(Slab s, int f, int nf, double *fb, int gofs /* globa
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (i > s.nxl) return;
     for (int q = 0; q < nf; q++) {
-        const double *a = plane(s, f + q);
-        fb[((size_t)q * 2 + 0) * s.nxg + (gofs + i - 1)] = a[cell(s, i, s.nyl - 1)];
-        fb[((size_t)q * 2 + 1) * s.nxg + (gofs + i - 1)] = a[cell(s, i, s.nyl)];
+        fb[((size_t)q * 2 + 0) * s.nxg + (gofs + i - 1)] = FD(s, f + q, cell(s, i, s.nyl - 1));
+        fb[((size_t)q * 2 + 1) * s.nxg + (gofs + i - 1)] = FD(s, f + q, cell(s, i, s.nyl));
     }
 }
 
@@ -229,9 +273,8 @@ __global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int nec
     for (int q = 0; q < nf; q++) {
         const double *B1 = fb + ((size_t)q * 2 + 0) * nx - 1;  // 1-based
         const double *B2 = fb + ((size_t)q * 2 + 1) * nx - 1;
-        double *a = plane(s, fdst + q);
         if (!necorner) {
-            a[cell(s, i, s.nyl + 1)] = sgn * B2[nx - g + 1];
+            FD(s, fdst + q, cell(s, i, s.nyl + 1)) = sgn * B2[nx - g + 1];
         } else {
             int src = nx - g;
             if (src == 0) src = nx;
@@ -246,8 +289,8 @@ __global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int nec
             } else {
                 v = B2[src];
             }
-            a[cell(s, i, s.nyl)] = sgn * v;
-            a[cell(s, i, s.nyl + 1)] = sgn * B1[src];
+            FD(s, fdst + q, cell(s, i, s.nyl)) = sgn * v;
+            FD(s, fdst + q, cell(s, i, s.nyl + 1)) = sgn * B1[src];
         }
     }
 }
@@ -256,9 +299,8 @@ __global__ void k_halo_ew_local(Slab s, int f, int nf, int cyclic, double fill) 
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > s.nyl + 1) return;
     for (int q = 0; q < nf; q++) {
-        double *a = plane(s, f + q);
-        a[cell(s, 0, j)] = cyclic ? a[cell(s, s.nxl, j)] : fill;
-        a[cell(s, s.nxl + 1, j)] = cyclic ? a[cell(s, 1, j)] : fill;
+        FD(s, f + q, cell(s, 0, j)) = cyclic ? FD(s, f + q, cell(s, s.nxl, j)) : fill;
+        FD(s, f + q, cell(s, s.nxl + 1, j)) = cyclic ? FD(s, f + q, cell(s, 1, j)) : fill;
     }
 }
 
@@ -269,9 +311,8 @@ __global__ void k_ew_pack(Slab s, int f, int nf, double *sendW, double *sendE) {
     if (j > s.nyl + 1) return;
     const int rows = s.nyl + 2;
     for (int q = 0; q < nf; q++) {
-        const double *a = plane(s, f + q);
-        sendW[(size_t)q * rows + j] = a[cell(s, 1, j)];
-        sendE[(size_t)q * rows + j] = a[cell(s, s.nxl, j)];
+        sendW[(size_t)q * rows + j] = FD(s, f + q, cell(s, 1, j));
+        sendE[(size_t)q * rows + j] = FD(s, f + q, cell(s, s.nxl, j));
     }
 }
 
@@ -280,18 +321,17 @@ __global__ void k_ew_unpack(Slab s, int f, int nf, const double *recvW, const do
     if (j > s.nyl + 1) return;
     const int rows = s.nyl + 2;
     for (int q = 0; q < nf; q++) {
-        double *a = plane(s, f + q);
-        a[cell(s, 0, j)] = haveW ? recvW[(size_t)q * rows + j] : fill;
-        a[cell(s, s.nxl + 1, j)] = haveE ? recvE[(size_t)q * rows + j] : fill;
+        FD(s, f + q, cell(s, 0, j)) = haveW ? recvW[(size_t)q * rows + j] : fill;
+        FD(s, f + q, cell(s, s.nxl + 1, j)) = haveE ? recvE[(size_t)q * rows + j] : fill;
     }
 }
 
 // icetmask plane (double 0/1, after its halo update) -> cmask bit, then strip activity flags
 __global__ void k_icetm_to_cmask(Slab s) {
     SLAB_IJ_ALL
-    unsigned char cm = s.cmask[k] & CM_U;
-    if (plane(s, F_ICETM)[k] == 1.0) cm |= CM_T;
-    s.cmask[k] = cm;
+    unsigned char cm = s.cmask[km] & CM_U;
+    if (FD(s, F_ICETM, k) == 1.0) cm |= CM_T;
+    s.cmask[km] = cm;
 }
 
 // one wave per strip: is there any T work (cols cx*63+1..+64, rows jb..jb+R) or U work?
@@ -308,7 +348,7 @@ __global__ void k_strip_flags(Slab s, int ncx, int nry, int R, unsigned char *fl
         for (int jj = 0; jj <= R; jj++) {
             const int j = jb + jj;
             if (j > s.nyl + 1) break;
-            const unsigned char m = s.cmask[cell(s, i, j)];
+            const unsigned char m = s.cmask[mcell(s, i, j)];
             if (m & CM_T) {
                 any = 1;
                 if (lane < STRIP_W && jj < R && i <= s.nxl && j <= s.nyl) nt++;
@@ -344,6 +384,18 @@ struct SubArgs {
 
 __device__ __forceinline__ double shfl_dn1(double x) { return __shfl_down(x, 1); }
 
+// pair-plane access with a wave-uniform row base (SGPR) and a 32-bit lane offset (VGPR):
+// rb = byte address of (row j, pair plane 0, column 0); pp = pitch in bytes of one pair plane.
+__device__ __forceinline__ double2 ldp(const char *rb, size_t pp, int f_even, unsigned lo) {
+    return *reinterpret_cast<const double2 *>(rb + (size_t)(f_even >> 1) * pp + lo);
+}
+__device__ __forceinline__ void stp(char *rb, size_t pp, int f_even, unsigned lo, double x, double y) {
+    *reinterpret_cast<double2 *>(rb + (size_t)(f_even >> 1) * pp + lo) = make_double2(x, y);
+}
+__device__ __forceinline__ void st1(char *rb, size_t pp, int f, unsigned lo, double x) {
+    *reinterpret_cast<double *>(rb + (size_t)(f >> 1) * pp + lo + (f & 1) * 8) = x;
+}
+
 template <bool LAST, bool REVP>
 __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     const Slab &s = a.s;
@@ -353,9 +405,9 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     // gridDim.x is a multiple of 8 (host rounds up), so this is a bijection on [0, gridDim.x).
     const int chunk = gridDim.x >> 3;
     const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    const int sid = wg * 4 + (threadIdx.x >> 6);
+    const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (sid >= a.nstrips) return;
-    const int st = a.strips[sid];
+    const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R;
     const int i = cx * STRIP_W + 1 + lane;            // T column of this lane
@@ -364,11 +416,12 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     const bool ownT = colT && (lane < STRIP_W);       // ... and owns its sigma stores
     const bool colU = (i <= s.nxl) && (lane < STRIP_W);
 
-    const size_t fs = s.fstride;
-    const double *Sr = plane(s, a.cur ? F_STATE1 : F_STATE0);
-    double *Sw = plane(s, a.cur ? F_STATE0 : F_STATE1);
-    const double *ur = Sr + (size_t)S_U * fs, *vr = Sr + (size_t)S_V * fs;
-    const double *P = s.F;                            // plane(s,f)[k] = P[f*fs + k]
+    const size_t pp = (size_t)s.pitch * 16;           // bytes per row of one pair plane
+    const size_t rowb = (size_t)s.rstride * 16;       // bytes per row of all planes
+    const unsigned lo = (unsigned)(C0 + i) * 16u;     // lane byte offset inside a pair-plane row
+    const int SR = a.cur ? F_STATE1 : F_STATE0;       // read buffer
+    const int SW = a.cur ? F_STATE0 : F_STATE1;       // write buffer
+    char *const base = reinterpret_cast<char *>(s.F);
 
     const double ecci = a.ecci, arlx1i = a.arlx1i, denom1 = a.denom1;
     const double p111 = 1.0 / 9.0, p055 = p111 * 0.5, p027 = p055 * 0.5;
@@ -377,8 +430,9 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     // carried from the previous row (j-1)
     double u_im = 0.0, u_mm = 0.0, v_im = 0.0, v_mm = 0.0;
     if (colT) {
-        const size_t k0 = cell(s, i, jb - 1);
-        u_im = ur[k0]; u_mm = ur[k0 - 1]; v_im = vr[k0]; v_mm = vr[k0 - 1];
+        const char *rb0 = base + (size_t)(jb - 1) * rowb;
+        const double2 a0 = ldp(rb0, pp, SR + S_U, lo), a1 = ldp(rb0, pp, SR + S_U, lo - 16u);
+        u_im = a0.x; v_im = a0.y; u_mm = a1.x; v_mm = a1.y;
     }
     double s1c = 0.0, s5c = 0.0, s2r = 0.0, s7r = 0.0;
     unsigned char mprev = 0;
@@ -386,29 +440,31 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     for (int jj = 0; jj <= R; jj++) {
         const int j = jb + jj;
         if (j > s.nyl + 1) break;
-        const size_t k = cell(s, i, j);
+        char *const rb = base + (size_t)j * rowb;     // wave-uniform
         unsigned char m = 0;
         double u_ij = 0.0, u_mj = 0.0, v_ij = 0.0, v_mj = 0.0;
         if (colT) {
-            m = s.cmask[k];
-            u_ij = ur[k]; u_mj = ur[k - 1]; v_ij = vr[k]; v_mj = vr[k - 1];
+            m = s.cmask[(size_t)j * s.pitch + C0 + i];
+            const double2 a0 = ldp(rb, pp, SR + S_U, lo), a1 = ldp(rb, pp, SR + S_U, lo - 16u);
+            u_ij = a0.x; v_ij = a0.y; u_mj = a1.x; v_mj = a1.y;
         }
         const bool tact = (m & CM_T) != 0;
         double str1 = 0.0, str2 = 0.0, str3 = 0.0, str4 = 0.0, str5 = 0.0, str6 = 0.0, str7 = 0.0, str8 = 0.0;
 
         if (__any(tact)) {
             if (tact) {
-                const double cyp = P[(size_t)F_CYP * fs + k], cxp = P[(size_t)F_CXP * fs + k];
-                const double cym = P[(size_t)F_CYM * fs + k], cxm = P[(size_t)F_CXM * fs + k];
-                const double dxt = P[(size_t)F_DXT * fs + k], dyt = P[(size_t)F_DYT * fs + k];
-                const double dxhy = P[(size_t)F_DXHY * fs + k], dyhx = P[(size_t)F_DYHX * fs + k];
-                const double tiny = P[(size_t)F_TINYAREA * fs + k], strength = P[(size_t)F_STRENGTH * fs + k];
-                double sp1 = Sr[(size_t)(S_SP + 0) * fs + k], sp2 = Sr[(size_t)(S_SP + 1) * fs + k];
-                double sp3 = Sr[(size_t)(S_SP + 2) * fs + k], sp4 = Sr[(size_t)(S_SP + 3) * fs + k];
-                double sm1 = Sr[(size_t)(S_SM + 0) * fs + k], sm2 = Sr[(size_t)(S_SM + 1) * fs + k];
-                double sm3 = Sr[(size_t)(S_SM + 2) * fs + k], sm4 = Sr[(size_t)(S_SM + 3) * fs + k];
-                double s121 = Sr[(size_t)(S_S12 + 0) * fs + k], s122 = Sr[(size_t)(S_S12 + 1) * fs + k];
-                double s123 = Sr[(size_t)(S_S12 + 2) * fs + k], s124 = Sr[(size_t)(S_S12 + 3) * fs + k];
+                const double2 cp = ldp(rb, pp, F_CXP, lo), cm = ldp(rb, pp, F_CXM, lo);
+                const double2 dd = ldp(rb, pp, F_DXT, lo), dh = ldp(rb, pp, F_DXHY, lo);
+                const double2 ts = ldp(rb, pp, F_TINYAREA, lo);
+                const double2 q0 = ldp(rb, pp, SR + S_SP, lo), q1 = ldp(rb, pp, SR + S_SP + 2, lo);
+                const double2 q2 = ldp(rb, pp, SR + S_SM, lo), q3 = ldp(rb, pp, SR + S_SM + 2, lo);
+                const double2 q4 = ldp(rb, pp, SR + S_S12, lo), q5 = ldp(rb, pp, SR + S_S12 + 2, lo);
+                const double cxp = cp.x, cyp = cp.y, cxm = cm.x, cym = cm.y;
+                const double dxt = dd.x, dyt = dd.y, dxhy = dh.x, dyhx = dh.y;
+                const double tiny = ts.x, strength = ts.y;
+                double sp1 = q0.x, sp2 = q0.y, sp3 = q1.x, sp4 = q1.y;
+                double sm1 = q2.x, sm2 = q2.y, sm3 = q3.x, sm4 = q3.y;
+                double s121 = q4.x, s122 = q4.y, s123 = q5.x, s124 = q5.y;
 
                 // strain rates * area (ice_dyn_evp.F90:627-654)
                 const double divune = cyp * u_ij - dyt * u_mj + cxp * v_ij - dxt * v_im;
@@ -435,15 +491,15 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
                 const bool store = ownT && (jj < R);
                 if (LAST) {                                                         // :665-677
                     if (store) {
-                        const double tarear = P[(size_t)F_TAREAR * fs + k];
+                        const double tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
                         const double divu = 0.25 * (divune + divunw + divuse + divusw) * tarear;
                         const double tmp = 0.25 * (Deltane + Deltanw + Deltase + Deltasw) * tarear;
-                        s.F[(size_t)F_DIVU * fs + k] = divu;
-                        s.F[(size_t)F_RDGCONV * fs + k] = -fmin(divu, 0.0);
-                        s.F[(size_t)F_RDGSHEAR * fs + k] = 0.5 * (tmp - fabs(divu));
-                        const double ts = tensionne + tensionnw + tensionse + tensionsw;
+                        st1(rb, pp, F_DIVU, lo, divu);
+                        st1(rb, pp, F_RDGCONV, lo, -fmin(divu, 0.0));
+                        st1(rb, pp, F_RDGSHEAR, lo, 0.5 * (tmp - fabs(divu)));
+                        const double tt = tensionne + tensionnw + tensionse + tensionsw;
                         const double ss = shearne + shearnw + shearse + shearsw;
-                        s.F[(size_t)F_SHEAR * fs + k] = 0.25 * tarear * sqrt(ts * ts + ss * ss);
+                        st1(rb, pp, F_SHEAR, lo, 0.25 * tarear * sqrt(tt * tt + ss * ss));
                     }
                 }
 
@@ -452,7 +508,7 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
                 double c0nw = strength / fmax(Deltanw, tiny);
                 double c0sw = strength / fmax(Deltasw, tiny);
                 double c0se = strength / fmax(Deltase, tiny);
-                if (LAST) { if (store) s.F[(size_t)F_PRSSIG * fs + k] = c0ne * Deltane; }
+                if (LAST) { if (store) st1(rb, pp, F_PRSSIG, lo, c0ne * Deltane); }
                 const double c1ne = c0ne * arlx1i, c1nw = c0nw * arlx1i, c1sw = c0sw * arlx1i, c1se = c0se * arlx1i;
                 c0ne = c1ne * ecci; c0nw = c1nw * ecci; c0sw = c1sw * ecci; c0se = c1se * ecci;
 
@@ -471,12 +527,9 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
                 s124 = (s124 + c0se * shearse * 0.5) * denom1;
 
                 if (store) {
-                    Sw[(size_t)(S_SP + 0) * fs + k] = sp1; Sw[(size_t)(S_SP + 1) * fs + k] = sp2;
-                    Sw[(size_t)(S_SP + 2) * fs + k] = sp3; Sw[(size_t)(S_SP + 3) * fs + k] = sp4;
-                    Sw[(size_t)(S_SM + 0) * fs + k] = sm1; Sw[(size_t)(S_SM + 1) * fs + k] = sm2;
-                    Sw[(size_t)(S_SM + 2) * fs + k] = sm3; Sw[(size_t)(S_SM + 3) * fs + k] = sm4;
-                    Sw[(size_t)(S_S12 + 0) * fs + k] = s121; Sw[(size_t)(S_S12 + 1) * fs + k] = s122;
-                    Sw[(size_t)(S_S12 + 2) * fs + k] = s123; Sw[(size_t)(S_S12 + 3) * fs + k] = s124;
+                    stp(rb, pp, SW + S_SP, lo, sp1, sp2);    stp(rb, pp, SW + S_SP + 2, lo, sp3, sp4);
+                    stp(rb, pp, SW + S_SM, lo, sm1, sm2);    stp(rb, pp, SW + S_SM + 2, lo, sm3, sm4);
+                    stp(rb, pp, SW + S_S12, lo, s121, s122); stp(rb, pp, SW + S_S12 + 2, lo, s123, s124);
                 }
 
                 // combinations for the momentum equation (:752-795)
@@ -534,14 +587,14 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
             const bool uact = colU && ((mprev & CM_U) != 0);
             if (__any(uact)) {
                 if (uact) {
-                    const size_t ku = k - s.pitch;
+                    char *const ru = rb - rowb;
                     const double uold = u_im, vold = v_im;
-                    const double vrelc = P[(size_t)F_VRELC * fs + ku];
-                    const double uocn = P[(size_t)F_UOCN * fs + ku], vocn = P[(size_t)F_VOCN * fs + ku];
-                    const double waterx = P[(size_t)F_WATERX * fs + ku], watery = P[(size_t)F_WATERY * fs + ku];
-                    const double forcex = P[(size_t)F_FORCEX * fs + ku], forcey = P[(size_t)F_FORCEY * fs + ku];
-                    const double umassdti = P[(size_t)F_UMASSDTI * fs + ku], fm = P[(size_t)F_FM * fs + ku];
-                    const double uarear = P[(size_t)F_UAREAR * fs + ku];
+                    const double2 va = ldp(ru, pp, F_VRELC, lo), oc = ldp(ru, pp, F_UOCN, lo);
+                    const double2 wa = ldp(ru, pp, F_WATERX, lo), fo = ldp(ru, pp, F_FORCEX, lo);
+                    const double2 mf = ldp(ru, pp, F_UMASSDTI, lo);
+                    const double vrelc = va.x, uarear = va.y, uocn = oc.x, vocn = oc.y;
+                    const double waterx = wa.x, watery = wa.y, forcex = fo.x, forcey = fo.y;
+                    const double umassdti = mf.x, fm = mf.y;
                     const double du = uocn - uold, dv = vocn - vold;
                     const double vrel = vrelc * sqrt(du * du + dv * dv);            // :708-709
                     const double taux = vrel * waterx, tauy = vrel * watery;        // :711-712
@@ -551,20 +604,19 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
                     const double strintx = uarear * (((s1c + s2r) + str3) + s4n);   // :725-728
                     const double strinty = uarear * (((s5c + str6) + s7r) + s8n);
                     double ui = 0.0, vi = 0.0;
-                    if (REVP) { ui = P[(size_t)F_UVEL_INIT * fs + ku]; vi = P[(size_t)F_VVEL_INIT * fs + ku]; }
+                    if (REVP) { const double2 iv = ldp(ru, pp, F_UVEL_INIT, lo); ui = iv.x; vi = iv.y; }
                     const double cc1 = strintx + forcex + taux + umassdti * (a.brlx * uold + a.revp * ui);   // :731-734
                     const double cc2 = strinty + forcey + tauy + umassdti * (a.brlx * vold + a.revp * vi);
                     const double un = (cca * cc1 + ccb * cc2) / ab2;                // :736-737
                     const double vn = (cca * cc2 - ccb * cc1) / ab2;
-                    Sw[(size_t)S_U * fs + ku] = un;
-                    Sw[(size_t)S_V * fs + ku] = vn;
+                    stp(ru, pp, SW + S_U, lo, un, vn);
                     if (a.wrap) {   // single-rank cyclic E-W: the owner also writes the ghost image
-                        if (i == 1) { Sw[(size_t)S_U * fs + ku + s.nxl] = un; Sw[(size_t)S_V * fs + ku + s.nxl] = vn; }
-                        if (i == s.nxl) { Sw[(size_t)S_U * fs + ku - s.nxl] = un; Sw[(size_t)S_V * fs + ku - s.nxl] = vn; }
+                        if (i == 1) stp(ru, pp, SW + S_U, lo + (unsigned)s.nxl * 16u, un, vn);
+                        if (i == s.nxl) stp(ru, pp, SW + S_U, lo - (unsigned)s.nxl * 16u, un, vn);
                     }
                     if (LAST) {
-                        s.F[(size_t)F_STRINTX * fs + ku] = strintx;
-                        s.F[(size_t)F_STRINTY * fs + ku] = strinty;
+                        st1(ru, pp, F_STRINTX, lo, strintx);
+                        st1(ru, pp, F_STRINTY, lo, strinty);
                     }
                 }
             }
@@ -587,23 +639,23 @@ template __global__ void k_subcycle<true, true>(SubArgs);
 __global__ void k_finish(Slab s, DevParams p, int cur) {
     SLAB_IJ_ALL
     double xT = 0.0, yT = 0.0;                                                     // :806-811
-    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl && s.iceumask[k]) {
-        const double *S = plane(s, cur ? F_STATE1 : F_STATE0);
-        const double u = S[(size_t)S_U * s.fstride + k], v = S[(size_t)S_V * s.fstride + k];
-        const double du = plane(s, F_UOCN)[k] - u, dv = plane(s, F_VOCN)[k] - v;
-        const double aiu = plane(s, F_AIU)[k], fm = plane(s, F_FM)[k];
-        double vrel = p.rhow * plane(s, F_CW)[k] * sqrt(du * du + dv * dv);        // :818-819
+    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl && s.iceumask[km]) {
+        const int SB = cur ? F_STATE1 : F_STATE0;
+        const double u = FD(s, SB + S_U, k), v = FD(s, SB + S_V, k);
+        const double du = FD(s, F_UOCN, k) - u, dv = FD(s, F_VOCN, k) - v;
+        const double aiu = FD(s, F_AIU, k), fm = FD(s, F_FM, k);
+        double vrel = p.rhow * FD(s, F_CW, k) * sqrt(du * du + dv * dv);        // :818-819
         vrel = vrel * aiu;                                                         // :827
         const double sg = copysign(1.0, fm);
         const double sx = vrel * (du * p.cosw - dv * p.sinw * sg);                 // :828-831
         const double sy = vrel * (dv * p.cosw + du * p.sinw * sg);
-        plane(s, F_STROCNX)[k] = sx;
-        plane(s, F_STROCNY)[k] = sy;
+        FD(s, F_STROCNX, k) = sx;
+        FD(s, F_STROCNY, k) = sy;
         xT = sx / aiu;                                                             // :840-841
         yT = sy / aiu;
     }
-    plane(s, F_STROCNXT)[k] = xT;
-    plane(s, F_STROCNYT)[k] = yT;
+    FD(s, F_STROCNXT, k) = xT;
+    FD(s, F_STROCNYT, k) = yT;
 }
 
 }  // namespace evpk

@@ -80,11 +80,28 @@ class SynthCase:
         return dy0 * (1.0 + 0.1 * np.sin(2.0 * np.pi * Iw / self.nx) * np.cos(np.deg2rad(self._latT(J))))
 
     # ---- masks ---------------------------------------------------------------------
+    def _fold(self, I, J):
+        """tripole: a cell-centre index beyond the north edge is the 180-degree image of a physical
+        cell: (i, ny+k) -> (nx-i+1, ny-k+1)  (centre fold of serial/ice_boundary.F90:804-807)."""
+        if self.ns_boundary != C.BND_TRIPOLE:
+            return I, J
+        I, J = np.broadcast_arrays(I, J)
+        up = J > self.ny
+        Iw = self._wrap(I)
+        return np.where(up, self.nx - Iw + 1, I), np.where(up, 2 * self.ny + 1 - J, J)
+
     def hm(self, I, J):
         I, J = np.broadcast_arrays(I, J)
+        I, J = self._fold(I, J)
         Iw = self._wrap(I)
         ocean = self._inside(I, J)
-        ocean = ocean & (J > 2) & (J < self.ny - 1)
+        if self.ns_boundary == C.BND_TRIPOLE:
+            # tripole: the north edge is the fold, ocean reaches it; only the two grid poles
+            # (i = nx/2 and i = nx on the top row) sit on land, as on real tripole grids
+            pole = (J >= self.ny - 1) & ((np.abs(Iw - self.nx // 2) <= 1) | (Iw >= self.nx - 1) | (Iw <= 1))
+            ocean = ocean & (J > 2) & ~pole
+        else:
+            ocean = ocean & (J > 2) & (J < self.ny - 1)
         if self.land == "continents":
             x = 2.0 * np.pi * Iw / self.nx
             y = np.pi * J / self.ny
@@ -135,6 +152,11 @@ class SynthCase:
         return self._eval(name, I, J, self, self.HTN, self.HTE, lambda: self._icy(I, J), lambda: self.hm(I, J), lambda: self.uvm(I, J))
 
     def _eval(self, name, I, J, self_, HTN, HTE, icy_fn, hm_fn, uvm_fn):
+        if name in ("aice", "aice_init", "vice", "vsno", "strength") and self.ns_boundary == C.BND_TRIPOLE:
+            If, Jf = self._fold(I, J)          # T-cell scalars: ghost row north of the fold = image cells
+            I, J = If, Jf
+            icy_fn = lambda: self._icy(I, J)
+            self_ = self
         Iw = self._wrap(I)
         s = self.seed
         if name == "dxt":

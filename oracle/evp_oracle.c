@@ -521,15 +521,17 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
     free(G); free(top); free(north);
 }
 
-/* Optional hook for multi-process CPU tests: after the local update (sources on other
-   ranks read as `fill`), the hook patches the ghost cells whose source lives elsewhere. */
+/* Optional hook for multi-process CPU tests.  Phase 0 runs before the local update (the hook
+   can save the rows a tripole fold needs), phase 1 after it (sources on other ranks read as
+   `fill` locally; the hook patches the cells whose source lives elsewhere). */
 static orc_halo_cb g_halo_cb = NULL;
 static void *g_halo_cb_user = NULL;
 void orc_set_halo_callback(orc_halo_cb cb, void *user) { g_halo_cb = cb; g_halo_cb_user = user; }
 
 void orc_halo_r8(const orc_geom *g, double *a, int loc, int kind, double fill) {
+    if (g_halo_cb) g_halo_cb(a, loc, kind, fill, 0, g_halo_cb_user);   /* phase 0: before the local update */
     halo_generic(g, a, a, loc, kind, fill, 0);
-    if (g_halo_cb) g_halo_cb(a, loc, kind, fill, g_halo_cb_user);
+    if (g_halo_cb) g_halo_cb(a, loc, kind, fill, 1, g_halo_cb_user);   /* phase 1: patch remote sources */
 }
 
 void orc_halo_stress(const orc_geom *g, double *a1, const double *a2) {

@@ -135,7 +135,7 @@ void orc_strength_hibler(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
                          const double *aice, const double *vice, double *strength);
 
 /* halo updates, MPI-backend semantics (ghost cells pre-filled with `fill`) */
-typedef void (*orc_halo_cb)(double *a, int loc, int kind, double fill, void *user);
+typedef void (*orc_halo_cb)(double *a, int loc, int kind, double fill, int phase, void *user);
 void orc_set_halo_callback(orc_halo_cb cb, void *user);   /* multi-process CPU tests only */
 void orc_halo_r8(const orc_geom *g, double *a, int loc, int kind, double fill);
 void orc_halo_i4(const orc_geom *g, int32_t *a, int32_t fill);

@@ -57,7 +57,7 @@ class OrcFields(ct.Structure):
                 [(n, c_f64p) for n in _F64_OUT] + [("icetmask", c_i32p)])
 
 
-HALO_CB = ct.CFUNCTYPE(None, c_f64p, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p)
+HALO_CB = ct.CFUNCTYPE(None, c_f64p, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_void_p)
 
 
 def build(force: bool = False) -> str:
@@ -162,12 +162,12 @@ def halo_r8(d, a: np.ndarray, loc: int, kind: int, fill: float = 0.0):
 
 
 def set_halo_callback(fn):
-    """fn(array_view, loc, kind, fill) patches ghost cells in place; pass None to clear.
+    """fn(array_ptr, loc, kind, fill, phase) -- phase 0 before, 1 after the local update; None clears.
     Returns the ctypes callback object, which the caller must keep alive."""
     if fn is None:
         lib().orc_set_halo_callback(ct.cast(None, HALO_CB), None)
         return None
-    cb = HALO_CB(lambda a, loc, kind, fill, user: fn(a, loc, kind, fill))
+    cb = HALO_CB(lambda a, loc, kind, fill, phase, user: fn(a, loc, kind, fill, phase))
     lib().orc_set_halo_callback(cb, None)
     return cb
 

@@ -1,0 +1,196 @@
+"""world_size-2 CPU test of the sharded path (gloo): x-slab decomposition, ring neighbours from
+evpk_slab_layout, and the halo protocol the multi-GPU library uses --
+
+  * E-W: each rank sends its two physical edge columns over ALL rows (ghost rows included, which
+    carries the corners) and receives its two ghost columns; with two ranks on a cyclic ring one
+    message [W edge | E edge] goes each way (cice5_amd/csrc/evpk_api.hip, halo()).
+  * tripole: the two top rows are all-gathered and every rank applies the fold locally
+    (k_fold_pack / k_fold_apply).
+
+The arithmetic on each rank is the CPU oracle with its local halo update patched through a hook;
+the result must equal the single-process oracle bit for bit (as the reference is decomposition
+invariant).
+"""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _edge_column(d, a, which):
+    """Full-height (ny+2) column of the slab: 'W' = first physical column, 'E' = last."""
+    i0, i1, _, _ = d.slab()
+    col = np.zeros(d.ny_global + 2)
+    for n, b in enumerate(d.local_blocks):
+        if which == "W" and b.iglob_lo != i0:
+            continue
+        if which == "E" and b.iglob_lo + (b.ihi - b.ilo) != i1:
+            continue
+        ic = (b.ilo if which == "W" else b.ihi) - 1
+        for j in range(b.jlo - 1, b.jhi + 2):          # 1-based j = jlo-1 .. jhi+1 -> 0-based j-1
+            gj = b.jglob_lo + (j - b.jlo)
+            if 0 <= gj <= d.ny_global + 1:
+                col[gj] = a[n, j - 1, ic]
+    return col
+
+
+def _set_ghost_column(d, a, which, col):
+    i0, i1, _, _ = d.slab()
+    for n, b in enumerate(d.local_blocks):
+        if which == "W" and b.iglob_lo != i0:
+            continue
+        if which == "E" and b.iglob_lo + (b.ihi - b.ilo) != i1:
+            continue
+        ic = (b.ilo - 1 if which == "W" else b.ihi + 1) - 1
+        for j in range(b.jlo - 1, b.jhi + 2):
+            gj = b.jglob_lo + (j - b.jlo)
+            a[n, j - 1, ic] = col[gj]
+
+
+def _fold_rows(nx, B1, B2, necorner, sgn):
+    """numpy mirror of k_fold_apply: returns (top_row or None, north_ghost_row), index 1..nx."""
+    g = np.arange(1, nx + 1)          # B1, B2 are 1-based (index 0 unused); results are 0-based over g = 1..nx
+    if not necorner:
+        return None, sgn * B2[nx - g + 1]
+    src = nx - g
+    src[src == 0] = nx
+    sym = B2.copy()
+    h = nx // 2
+    for i in range(1, h):
+        x = 0.5 * (B2[i] + sgn * B2[nx - i])
+        sym[i] = x
+        sym[nx - i] = sgn * x
+    return sgn * sym[src], sgn * B1[src]
+
+
+def _worker(rank, world, port, ns, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          OMP_NUM_THREADS="2")
+        import torch
+        import torch.distributed as dist
+        from cice5_amd import blocks, constants as C, evpk, synth
+        from oracle import orc
+        from tests import util
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        nx, ny, bsx, bsy, ndte = 48, 40, 12, 10, 30
+        case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[ns], land="continents")
+        d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=ns)
+        f = synth.make_block_fields(case, d)
+        i0, i1, j0, j1 = d.slab()
+        assert (j0, j1) == (1, ny) and i1 - i0 + 1 == nx // world
+        lay = evpk.slab_layout(nx, world, rank, d.ew_boundary, i0, i1)
+        assert lay["west"] == lay["east"] == 1 - rank
+        shape = (d.nblocks, d.ny_block, d.nx_block)
+        tripole = ns == "tripole"
+
+        saved = {}
+
+        def patch(ptr, loc, kind, fill, phase):
+            a = np.ctypeslib.as_array(ptr, shape=shape)
+            sgn = -1.0 if kind == C.KIND_VECTOR else 1.0
+            if phase == 0:
+                if tripole:     # the two top physical rows as they are BEFORE any update
+                    loc_rows = np.zeros((2, i1 - i0 + 1))
+                    for n, b in enumerate(d.local_blocks):
+                        if b.tripole:
+                            c0 = b.iglob_lo - i0
+                            w = b.ihi - b.ilo + 1
+                            loc_rows[0, c0:c0 + w] = a[n, b.jhi - 2, b.ilo - 1:b.ihi]
+                            loc_rows[1, c0:c0 + w] = a[n, b.jhi - 1, b.ilo - 1:b.ihi]
+                    saved["rows"] = loc_rows
+                return
+            if tripole:
+                # all-gather the two top rows (global rows ny-1, ny) of every rank's columns
+                t = torch.from_numpy(saved.pop("rows"))
+                parts = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                allrows = np.concatenate([p.numpy() for p in parts], axis=1)
+                B1 = np.concatenate([[0.0], allrows[0]])
+                B2 = np.concatenate([[0.0], allrows[1]])
+                top, north = _fold_rows(nx, B1, B2, loc == C.LOC_NECORNER, sgn)
+                for n, b in enumerate(d.local_blocks):
+                    if b.tripole:
+                        for i in range(1, d.nx_block + 1):
+                            g = (b.iglob_lo + (i - b.ilo) - 1) % nx + 1
+                            a[n, b.jhi, i - 1] = north[g - 1]
+                            if top is not None:
+                                a[n, b.jhi - 1, i - 1] = top[g - 1]
+            # E-W: one message each way with both edges (two ranks, cyclic ring)
+            send = torch.from_numpy(np.concatenate([_edge_column(d, a, "W"), _edge_column(d, a, "E")]))
+            recv = torch.zeros_like(send)
+            peer = lay["west"]
+            if rank == 0:
+                dist.send(send, peer); dist.recv(recv, peer)
+            else:
+                dist.recv(recv, peer); dist.send(send, peer)
+            r = recv.numpy()
+            half = ny + 2
+            _set_ghost_column(d, a, "E", r[:half])      # the peer's W edge is my east ghost
+            _set_ghost_column(d, a, "W", r[half:])      # the peer's E edge is my west ghost
+
+        keep = orc.set_halo_callback(patch)
+        xmin = synth.global_min_dx(case)
+        p = orc.make_params(3600.0, ndte, xmin)
+        nt, nu, _ = orc.evp(d, p, f)
+        orc.set_halo_callback(None)
+        del keep
+        # reference: the whole domain in this process
+        d1 = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns)
+        f1 = synth.make_block_fields(case, d1)
+        nt1, nu1 = orc.evp(d1, p, f1)[:2]
+        tot = torch.tensor([nt, nu], dtype=torch.int64)
+        dist.all_reduce(tot)
+        assert (int(tot[0]), int(tot[1])) == (nt1, nu1)
+        bad = []
+        for name in ["uvel", "vvel", "divu", "strocnxT", "strintx", "prs_sig"] + util.SIGMA:
+            G = blocks.gather_global(d1, f1[name])[:, i0 - 1:i1]
+            L = blocks.gather_global(d, f[name])[:, i0 - 1:i1]
+            if not np.array_equal(G, L):
+                bad.append(name)
+        # ghost columns of the velocity too
+        for n, b in enumerate(d.local_blocks):
+            n1 = next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id)
+            if not np.array_equal(f["uvel"][n], f1["uvel"][n1]):
+                bad.append(f"uvel ghosts of block {b.block_id}")
+        assert np.abs(f["uvel"]).max() > 1e-3
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bad))
+    except Exception:
+        q.put((rank, ["EXC " + traceback.format_exc()]))
+
+
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_two_rank_slab_exchange_gloo(ns):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ns, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in procs:
+        res.append(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()
+    for rank, bad in res:
+        assert not bad, f"rank {rank}: {bad}"

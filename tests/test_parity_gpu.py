@@ -139,6 +139,16 @@ def test_strip_rows_do_not_matter():
         assert not util.compare(d, g, out[0])
 
 
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_forced_exchange_path(ns, monkeypatch):
+    """EVPK_FORCE_EXCHANGE=1 makes a single rank take the multi-rank code path (pack edge columns ->
+    exchange -> unpack, fold through the all-gather re-pack); only the RCCL calls themselves are
+    replaced by device copies.  Must still match the oracle bit for bit."""
+    monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+    _both(48, 40, 12, 10, ns=ns, land="continents", ndte=40, ncalls=2)
+    _both(100, 116, 25, 29, ns=ns, land="continents", ndte=30)
+
+
 def test_staged_api_equals_run():
     """upload/prep/subcycle/finish/download == evpk_run; subcycles may be issued in pieces."""
     case, d, f = util.make_case(100, 116, 25, 29, land="continents")
