@@ -1,0 +1,114 @@
+!=======================================================================
+! evp_driver -- stand-alone Fortran host for the drop-in shim: loads a binary
+! fixture (written by tests/test_fortran_gpu.py) into the module arrays, calls
+!     call evp (dt)
+! exactly as ice_step_mod.F90:1119 does, and writes the arrays evp leaves
+! modified.  Used on the GPU box to prove the Fortran -> ISO_C_BINDING ->
+! libevpk -> HIP path end to end (BASELINE config 1 plumbing).
+!   usage: evp_driver <fixture.bin> <out.bin>
+!=======================================================================
+      program evp_driver
+
+      use ice_kinds_mod
+      use ice_blocks
+      use ice_domain
+      use ice_domain_size
+      use ice_grid
+      use ice_state
+      use ice_flux
+      use ice_atmo
+      use ice_dyn_shared
+      use ice_dyn_evp, only: evp
+
+      implicit none
+      character (len=512) :: fin, fout
+      integer (int_kind) :: hdr(10), n, i, nb, ncalls, call_no, ew, ns
+      real (dbl_kind) :: sc(8), dt
+      integer (int_kind), allocatable :: geo(:,:), itmp(:,:,:)
+      character (len=16) :: nsname
+      common /mock_bnd/ nsname
+
+      call get_command_argument (1, fin)
+      call get_command_argument (2, fout)
+      open (10, file=trim(fin), access='stream', form='unformatted', status='old')
+      read (10) hdr
+      read (10) sc
+      nx_global = hdr(1); ny_global = hdr(2); nx_block = hdr(3); ny_block = hdr(4); nb = hdr(5)
+      ew = hdr(6); ns = hdr(7); ndte = hdr(8); revised_evp = hdr(9) /= 0; ncalls = hdr(10)
+      dt = sc(1); revp = sc(2); ecci = sc(3); denom1 = sc(4); arlx1i = sc(5); brlx = sc(6); cosw = sc(7); sinw = sc(8)
+      nblocks = nb; max_blocks = nb
+      ew_boundary_type = 'cyclic'; if (ew == 1) ew_boundary_type = 'open'; if (ew == 2) ew_boundary_type = 'closed'
+      ns_boundary_type = 'open'; if (ns == 2) ns_boundary_type = 'closed'; if (ns == 3) ns_boundary_type = 'tripole'
+      nsname = ns_boundary_type
+
+      allocate (geo(nb,6), all_blocks(nb), blocks_ice(nb))
+      read (10) geo
+      do n = 1, nb
+         blocks_ice(n) = n
+         all_blocks(n)%block_id = n
+         all_blocks(n)%ilo = geo(n,1); all_blocks(n)%ihi = geo(n,2)
+         all_blocks(n)%jlo = geo(n,3); all_blocks(n)%jhi = geo(n,4)
+         allocate (all_blocks(n)%i_glob(nx_block), all_blocks(n)%j_glob(ny_block))
+         do i = 1, nx_block
+            all_blocks(n)%i_glob(i) = geo(n,5) + (i - geo(n,1))
+         enddo
+         do i = 1, ny_block
+            all_blocks(n)%j_glob(i) = geo(n,6) + (i - geo(n,3))
+         enddo
+         all_blocks(n)%tripole = (ns == 3 .and. all_blocks(n)%j_glob(geo(n,4)) == ny_global)
+      enddo
+
+      call rd (dxt); call rd (dyt); call rd (dxhy); call rd (dyhx); call rd (cxp); call rd (cyp)
+      call rd (cxm); call rd (cym); call rd (tarear); call rd (uarear); call rd (tinyarea)
+      call rd (tarea); call rd (uarea); call rd (fcor_blk)
+      call rd (aice); call rd (vice); call rd (vsno); call rd (aice_init)
+      call rd (strairxT); call rd (strairyT); call rd (strax); call rd (stray)
+      call rd (uocn); call rd (vocn); call rd (ss_tltx); call rd (ss_tlty); call rd (Cdn_ocn); call rd (strength)
+      call rd (uvel); call rd (vvel)
+      call rd (stressp_1); call rd (stressp_2); call rd (stressp_3); call rd (stressp_4)
+      call rd (stressm_1); call rd (stressm_2); call rd (stressm_3); call rd (stressm_4)
+      call rd (stress12_1); call rd (stress12_2); call rd (stress12_3); call rd (stress12_4)
+      allocate (itmp(nx_block,ny_block,nb), tmask(nx_block,ny_block,nb), umask(nx_block,ny_block,nb), &
+                iceumask(nx_block,ny_block,nb))
+      read (10) itmp; tmask = itmp /= 0
+      read (10) itmp; umask = itmp /= 0
+      read (10) itmp; iceumask = itmp /= 0
+      close (10)
+
+      call zr (divu); call zr (shear); call zr (rdg_conv); call zr (rdg_shear); call zr (prs_sig)
+      call zr (strintx); call zr (strinty); call zr (strocnx); call zr (strocny)
+      call zr (strocnxT); call zr (strocnyT); call zr (strairx); call zr (strairy)
+      call zr (strtltx); call zr (strtlty); call zr (fm); call zr (uvel_init); call zr (vvel_init); call zr (aice0)
+      allocate (aicen(nx_block,ny_block,1,nb), vicen(nx_block,ny_block,1,nb))
+      aicen = 0.0_dbl_kind; vicen = 0.0_dbl_kind
+
+      do call_no = 1, ncalls
+         call evp (dt)
+      enddo
+
+      open (11, file=trim(fout), access='stream', form='unformatted', status='replace')
+      write (11) uvel, vvel, stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
+                 stress12_1, stress12_2, stress12_3, stress12_4, divu, shear, rdg_conv, rdg_shear, prs_sig, &
+                 strintx, strinty, strocnx, strocny, strocnxT, strocnyT, strairx, strairy, strtltx, strtlty, fm, &
+                 uvel_init, vvel_init
+      itmp = 0
+      where (iceumask) itmp = 1
+      write (11) itmp
+      close (11)
+      write (*,'(a,i0,a,i0,a,es12.5)') 'evp_driver: ', ncalls, ' call(s) of evp(dt) on ', nb, ' block(s); max |uvel| = ', maxval(abs(uvel))
+
+      contains
+
+      subroutine rd (a)
+      real (dbl_kind), allocatable, intent(inout) :: a(:,:,:)
+      allocate (a(nx_block,ny_block,nb))
+      read (10) a
+      end subroutine rd
+
+      subroutine zr (a)
+      real (dbl_kind), allocatable, intent(inout) :: a(:,:,:)
+      allocate (a(nx_block,ny_block,nb))
+      a = 0.0_dbl_kind
+      end subroutine zr
+
+      end program evp_driver

@@ -1,0 +1,131 @@
+!=======================================================================
+! evpk_mod -- ISO_C_BINDING view of libevpk (include/evpk.h): the C ABI of the
+! MI355X EVP solver, as a Fortran host model binds it.
+!
+! The derived types mirror the C structs field for field (bind(C)); all array
+! arguments are passed as c_loc of the caller's own block arrays
+! real(dbl_kind) a(nx_block,ny_block,max_blocks) -- the library borrows them
+! for the duration of a call only.  Fortran LOGICAL arrays are not interoperable:
+! the caller converts tmask/umask/iceumask to integer(c_int32_t) 0/1.
+!=======================================================================
+      module evpk_mod
+
+      use, intrinsic :: iso_c_binding
+      implicit none
+      private
+
+      integer (c_int), parameter, public :: &
+         EVPK_BND_CYCLIC = 0, EVPK_BND_OPEN = 1, EVPK_BND_CLOSED = 2, EVPK_BND_TRIPOLE = 3
+      integer, parameter, public :: EVPK_UNIQUE_ID_BYTES = 128
+
+      type, bind(C), public :: evpk_geom
+         integer (c_int32_t) :: nx_global, ny_global
+         integer (c_int32_t) :: nx_block, ny_block, nblocks
+         integer (c_int32_t) :: ew_boundary, ns_boundary
+         type (c_ptr) :: ilo, ihi, jlo, jhi
+         type (c_ptr) :: iglob_lo, jglob_lo
+         integer (c_int32_t) :: rank, nranks
+         integer (c_int32_t) :: device
+         type (c_ptr) :: unique_id
+         type (c_ptr) :: dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym
+         type (c_ptr) :: tarear, uarear, tinyarea, tarea, uarea, fcor
+         type (c_ptr) :: tmask, umask
+      end type evpk_geom
+
+      type, bind(C), public :: evpk_params
+         real (c_double) :: dt
+         integer (c_int32_t) :: ndte
+         integer (c_int32_t) :: revised_evp
+         real (c_double) :: revp, ecci, denom1, arlx1i, brlx
+         real (c_double) :: cosw, sinw
+         real (c_double) :: rhow, rhoi, rhos, gravit
+         real (c_double) :: a_min, m_min
+         integer (c_int32_t) :: tilt_from_slope
+         integer (c_int32_t) :: wind_on_ugrid
+      end type evpk_params
+
+      type, bind(C), public :: evpk_step_in
+         type (c_ptr) :: aice, vice, vsno, aice_init
+         type (c_ptr) :: strairxT, strairyT, strax, stray
+         type (c_ptr) :: uocn, vocn, ss_tltx, ss_tlty, Cdn_ocn
+         type (c_ptr) :: strength
+      end type evpk_step_in
+
+      type, bind(C), public :: evpk_state
+         type (c_ptr) :: uvel, vvel
+         type (c_ptr) :: stressp(4), stressm(4), stress12(4)
+         type (c_ptr) :: iceumask
+         type (c_ptr) :: divu, shear, rdg_conv, rdg_shear, prs_sig
+         type (c_ptr) :: strintx, strinty, strocnx, strocny, strocnxT, strocnyT
+         type (c_ptr) :: strairx, strairy, strtltx, strtlty, fm
+         type (c_ptr) :: tmass
+         type (c_ptr) :: aiu, umass, uvel_init, vvel_init
+         type (c_ptr) :: icetmask
+      end type evpk_state
+
+      type, bind(C), public :: evpk_stats
+         integer (c_int64_t) :: icellt, icellu, ncell_slab
+         integer (c_int32_t) :: nstrips, nstrips_total, subcycles_done
+         real (c_float) :: loop_ms, kernel_ms
+         integer (c_int32_t) :: kernel_launches
+      end type evpk_stats
+
+      public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &
+                evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string
+
+      interface
+         integer (c_int) function evpk_get_unique_id (id) bind(C, name='evpk_get_unique_id')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: id
+         end function
+         integer (c_int) function evpk_create (g, ctx) bind(C, name='evpk_create')
+            import :: c_int, c_ptr, evpk_geom
+            type (evpk_geom), intent(in) :: g
+            type (c_ptr), intent(out) :: ctx
+         end function
+         integer (c_int) function evpk_set_params (ctx, p) bind(C, name='evpk_set_params')
+            import :: c_int, c_ptr, evpk_params
+            type (c_ptr), value :: ctx
+            type (evpk_params), intent(in) :: p
+         end function
+         integer (c_int) function evpk_run (ctx, sin, st) bind(C, name='evpk_run')
+            import :: c_int, c_ptr, evpk_step_in, evpk_state
+            type (c_ptr), value :: ctx
+            type (evpk_step_in), intent(in) :: sin
+            type (evpk_state), intent(in) :: st
+         end function
+         integer (c_int) function evpk_get_stats (ctx, s) bind(C, name='evpk_get_stats')
+            import :: c_int, c_ptr, evpk_stats
+            type (c_ptr), value :: ctx
+            type (evpk_stats), intent(out) :: s
+         end function
+         integer (c_int) function evpk_destroy (ctx) bind(C, name='evpk_destroy')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ctx
+         end function
+         type (c_ptr) function evpk_last_error (ctx) bind(C, name='evpk_last_error')
+            import :: c_ptr
+            type (c_ptr), value :: ctx
+         end function
+      end interface
+
+      contains
+
+      ! C string of evpk_last_error -> Fortran string (for abort_ice)
+      function evpk_error_string (ctx) result (msg)
+         type (c_ptr), intent(in) :: ctx
+         character (len=512) :: msg
+         type (c_ptr) :: p
+         character (kind=c_char), pointer :: s(:)
+         integer :: i
+         msg = ' '
+         p = evpk_last_error (ctx)
+         if (.not. c_associated(p)) return
+         call c_f_pointer (p, s, [512])
+         do i = 1, 512
+            if (s(i) == c_null_char) exit
+            msg(i:i) = s(i)
+         enddo
+      end function evpk_error_string
+
+      end module evpk_mod

@@ -1,0 +1,350 @@
+!=======================================================================
+! ice_dyn_evp -- drop-in replacement of source/ice_dyn_evp.F90 (COSIMA/cice5)
+! for MI355X: same module name, same public entry point
+!
+!     subroutine evp (dt)          (reference: ice_dyn_evp.F90:68)
+!
+! so that ice_step_mod.F90:1119  `if (kdyn == 1) call evp (dt)`  links unchanged.
+! All module-global state keeps living in the reference's own modules
+! (ice_state, ice_flux, ice_grid, ice_dyn_shared, ...); this module hands those
+! arrays to libevpk (HIP kernels) through the ISO_C_BINDING interface evpk_mod
+! and copies nothing else.  What stays on the host, exactly as in the reference:
+!   * evp_prep1 + halo of icetmask + the T-cell index list, needed only to call
+!     ice_strength with its reference signature (ice_dyn_evp.F90:194-212,291-301;
+!     ice_dyn_shared.F90:528-537);
+!   * timers (timer_dynamics) and abort_ice on error.
+! Everything else of evp() -- to_ugrid, t2ugrid_vector, evp_prep2, the ndte
+! subcycles of stress + stepu with their halo updates, the tripole stress fold,
+! evp_finish, u2tgrid_vector -- runs on the GPU inside evpk_run.
+!
+! cpp:  EVPK_USE_MPI   broadcast the RCCL unique id with MPI (mpi/ comm layer)
+!       AusCOM, ACCESS, coupled   as in the reference
+!=======================================================================
+
+      module ice_dyn_evp
+
+      use ice_kinds_mod
+      use ice_dyn_shared ! everything
+      use, intrinsic :: iso_c_binding
+      use evpk_mod
+
+#ifdef AusCOM
+      use cpl_parameters
+      use cpl_arrays_setup, only : sicemass
+#endif
+
+      implicit none
+      private
+      public :: evp
+      save
+
+      type (c_ptr) :: ctx = c_null_ptr          ! libevpk context (one per MPI rank = one GPU)
+      logical (kind=log_kind) :: ctx_ready = .false.
+
+      ! LOGICAL arrays are not C-interoperable: int32 copies (ice_kinds_mod.F90:20-21)
+      integer (c_int32_t), dimension(:,:,:), allocatable, target :: &
+         tmask_i, umask_i, iceumask_i
+
+      integer (c_int32_t), dimension(:), allocatable, target :: &
+         g_ilo, g_ihi, g_jlo, g_jhi, g_iglob, g_jglob
+
+      character (kind=c_char), dimension(EVPK_UNIQUE_ID_BYTES), target :: uid
+
+!=======================================================================
+
+      contains
+
+!=======================================================================
+! First call: describe the block decomposition and the time-invariant grid
+! to the library (replaces nothing in the reference: evp() reads the same
+! entities from ice_blocks / ice_domain / ice_grid on every call).
+
+      subroutine evpk_setup
+
+      use ice_blocks, only: block, get_block, nx_block, ny_block
+      use ice_communicate, only: my_task, master_task, get_num_procs
+      use ice_domain, only: nblocks, blocks_ice, ew_boundary_type, ns_boundary_type
+      use ice_domain_size, only: nx_global, ny_global, max_blocks
+      use ice_exit, only: abort_ice
+      use ice_grid, only: tmask, umask, dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, &
+          tarear, uarear, tinyarea, tarea, uarea
+#ifdef EVPK_USE_MPI
+      use ice_communicate, only: MPI_COMM_ICE
+      include 'mpif.h'
+      integer :: ierr
+#endif
+
+      type (evpk_geom) :: g
+      type (block) :: this_block
+      integer (kind=int_kind) :: iblk, rc, ndev
+
+      allocate (g_ilo(nblocks), g_ihi(nblocks), g_jlo(nblocks), g_jhi(nblocks), &
+                g_iglob(nblocks), g_jglob(nblocks))
+      do iblk = 1, nblocks
+         this_block = get_block(blocks_ice(iblk),iblk)
+         g_ilo(iblk) = this_block%ilo
+         g_ihi(iblk) = this_block%ihi
+         g_jlo(iblk) = this_block%jlo
+         g_jhi(iblk) = this_block%jhi
+         g_iglob(iblk) = this_block%i_glob(this_block%ilo)
+         g_jglob(iblk) = this_block%j_glob(this_block%jlo)
+      enddo
+
+      allocate (tmask_i   (nx_block,ny_block,max_blocks), &
+                umask_i   (nx_block,ny_block,max_blocks), &
+                iceumask_i(nx_block,ny_block,max_blocks))
+      tmask_i = 0
+      umask_i = 0
+      where (tmask) tmask_i = 1
+      where (umask) umask_i = 1
+
+      g%nx_global = nx_global
+      g%ny_global = ny_global
+      g%nx_block  = nx_block
+      g%ny_block  = ny_block
+      g%nblocks   = nblocks
+      g%ew_boundary = bnd_code(ew_boundary_type)
+      g%ns_boundary = bnd_code(ns_boundary_type)
+      g%ilo = c_loc(g_ilo);  g%ihi = c_loc(g_ihi)
+      g%jlo = c_loc(g_jlo);  g%jhi = c_loc(g_jhi)
+      g%iglob_lo = c_loc(g_iglob);  g%jglob_lo = c_loc(g_jglob)
+      g%rank   = my_task
+      g%nranks = get_num_procs()
+      g%device = 0                       ! one rank per GPU: ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES selects it
+      g%unique_id = c_null_ptr
+      if (g%nranks > 1) then
+#ifdef EVPK_USE_MPI
+         if (my_task == master_task) then
+            if (evpk_get_unique_id(c_loc(uid)) /= 0) call abort_ice('evp: evpk_get_unique_id failed')
+         endif
+         call MPI_BCAST(uid, EVPK_UNIQUE_ID_BYTES, MPI_BYTE, master_task, MPI_COMM_ICE, ierr)
+         g%unique_id = c_loc(uid)
+#else
+         call abort_ice('evp: more than one task needs -DEVPK_USE_MPI')
+#endif
+      endif
+      g%dxt = c_loc(dxt);   g%dyt = c_loc(dyt);   g%dxhy = c_loc(dxhy); g%dyhx = c_loc(dyhx)
+      g%cxp = c_loc(cxp);   g%cyp = c_loc(cyp);   g%cxm  = c_loc(cxm);  g%cym  = c_loc(cym)
+      g%tarear = c_loc(tarear); g%uarear = c_loc(uarear); g%tinyarea = c_loc(tinyarea)
+      g%tarea  = c_loc(tarea);  g%uarea  = c_loc(uarea);  g%fcor = c_loc(fcor_blk)
+      g%tmask  = c_loc(tmask_i); g%umask = c_loc(umask_i)
+
+      rc = evpk_create (g, ctx)
+      if (rc /= 0) call abort_ice('evp: evpk_create: '//trim(evpk_error_string(c_null_ptr)))
+      ctx_ready = .true.
+
+      end subroutine evpk_setup
+
+!=======================================================================
+
+      integer (c_int32_t) function bnd_code (name)
+      use ice_exit, only: abort_ice
+      character (*), intent(in) :: name
+      select case (trim(name))
+      case ('cyclic');   bnd_code = EVPK_BND_CYCLIC
+      case ('open');     bnd_code = EVPK_BND_OPEN
+      case ('closed');   bnd_code = EVPK_BND_CLOSED
+      case ('tripole');  bnd_code = EVPK_BND_TRIPOLE
+      case default
+         bnd_code = -1
+         call abort_ice('evp: boundary type not supported on the GPU path: '//trim(name))
+      end select
+      end function bnd_code
+
+!=======================================================================
+! Elastic-viscous-plastic dynamics driver -- same interface as the reference.
+
+      subroutine evp (dt)
+
+      use ice_atmo, only: Cdn_ocn
+      use ice_boundary, only: ice_HaloUpdate
+      use ice_blocks, only: block, get_block, nx_block, ny_block
+      use ice_constants, only: field_loc_center, field_type_scalar, c0, &
+          rhow, rhoi, rhos, gravit, p001, p01
+      use ice_domain, only: nblocks, blocks_ice, halo_info
+      use ice_domain_size, only: max_blocks
+      use ice_exit, only: abort_ice
+      use ice_flux, only: rdg_conv, rdg_shear, prs_sig, strairxT, strairyT, &
+          strairx, strairy, uocn, vocn, ss_tltx, ss_tlty, iceumask, fm, &
+          strtltx, strtlty, strocnx, strocny, strintx, strinty, &
+          strocnxT, strocnyT, strax, stray, &
+          stressp_1, stressp_2, stressp_3, stressp_4, &
+          stressm_1, stressm_2, stressm_3, stressm_4, &
+          stress12_1, stress12_2, stress12_3, stress12_4
+      use ice_mechred, only: ice_strength
+      use ice_state, only: aice, vice, vsno, uvel, vvel, divu, shear, &
+          aice_init, aice0, aicen, vicen, strength
+      use ice_timers, only: timer_dynamics, timer_bound, &
+          ice_timer_start, ice_timer_stop
+#ifdef ACCESS
+      use ice_atmo, only: calc_strair
+#endif
+
+      real (kind=dbl_kind), intent(in) :: &
+         dt      ! time step
+
+      ! local variables
+
+      integer (kind=int_kind) :: &
+         iblk, ilo,ihi,jlo,jhi, i, j, icellt, rc
+
+      integer (kind=int_kind), dimension (nx_block*ny_block) :: &
+         indxti, indxtj     ! compressed T-cell index list for ice_strength
+
+      real (kind=dbl_kind), dimension (:,:,:), allocatable, target :: &
+         tmass, aiu, umass  ! outputs of the library the reference keeps as locals
+
+      integer (kind=int_kind), dimension (:,:,:), allocatable, target :: &
+         icetmask
+
+      type (block) :: this_block
+      type (evpk_params)  :: p
+      type (evpk_step_in) :: sin
+      type (evpk_state)   :: st
+
+      call ice_timer_start(timer_dynamics) ! dynamics
+
+      if (.not. ctx_ready) call evpk_setup
+
+      allocate (tmass(nx_block,ny_block,max_blocks), aiu(nx_block,ny_block,max_blocks), &
+                umass(nx_block,ny_block,max_blocks), icetmask(nx_block,ny_block,max_blocks))
+
+      !-----------------------------------------------------------------
+      ! scalars of set_evp_parameters (ice_dyn_shared.F90:185-259), read
+      ! every call so that a changed dt / namelist is honoured
+      !-----------------------------------------------------------------
+      p%dt = dt
+      p%ndte = ndte
+      p%revised_evp = merge(1, 0, revised_evp)
+      p%revp = revp;  p%ecci = ecci;  p%denom1 = denom1
+      p%arlx1i = arlx1i;  p%brlx = brlx
+      p%cosw = cosw;  p%sinw = sinw
+      p%rhow = rhow;  p%rhoi = rhoi;  p%rhos = rhos;  p%gravit = gravit
+      p%a_min = p001; p%m_min = p01      ! a_min, m_min are private parameters of ice_dyn_shared (:60-61)
+#ifdef coupled
+      p%tilt_from_slope = 1
+#else
+      p%tilt_from_slope = 0
+#endif
+#ifdef AusCOM
+      if (.not. use_ocnslope) p%tilt_from_slope = 0      ! ice_dyn_shared.F90:604-608
+#endif
+      p%wind_on_ugrid = 0
+#ifdef ACCESS
+      if (.not. calc_strair) p%wind_on_ugrid = 1         ! ice_dyn_evp.F90:226-228
+#endif
+      rc = evpk_set_params (ctx, p)
+      if (rc /= 0) call abort_ice('evp: evpk_set_params: '//trim(evpk_error_string(ctx)))
+
+      !-----------------------------------------------------------------
+      ! ice strength (host, reference routine and signature): needs the
+      ! T-cell list of evp_prep2, hence evp_prep1 + halo of icetmask
+      !-----------------------------------------------------------------
+      do iblk = 1, nblocks
+         this_block = get_block(blocks_ice(iblk),iblk)
+         call evp_prep1 (nx_block,           ny_block,           &
+                         this_block%ilo, this_block%ihi, this_block%jlo, this_block%jhi, &
+                         aice    (:,:,iblk), vice    (:,:,iblk), &
+                         vsno    (:,:,iblk), tmask_l (iblk),     &
+                         strairxT(:,:,iblk), strairyT(:,:,iblk), &
+                         strairx (:,:,iblk), strairy (:,:,iblk), &
+                         tmass   (:,:,iblk), icetmask(:,:,iblk))
+      enddo
+      call ice_timer_start(timer_bound)
+      call ice_HaloUpdate (icetmask,          halo_info, &
+                           field_loc_center,  field_type_scalar)
+      call ice_timer_stop(timer_bound)
+
+      do iblk = 1, nblocks
+         this_block = get_block(blocks_ice(iblk),iblk)
+         ilo = this_block%ilo;  ihi = this_block%ihi
+         jlo = this_block%jlo;  jhi = this_block%jhi
+         icellt = 0
+         do j = jlo, jhi+1
+         do i = ilo, ihi+1
+            if (icetmask(i,j,iblk) == 1) then
+               icellt = icellt + 1
+               indxti(icellt) = i
+               indxtj(icellt) = j
+            endif
+         enddo
+         enddo
+         call ice_strength (nx_block, ny_block,   &
+                            ilo, ihi, jlo, jhi,   &
+                            icellt,               &
+                            indxti,   indxtj,     &
+                            aice    (:,:,  iblk), &
+                            vice    (:,:,  iblk), &
+                            aice0   (:,:,  iblk), &
+                            aicen   (:,:,:,iblk), &
+                            vicen   (:,:,:,iblk), &
+                            strength(:,:,  iblk) )
+      enddo
+
+      !-----------------------------------------------------------------
+      ! everything else of evp(): one call into the HIP library
+      !-----------------------------------------------------------------
+      iceumask_i = 0
+      where (iceumask) iceumask_i = 1
+
+      sin%aice = c_loc(aice);  sin%vice = c_loc(vice);  sin%vsno = c_loc(vsno)
+      sin%aice_init = c_loc(aice_init)
+      sin%strairxT = c_loc(strairxT);  sin%strairyT = c_loc(strairyT)
+      sin%strax = c_loc(strax);        sin%stray = c_loc(stray)
+      sin%uocn = c_loc(uocn);          sin%vocn = c_loc(vocn)
+      sin%ss_tltx = c_loc(ss_tltx);    sin%ss_tlty = c_loc(ss_tlty)
+      sin%Cdn_ocn = c_loc(Cdn_ocn)
+      sin%strength = c_loc(strength)
+
+      st%uvel = c_loc(uvel);  st%vvel = c_loc(vvel)
+      st%stressp(1) = c_loc(stressp_1);   st%stressp(2) = c_loc(stressp_2)
+      st%stressp(3) = c_loc(stressp_3);   st%stressp(4) = c_loc(stressp_4)
+      st%stressm(1) = c_loc(stressm_1);   st%stressm(2) = c_loc(stressm_2)
+      st%stressm(3) = c_loc(stressm_3);   st%stressm(4) = c_loc(stressm_4)
+      st%stress12(1) = c_loc(stress12_1); st%stress12(2) = c_loc(stress12_2)
+      st%stress12(3) = c_loc(stress12_3); st%stress12(4) = c_loc(stress12_4)
+      st%iceumask = c_loc(iceumask_i)
+      st%divu = c_loc(divu);          st%shear = c_loc(shear)
+      st%rdg_conv = c_loc(rdg_conv);  st%rdg_shear = c_loc(rdg_shear)
+      st%prs_sig = c_loc(prs_sig)
+      st%strintx = c_loc(strintx);    st%strinty = c_loc(strinty)
+      st%strocnx = c_loc(strocnx);    st%strocny = c_loc(strocny)
+      st%strocnxT = c_loc(strocnxT);  st%strocnyT = c_loc(strocnyT)
+      st%strairx = c_loc(strairx);    st%strairy = c_loc(strairy)
+      st%strtltx = c_loc(strtltx);    st%strtlty = c_loc(strtlty)
+      st%fm = c_loc(fm)
+      st%tmass = c_loc(tmass)
+      st%aiu = c_loc(aiu);  st%umass = c_loc(umass)
+      st%uvel_init = c_loc(uvel_init);  st%vvel_init = c_loc(vvel_init)
+      st%icetmask = c_null_ptr
+
+      rc = evpk_run (ctx, sin, st)
+      if (rc /= 0) call abort_ice('evp: evpk_run: '//trim(evpk_error_string(ctx)))
+
+      iceumask = (iceumask_i == 1)
+
+#ifdef AusCOM
+      sicemass(:,:,:) = tmass(:,:,:)          ! ice_dyn_evp.F90:205-207
+#endif
+
+      deallocate (tmass, aiu, umass, icetmask)
+
+      call ice_timer_stop(timer_dynamics)    ! dynamics
+
+      contains
+
+         ! tmask(:,:,iblk) as the explicit-shape logical argument evp_prep1 expects
+         function tmask_l (ib) result (m)
+            use ice_grid, only: tmask
+            integer (kind=int_kind), intent(in) :: ib
+            logical (kind=log_kind) :: m(nx_block,ny_block)
+            m = tmask(:,:,ib)
+         end function tmask_l
+
+      end subroutine evp
+
+!=======================================================================
+
+      end module ice_dyn_evp
+
+!=======================================================================
