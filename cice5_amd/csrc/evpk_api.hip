@@ -652,6 +652,16 @@ extern "C" int evpk_run(evpk_ctx *c, const evpk_step_in *in, evpk_state *st) {
     return evpk_download(c, st);
 }
 
+extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
+    if (!c) return 1;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int n = 0; n < nrep; n++)   // WORK1/WORK2 pair plane: scratch, rewritten by the next prep/finish
+        hipLaunchKernelGGL(k_calib_copy_pair, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, (int)(F_WORK1 & ~1), (int)(F_DIVU & ~1));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     if (!c || !o) return 1;
     o->icellt = c->icellt; o->icellu = c->icellu;

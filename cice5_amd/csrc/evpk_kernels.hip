@@ -166,6 +166,18 @@ __global__ void k_to_tgrid(Slab s, int fsrc, int fdst) {
     }
 }
 
+// profiling aid: copy one pair plane with the hot kernel's access shape (16 B per lane, coalesced);
+// moves exactly (nxl+2)*(nyl+2)*16 bytes each way -- a known byte count to calibrate FETCH_SIZE / WRITE_SIZE
+__global__ void k_calib_copy_pair(Slab s, int fsrc_even, int fdst_even) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > s.nxl + 1 || j > s.nyl + 1) return;
+    const size_t k = cell(s, i, j);
+    const double2 *src = reinterpret_cast<const double2 *>(s.F) + (size_t)(fsrc_even >> 1) * s.pitch + k;
+    double2 *dst = reinterpret_cast<double2 *>(s.F) + (size_t)(fdst_even >> 1) * s.pitch + k;
+    *dst = *src;
+}
+
 __global__ void k_copy_plane(Slab s, int fsrc, int fdst) {
     SLAB_IJ_ALL
     FD(s, fdst, k) = FD(s, fsrc, k);

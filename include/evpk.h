@@ -138,6 +138,11 @@ int evpk_download(evpk_ctx *c, evpk_state *st);
 int evpk_sync(evpk_ctx *c);
 
 int evpk_get_stats(evpk_ctx *c, evpk_stats *s);
+
+/* Profiling aid: nrep device-to-device copies of one scratch pair plane with the hot kernel's access
+ * shape (16 B per lane, coalesced).  Each moves exactly (nxl+2)*(nyl+2)*16 bytes each way: a known
+ * byte count in the PMC trace to calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
+int evpk_calibrate(evpk_ctx *c, int32_t nrep);
 int evpk_destroy(evpk_ctx *c);
 const char *evpk_last_error(const evpk_ctx *c);  /* c may be NULL: error of the last failed evpk_create */
 
