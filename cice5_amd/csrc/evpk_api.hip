@@ -29,6 +29,7 @@ struct evpk_ctx {
     Slab s{};
     DevParams p{};
     bool have_params = false, uploaded = false, prepped = false;
+    bool fresh = true;          // state planes were (re)loaded from the host since the last prep
     int nxb = 0, nyb = 0, nblocks = 0;
     std::vector<BlockDesc> bd;
     BlockDesc *d_bd = nullptr;
@@ -437,8 +438,9 @@ extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
 }
 
 extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state *st) {
-    if (!c || !in || !st) return 1;
+    if (!c || !in) return 1;
     if (!c->have_params) FAIL(c, "evpk_set_params has not been called");
+    if (!st && !c->uploaded) FAIL(c, "the first evpk_upload needs the state");
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
     struct { const double *h; int f; bool need; } ip[] = {
@@ -451,6 +453,11 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
     for (auto &e : ip) {
         if (!e.h) { if (e.need) FAIL(c, "a required input pointer is NULL"); continue; }
         if (upload_f(c, e.h, e.f)) return 1;
+    }
+    if (!st) {      // inputs only: the prognostic state stays resident on the device
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->prepped = false;
+        return 0;
     }
     if (!st->uvel || !st->vvel || !st->iceumask) FAIL(c, "uvel/vvel/iceumask is NULL");
     if (upload_f(c, st->uvel, F_STATE0 + S_U)) return 1;
@@ -469,6 +476,7 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
     c->cur = 0;
     c->uploaded = true;
     c->prepped = false;
+    c->fresh = true;
     return 0;
 }
 
@@ -484,27 +492,25 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         c->cur = 0;
     }
     // evp_prep1 + zero diagnostics (ice_dyn_evp.F90:171-203)
-    hipLaunchKernelGGL(k_prep1a, g2, B2D, 0, c->stream, s, c->p);
+    const int fresh = c->fresh ? 1 : 0;
+    hipLaunchKernelGGL(k_prep1a, g2, B2D, 0, c->stream, s, c->p, fresh);
     hipLaunchKernelGGL(k_prep1b, g2, B2D, 0, c->stream, s);
     if (halo(c, F_ICETM, 1, false, false, 0.0)) return 1;                         // :210-211
-    // to_ugrid (:218-219)
-    hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_TMASS, (int)F_UMASS);
-    hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_AICE_INIT, (int)F_AIU);
-    if (!c->p.wind_on_ugrid) {                                                    // t2ugrid_vector (:240-241)
-        if (halo(c, F_STRAIRX, 2, false, true, 0.0)) return 1;
-        hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STRAIRX, (int)F_WORK1);
-        hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STRAIRY, (int)F_WORK2);
-        hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_WORK1, (int)F_STRAIRX);
-        hipLaunchKernelGGL(k_to_ugrid, g2, B2D, 0, c->stream, s, (int)F_WORK2, (int)F_STRAIRY);
-    }
+    // to_ugrid (:218-219) and t2ugrid_vector (:240-241; the T-grid wind sits in the work planes)
+    if (!c->p.wind_on_ugrid && halo(c, F_WORK1, 2, false, true, 0.0)) return 1;
+    hipLaunchKernelGGL(k_to_ugrid4, g2, B2D, 0, c->stream, s, c->p.wind_on_ugrid ? 0 : 1);
     // evp_prep2 (:247-308); strength is an input (ice_strength, :291-301)
-    hipLaunchKernelGGL(k_prep2, g2, B2D, 0, c->stream, s, c->p);
+    hipLaunchKernelGGL(k_prep2, g2, B2D, 0, c->stream, s, c->p, fresh);
     if (halo(c, F_STRENGTH, 1, false, false, 0.0)) return 1;                      // :311-312
     if (halo(c, F_STATE0 + S_U, 2, true, true, 0.0)) return 1;                    // :314-315
-    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)(F_STATE0 + S_U), (int)(F_STATE1 + S_U));
-    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)(F_STATE0 + S_V), (int)(F_STATE1 + S_V));
+    {   // the top physical row may have been rewritten by a tripole fold, the ring by the halo: mirror into buffer 1
+        const int nring = 2 * (s.nxl + 2) + 2 * (s.nyl + 2);
+        hipLaunchKernelGGL(k_ring_copy, dim3((nring + 127) / 128), dim3(128), 0, c->stream, s, (int)(F_STATE0 + S_U), (int)(F_STATE1 + S_U), 2);
+        if (c->ns == EVPK_BND_TRIPOLE)
+            hipLaunchKernelGGL(k_row_copy, dim3((s.nxl + 2 + 127) / 128), dim3(128), 0, c->stream, s, (int)(F_STATE0 + S_U), (int)(F_STATE1 + S_U), 2, s.nyl);
+    }
+    c->fresh = false;
     // active strips
-    hipLaunchKernelGGL(k_icetm_to_cmask, g2, B2D, 0, c->stream, s);
     const int ns_tot = c->ncx * c->nry;
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 2, c->stream));
     hipLaunchKernelGGL(k_strip_flags, dim3((ns_tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx, c->nry, c->R, c->d_flags, c->d_counts);
@@ -597,11 +603,8 @@ extern "C" int evpk_finish(evpk_ctx *c) {
     }
     hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
     // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)
-    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STROCNXT, (int)F_WORK1);
-    hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)F_STROCNYT, (int)F_WORK2);
     if (halo(c, F_WORK1, 2, true, true, 0.0)) return 1;
-    hipLaunchKernelGGL(k_to_tgrid, g2, B2D, 0, c->stream, s, (int)F_WORK1, (int)F_STROCNXT);
-    hipLaunchKernelGGL(k_to_tgrid, g2, B2D, 0, c->stream, s, (int)F_WORK2, (int)F_STROCNYT);
+    hipLaunchKernelGGL(k_to_tgrid2, g2, B2D, 0, c->stream, s);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -656,7 +659,7 @@ extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
     if (!c) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     for (int n = 0; n < nrep; n++)   // WORK1/WORK2 pair plane: scratch, rewritten by the next prep/finish
-        hipLaunchKernelGGL(k_calib_copy_pair, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, (int)(F_WORK1 & ~1), (int)(F_DIVU & ~1));
+        hipLaunchKernelGGL(k_calib_copy_pair, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, (int)(F_WORK1 & ~1), (int)(F_WORK1 & ~1));   // in place: same bytes read and written
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;

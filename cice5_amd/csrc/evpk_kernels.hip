@@ -109,7 +109,9 @@ __global__ void k_fill_plane(Slab s, int f, double v) {
 // ------------------------------------------------------------------------------------
 // evp_prep1 (ice_dyn_shared.F90:270-365) on the slab
 // ------------------------------------------------------------------------------------
-__global__ void k_prep1a(Slab s, DevParams p) {
+// `fresh` = the state planes were just uploaded from the host (anything may be non-zero anywhere).
+// Otherwise cells that were inactive at the previous prep still hold their zeros and are skipped.
+__global__ void k_prep1a(Slab s, DevParams p, int fresh) {
     SLAB_IJ_ALL
     const double vice = FD(s, F_VICE, k), vsno = FD(s, F_VSNO, k), aice = FD(s, F_AICE, k);
     const bool tm = s.tmask[km] != 0;
@@ -117,11 +119,16 @@ __global__ void k_prep1a(Slab s, DevParams p) {
     if (tm) tmass = (p.rhoi * vice + p.rhos * vsno);                              // :322-326
     FD(s, F_TMASS, k) = tmass;
     s.tmphm[km] = (tm && (aice > p.a_min) && (tmass > p.m_min)) ? 1 : 0;           // :331-332
-    FD(s, F_STRAIRX, k) = FD(s, F_STRAIRXT, k);                             // :339-340
-    FD(s, F_STRAIRY, k) = FD(s, F_STRAIRYT, k);
-    // evp(): zero the diagnostics (ice_dyn_evp.F90:174-182)
-    FD(s, F_RDGCONV, k) = 0.0; FD(s, F_RDGSHEAR, k) = 0.0; FD(s, F_DIVU, k) = 0.0;
-    FD(s, F_SHEAR, k) = 0.0; FD(s, F_PRSSIG, k) = 0.0;
+    // :339-340 strairx = strairxT; the T->U average that follows (t2ugrid_vector) reads it from the
+    // work planes, so the copy lands there directly; U-grid wind (ACCESS) goes straight to strairx/y
+    const int wx = p.wind_on_ugrid ? F_STRAIRX : F_WORK1, wy = p.wind_on_ugrid ? F_STRAIRY : F_WORK2;
+    FD(s, wx, k) = FD(s, F_STRAIRXT, k);
+    FD(s, wy, k) = FD(s, F_STRAIRYT, k);
+    // evp(): zero the diagnostics (ice_dyn_evp.F90:174-182); only T cells active last time can be non-zero
+    if (fresh || (s.cmask[km] & CM_T)) {
+        FD(s, F_RDGCONV, k) = 0.0; FD(s, F_RDGSHEAR, k) = 0.0; FD(s, F_DIVU, k) = 0.0;
+        FD(s, F_SHEAR, k) = 0.0; FD(s, F_PRSSIG, k) = 0.0;
+    }
 }
 
 __global__ void k_prep1b(Slab s) {
@@ -151,6 +158,60 @@ __global__ void k_to_ugrid(Slab s, int fsrc, int fdst) {
 #undef TA_
     }
     FD(s, fdst, k) = r;
+}
+
+// the four T->U averages of evp() in one pass: umass <- tmass, aiu <- aice_init (ice_dyn_evp.F90:218-219) and,
+// unless the wind is already on the U grid, strairx/y <- work1/2 (t2ugrid_vector, :240-241)
+__global__ void k_to_ugrid4(Slab s, int wind) {
+    SLAB_IJ_ALL
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
+        const size_t ke = cell(s, i + 1, j), kn = cell(s, i, j + 1), kne = cell(s, i + 1, j + 1);
+        const double t0 = FD(s, F_TAREA, k), t1 = FD(s, F_TAREA, ke), t2 = FD(s, F_TAREA, kn), t3 = FD(s, F_TAREA, kne);
+        const double ua = FD(s, F_UAREA, k);
+#define UG_(f) (0.25 * (((FD(s, f, k) * t0 + FD(s, f, ke) * t1) + FD(s, f, kn) * t2) + FD(s, f, kne) * t3) / ua)
+        r0 = UG_(F_TMASS);
+        r1 = UG_(F_AICE_INIT);
+        if (wind) { r2 = UG_(F_WORK1); r3 = UG_(F_WORK2); }
+#undef UG_
+    }
+    FD(s, F_UMASS, k) = r0;
+    FD(s, F_AIU, k) = r1;
+    if (wind) { FD(s, F_STRAIRX, k) = r2; FD(s, F_STRAIRY, k) = r3; }
+}
+
+// the two U->T averages of u2tgrid_vector (ice_dyn_evp.F90:505-506): strocnxT/yT <- work1/2, physical cells
+__global__ void k_to_tgrid2(Slab s) {
+    SLAB_IJ_ALL
+    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
+        const size_t kw = cell(s, i - 1, j), ks = cell(s, i, j - 1), ksw = cell(s, i - 1, j - 1);
+        const double u0 = FD(s, F_UAREA, k), u1 = FD(s, F_UAREA, kw), u2 = FD(s, F_UAREA, ks), u3 = FD(s, F_UAREA, ksw);
+        const double ta = FD(s, F_TAREA, k);
+#define TG_(f) (0.25 * (((FD(s, f, k) * u0 + FD(s, f, kw) * u1) + FD(s, f, ks) * u2) + FD(s, f, ksw) * u3) / ta)
+        FD(s, F_STROCNXT, k) = TG_(F_WORK1);
+        FD(s, F_STROCNYT, k) = TG_(F_WORK2);
+#undef TG_
+    }
+}
+
+// ghost ring of nf planes: dst <- src (after a halo update of src)
+__global__ void k_ring_copy(Slab s, int fsrc, int fdst, int nf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nrow = s.nyl + 2, ncol = s.nxl + 2;
+    int i, j;
+    if (t < 2 * ncol) { i = t % ncol; j = (t < ncol) ? 0 : s.nyl + 1; }
+    else if (t < 2 * ncol + 2 * nrow) { const int q = t - 2 * ncol; j = q % nrow; i = (q < nrow) ? 0 : s.nxl + 1; }
+    else return;
+    const size_t k = cell(s, i, j);
+    for (int q = 0; q < nf; q++) FD(s, fdst + q, k) = FD(s, fsrc + q, k);
+}
+
+// one full row (all columns incl. ghosts) of nf planes: dst <- src
+__global__ void k_row_copy(Slab s, int fsrc, int fdst, int nf, int j) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > s.nxl + 1) return;
+    const size_t k = cell(s, i, j);
+    for (int q = 0; q < nf; q++) FD(s, fdst + q, k) = FD(s, fsrc + q, k);
 }
 
 // to_tgrid (ice_grid.F90:1924-1958): only physical cells of dst are written
@@ -184,45 +245,47 @@ __global__ void k_copy_plane(Slab s, int fsrc, int fdst) {
 }
 
 // ------------------------------------------------------------------------------------
-// evp_prep2 (ice_dyn_shared.F90:377-614) on the slab.  State lives in buffer 0 on entry;
-// both buffers are left identical on the physical cells (the ring is completed by the
-// halo update + copy that follow in evpk_prep).
+// evp_prep2 (ice_dyn_shared.F90:377-614) on the slab.  State lives in buffer 0 on entry; both
+// buffers are left identical (the velocity ring is completed by the halo update + ring copy that
+// follow in evpk_prep).  Invariant kept for the subcycle kernel, which never touches inactive
+// cells: sigma = 0 in both buffers where icetmask == 0, u = v = 0 in both where iceumask is false,
+// and the stepu input planes are 0 where iceumask is false.  Unless `fresh`, a cell that was
+// inactive at the previous prep already satisfies this and is skipped.
 // ------------------------------------------------------------------------------------
-__global__ void k_prep2(Slab s, DevParams p) {
+__global__ void k_prep2(Slab s, DevParams p, int fresh) {
     SLAB_IJ_ALL
-    const bool icet = FD(s, F_ICETM, k) == 1.0;
-    double wx = 0.0, wy = 0.0, fx = 0.0, fy = 0.0, umdti = 0.0, vrelc = 0.0;      // :484-490
+    const bool icet = FD(s, F_ICETM, k) == 1.0;          // after its halo update
+    const unsigned char cmold = s.cmask[km];
+    const bool prevT = fresh || (cmold & CM_T), prevU = fresh || (cmold & CM_U);
     if (p.revp == 1.0 || !icet) {                                                  // :492-518
+        if (icet || prevT) {
 #pragma unroll
-        for (int c = S_SP; c < NSTATE; c++) FD(s, F_STATE0 + c, k) = 0.0;
+            for (int c = S_SP; c < NSTATE; c++) { FD(s, F_STATE0 + c, k) = 0.0; FD(s, F_STATE1 + c, k) = 0.0; }
+        }
+    } else {
+#pragma unroll
+        for (int c = S_SP; c < NSTATE; c++) FD(s, F_STATE1 + c, k) = FD(s, F_STATE0 + c, k);
     }
     unsigned char cm = icet ? CM_T : 0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {                            // :545-577
         const double aiu = FD(s, F_AIU, k), umass = FD(s, F_UMASS, k);
-        const double uocn = FD(s, F_UOCN, k), vocn = FD(s, F_VOCN, k);
         const bool old = s.iceumask[km] != 0;
         const bool ium = (s.umask[km] != 0) && (aiu > p.a_min) && (umass > p.m_min);
         s.iceumask[km] = ium ? 1 : 0;
-        double u = FD(s, F_STATE0 + S_U, k), v = FD(s, F_STATE0 + S_V, k);
         if (ium) {
+            const double uocn = FD(s, F_UOCN, k), vocn = FD(s, F_VOCN, k);
+            double u = FD(s, F_STATE0 + S_U, k), v = FD(s, F_STATE0 + S_V, k);
             if (!old) { u = uocn; v = vocn; }
             cm |= CM_U;
-        } else {
-            u = 0.0; v = 0.0;
-            FD(s, F_STRINTX, k) = 0.0; FD(s, F_STRINTY, k) = 0.0;
-            FD(s, F_STROCNX, k) = 0.0; FD(s, F_STROCNY, k) = 0.0;
-        }
-        FD(s, F_STATE0 + S_U, k) = u;
-        FD(s, F_STATE0 + S_V, k) = v;
-        FD(s, F_UVEL_INIT, k) = u;
-        FD(s, F_VVEL_INIT, k) = v;
-        if (ium) {                                                                 // :583-612
-            umdti = umass / p.dt;
+            FD(s, F_STATE0 + S_U, k) = u; FD(s, F_STATE0 + S_V, k) = v;
+            FD(s, F_STATE1 + S_U, k) = u; FD(s, F_STATE1 + S_V, k) = v;
+            FD(s, F_UVEL_INIT, k) = u;    FD(s, F_VVEL_INIT, k) = v;
+            const double umdti = umass / p.dt;                                     // :583-612
             const double fm = FD(s, F_FCOR, k) * umass;
             FD(s, F_FM, k) = fm;
             const double sg = copysign(1.0, fm);
-            wx = uocn * p.cosw - vocn * p.sinw * sg;
-            wy = vocn * p.cosw + uocn * p.sinw * sg;
+            const double wx = uocn * p.cosw - vocn * p.sinw * sg;
+            const double wy = vocn * p.cosw + uocn * p.sinw * sg;
             double tx, ty;
             if (p.tilt_from_slope) {
                 tx = -p.gravit * umass * FD(s, F_SSTLTX, k);
@@ -233,18 +296,24 @@ __global__ void k_prep2(Slab s, DevParams p) {
             }
             FD(s, F_STRTLTX, k) = tx;
             FD(s, F_STRTLTY, k) = ty;
-            fx = FD(s, F_STRAIRX, k) + tx;
-            fy = FD(s, F_STRAIRY, k) + ty;
+            FD(s, F_WATERX, k) = wx; FD(s, F_WATERY, k) = wy;
+            FD(s, F_FORCEX, k) = FD(s, F_STRAIRX, k) + tx;
+            FD(s, F_FORCEY, k) = FD(s, F_STRAIRY, k) + ty;
+            FD(s, F_UMASSDTI, k) = umdti;
             // stepu: vrel = aiu*rhow*Cw*sqrt(..) evaluates (aiu*rhow)*Cw first (ice_dyn_shared.F90:708)
-            vrelc = aiu * p.rhow * FD(s, F_CW, k);
+            FD(s, F_VRELC, k) = aiu * p.rhow * FD(s, F_CW, k);
+        } else if (prevU || old) {
+            FD(s, F_STATE0 + S_U, k) = 0.0; FD(s, F_STATE0 + S_V, k) = 0.0;
+            FD(s, F_STATE1 + S_U, k) = 0.0; FD(s, F_STATE1 + S_V, k) = 0.0;
+            FD(s, F_UVEL_INIT, k) = 0.0;    FD(s, F_VVEL_INIT, k) = 0.0;
+            FD(s, F_STRINTX, k) = 0.0; FD(s, F_STRINTY, k) = 0.0;
+            FD(s, F_STROCNX, k) = 0.0; FD(s, F_STROCNY, k) = 0.0;
+            FD(s, F_WATERX, k) = 0.0; FD(s, F_WATERY, k) = 0.0;
+            FD(s, F_FORCEX, k) = 0.0; FD(s, F_FORCEY, k) = 0.0;
+            FD(s, F_UMASSDTI, k) = 0.0; FD(s, F_VRELC, k) = 0.0;
         }
     }
-    FD(s, F_WATERX, k) = wx; FD(s, F_WATERY, k) = wy;
-    FD(s, F_FORCEX, k) = fx; FD(s, F_FORCEY, k) = fy;
-    FD(s, F_UMASSDTI, k) = umdti; FD(s, F_VRELC, k) = vrelc;
     s.cmask[km] = cm;
-#pragma unroll
-    for (int c = 0; c < NSTATE; c++) FD(s, F_STATE1 + c, k) = FD(s, F_STATE0 + c, k);
 }
 
 // ------------------------------------------------------------------------------------
@@ -336,14 +405,6 @@ __global__ void k_ew_unpack(Slab s, int f, int nf, const double *recvW, const do
         FD(s, f + q, cell(s, 0, j)) = haveW ? recvW[(size_t)q * rows + j] : fill;
         FD(s, f + q, cell(s, s.nxl + 1, j)) = haveE ? recvE[(size_t)q * rows + j] : fill;
     }
-}
-
-// icetmask plane (double 0/1, after its halo update) -> cmask bit, then strip activity flags
-__global__ void k_icetm_to_cmask(Slab s) {
-    SLAB_IJ_ALL
-    unsigned char cm = s.cmask[km] & CM_U;
-    if (FD(s, F_ICETM, k) == 1.0) cm |= CM_T;
-    s.cmask[km] = cm;
 }
 
 // one wave per strip: is there any T work (cols cx*63+1..+64, rows jb..jb+R) or U work?
@@ -666,8 +727,9 @@ __global__ void k_finish(Slab s, DevParams p, int cur) {
         xT = sx / aiu;                                                             // :840-841
         yT = sy / aiu;
     }
-    FD(s, F_STROCNXT, k) = xT;
-    FD(s, F_STROCNYT, k) = yT;
+    // strocnxT/yT before the U->T average (u2tgrid_vector works on a copy, ice_grid.F90:1899): work planes
+    FD(s, F_WORK1, k) = xT;
+    FD(s, F_WORK2, k) = yT;
 }
 
 }  // namespace evpk

@@ -199,6 +199,11 @@ class Context:
         si, st = self._step_in(f), self._state(f)
         self._chk(self._L.evpk_upload(self._ctx, ct.byref(si), ct.byref(st)), "evpk_upload")
 
+    def upload_inputs(self, f):
+        """inputs only; the prognostic state stays resident on the device (evpk_upload with state == NULL)"""
+        si = self._step_in(f)
+        self._chk(self._L.evpk_upload(self._ctx, ct.byref(si), None), "evpk_upload")
+
     def prep(self):
         self._chk(self._L.evpk_prep(self._ctx), "evpk_prep")
 

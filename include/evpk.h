@@ -130,7 +130,7 @@ int evpk_set_params(evpk_ctx *c, const evpk_params *p);
 int evpk_run(evpk_ctx *c, const evpk_step_in *in, evpk_state *st);
 
 /* the same in stages (bench.py times prep..finish with the data resident in HBM) */
-int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state *st);
+int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state *st);  /* st == NULL: inputs only, the state stays resident on the device */
 int evpk_prep(evpk_ctx *c);
 int evpk_subcycle(evpk_ctx *c, int32_t nsub);   /* advances ksub; the last-subcycle diagnostics fire at ksub == ndte */
 int evpk_finish(evpk_ctx *c);

@@ -166,6 +166,45 @@ def test_staged_api_equals_run():
     assert not util.compare(d, b, a)
 
 
+def test_device_resident_steps_inputs_only_upload():
+    """The state (u, v, sigma, iceumask) stays on the device between evp() calls; only the inputs are
+    re-uploaded (evpk_upload with state == NULL).  Ice retreats and advances between the calls, which
+    exercises the skip-if-still-inactive logic of the prep kernels.  Oracle: the same calls back to back."""
+    case, d, f = util.make_case(100, 116, 25, 29, land="continents")
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, 30, xmin)
+    s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+    s.init_evp(3600.0)
+    ctx = s.ctx
+    I = np.arange(d.nx_block)[None, None, :] + np.zeros(fo["aice"].shape)
+    for call in range(4):
+        for ff in (fo, fg):
+            if call == 1:      # retreat: a band of ice disappears
+                cut = (ff["aice"] > 0) & (ff["aice"] < 0.8)
+                for n in ("aice", "vice", "vsno", "aice_init"):
+                    ff[n] = np.where(cut, 0.0, ff[n])
+            if call == 2:      # advance again, and new wind
+                for n in ("aice", "vice", "vsno", "aice_init", "strairxT", "strairyT", "strength"):
+                    ff[n] = f[n].copy()
+                ff["strairxT"] = -ff["strairxT"]
+            if call == 3:
+                ff["uocn"] = ff["uocn"] * 0.5
+        nt, nu, _ = orc.evp(d, p, fo)
+        if call == 0:
+            ctx.upload(fg)
+        else:
+            ctx.upload_inputs(fg)
+        ctx.prep(); ctx.subcycle(30); ctx.finish()
+        st = ctx.stats()
+        assert (st.icellt, st.icellu) == (nt, nu), call
+        out = util.clone(fg)
+        ctx.download(out)
+        bad = util.compare(d, out, fo)
+        assert not bad, f"call {call}: {bad[:6]}"
+    s.close()
+
+
 def test_errors_are_reported_not_fatal():
     case, d, f = util.make_case(100, 116, 100, 116)
     ctx = evpk.Context(d, f)
