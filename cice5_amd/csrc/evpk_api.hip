@@ -41,6 +41,11 @@ struct evpk_ctx {
     size_t stage_n = 0;
     // strips
     int ncx = 0, nry = 0, R = 8, nstrips = 0;
+    int ncx2 = 0, nstrips2 = 0;      // 61-column strips of the two-subcycle kernel
+    bool use_double = false;
+    unsigned char *d_flags2 = nullptr;
+    int *d_strips2 = nullptr;
+    int double_launches = 0;
     unsigned char *d_flags = nullptr;
     int *d_strips = nullptr;
     unsigned long long *d_counts = nullptr;
@@ -56,9 +61,10 @@ struct evpk_ctx {
     int cur = 0, ksub = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
-    float loop_ms = 0.f, kernel_ms = 0.f;
+    float loop_ms = 0.f, kernel_ms = 0.f, kernel2_ms = 0.f;
     int kernel_launches = 0;
-    bool time_kernels = false;
+    std::vector<char> kev_is_double;
+    bool time_kernels = true;      // HIP events around every subcycle kernel launch (EVPK_TIME_KERNELS=0 disables)
     bool force_exchange = false;   // EVPK_FORCE_EXCHANGE=1: single rank takes the multi-rank pack/exchange/unpack path (tests)
     std::string err;
 };
@@ -240,7 +246,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->d_flags2, c->d_strips2, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -332,6 +338,9 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipMalloc(&c->d_flags, (size_t)c->ncx * c->nry));
     HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * (size_t)c->ncx * c->nry));
     HIPCHK(c, hipMalloc(&c->d_counts, sizeof(unsigned long long) * 2));
+    c->ncx2 = (s.nxl + STRIP2_W - 1) / STRIP2_W;
+    HIPCHK(c, hipMalloc(&c->d_flags2, (size_t)c->ncx2 * c->nry));
+    HIPCHK(c, hipMalloc(&c->d_strips2, sizeof(int) * (size_t)c->ncx2 * c->nry));
 
     // neighbours on the slab ring
     int lay[5];
@@ -405,8 +414,12 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         // (they are divisors in to_ugrid / to_tgrid; the reference never visits them)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   // two subcycles per launch: single rank, no tripole fold between the subcycles (EVPK_DOUBLE=0 disables)
+        const char *e = getenv("EVPK_DOUBLE");
+        c->use_double = (g->nranks == 1) && (g->ns_boundary != EVPK_BND_TRIPOLE) && !c->force_exchange && !(e && atoi(e) == 0);
+    }
     const char *tk = getenv("EVPK_TIME_KERNELS");
-    c->time_kernels = tk && atoi(tk) != 0;
+    c->time_kernels = !(tk && atoi(tk) == 0);
     return 0;
 }
 
@@ -515,6 +528,13 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 2, c->stream));
     hipLaunchKernelGGL(k_strip_flags, dim3((ns_tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx, c->nry, c->R, c->d_flags, c->d_counts);
     HIPCHK(c, hipGetLastError());
+    const int ns_tot2 = c->ncx2 * c->nry;
+    std::vector<unsigned char> flags2(c->use_double ? ns_tot2 : 0);
+    if (c->use_double) {
+        hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry, c->R,
+                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->d_flags2);
+        HIPCHK(c, hipMemcpyAsync(flags2.data(), c->d_flags2, ns_tot2, hipMemcpyDeviceToHost, c->stream));
+    }
     std::vector<unsigned char> flags(ns_tot);
     unsigned long long cnt[2];
     HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags, ns_tot, hipMemcpyDeviceToHost, c->stream));
@@ -525,6 +545,12 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     for (int k = 0; k < ns_tot; k++) if (flags[k]) list.push_back(k);
     c->nstrips = (int)list.size();
     if (c->nstrips) HIPCHK(c, hipMemcpyAsync(c->d_strips, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, c->stream));
+    std::vector<int> list2;
+    if (c->use_double) {
+        for (int k = 0; k < ns_tot2; k++) if (flags2[k]) list2.push_back(k);
+        c->nstrips2 = (int)list2.size();
+        if (c->nstrips2) HIPCHK(c, hipMemcpyAsync(c->d_strips2, list2.data(), sizeof(int) * list2.size(), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->icellt = (long long)cnt[0];
     c->icellu = (long long)cnt[1];
@@ -542,27 +568,50 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     const bool wrap = (c->nranks == 1 && c->ew == EVPK_BND_CYCLIC && !c->force_exchange);
     const bool need_halo = (c->nranks > 1) || (c->ns == EVPK_BND_TRIPOLE) || c->force_exchange;
     c->kernel_ms = 0.f;
+    c->kernel2_ms = 0.f;
     c->kernel_launches = 0;
+    c->kev_is_double.assign((size_t)nsub + 1, 0);
     if (c->time_kernels) {
         while ((int)c->kev.size() < 2 * nsub) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int n = 0; n < nsub; n++) {
-        c->ksub++;
+    c->double_launches = 0;
+    for (int n = 0; n < nsub;) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.strips = c->d_strips; a.nstrips = c->nstrips; a.ncx = c->ncx; a.R = c->R; a.cur = c->cur; a.wrap = wrap ? 1 : 0;
-        const bool last = (c->ksub == c->p.ndte);
+        a.R = c->R; a.cur = c->cur;
         const bool revp = (c->p.revp == 1.0);
+        // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics)
+        if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte) {
+            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.wrap = (c->ew == EVPK_BND_CYCLIC) ? 1 : 0;
+            if (c->nstrips2 > 0) {
+                const dim3 g((((c->nstrips2 + 3) / 4 + 7) / 8) * 8), b(256);
+                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches], c->stream));
+                if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream, a);
+                else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream, a);
+                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches + 1], c->stream));
+                c->kev_is_double[c->kernel_launches] = 1;
+                c->kernel_launches++;
+                c->double_launches++;
+            }
+            c->ksub += 2;
+            n += 2;
+            c->cur ^= 1;
+            continue;
+        }
+        c->ksub++;
+        n++;
+        a.strips = c->d_strips; a.nstrips = c->nstrips; a.ncx = c->ncx; a.wrap = wrap ? 1 : 0;
+        const bool last = (c->ksub == c->p.ndte);
         if (c->nstrips > 0) {
             const dim3 g((((c->nstrips + 3) / 4 + 7) / 8) * 8), b(256);   // multiple of 8: see the XCD remap in k_subcycle
-            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * n], c->stream));
+            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches], c->stream));
             if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, c->stream, a);
             else if (last) hipLaunchKernelGGL((k_subcycle<true, false>), g, b, 0, c->stream, a);
             else if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, a);
             else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, a);
-            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * n + 1], c->stream));
+            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches + 1], c->stream));
             c->kernel_launches++;
         }
         c->cur ^= 1;
@@ -578,7 +627,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         for (int n = 0; n < c->kernel_launches; n++) {
             float ms = 0.f;
             HIPCHK(c, hipEventElapsedTime(&ms, c->kev[2 * n], c->kev[2 * n + 1]));
-            c->kernel_ms += ms;
+            if (c->kev_is_double[n]) c->kernel2_ms += ms; else c->kernel_ms += ms;
         }
     }
     return 0;
@@ -671,6 +720,8 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->ncell_slab = (int64_t)c->s.nxl * c->s.nyl;
     o->nstrips = c->nstrips; o->nstrips_total = c->ncx * c->nry;
     o->subcycles_done = c->ksub;
-    o->loop_ms = c->loop_ms; o->kernel_ms = c->kernel_ms; o->kernel_launches = c->kernel_launches;
+    o->loop_ms = c->loop_ms;
+    o->kernel_ms = c->kernel_ms; o->kernel_launches = c->kernel_launches - c->double_launches;
+    o->kernel2_ms = c->kernel2_ms; o->kernel2_launches = c->double_launches;
     return 0;
 }

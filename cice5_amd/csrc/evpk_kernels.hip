@@ -456,6 +456,7 @@ struct SubArgs {
 };
 
 __device__ __forceinline__ double shfl_dn1(double x) { return __shfl_down(x, 1); }
+__device__ __forceinline__ double shfl_up1(double x) { return __shfl_up(x, 1); }
 
 // pair-plane access with a wave-uniform row base (SGPR) and a 32-bit lane offset (VGPR):
 // rb = byte address of (row j, pair plane 0, column 0); pp = pitch in bytes of one pair plane.
@@ -467,6 +468,171 @@ __device__ __forceinline__ void stp(char *rb, size_t pp, int f_even, unsigned lo
 }
 __device__ __forceinline__ void st1(char *rb, size_t pp, int f, unsigned lo, double x) {
     *reinterpret_cast<double *>(rb + (size_t)(f >> 1) * pp + lo + (f & 1) * 8) = x;
+}
+
+struct TMet { double cxp, cyp, cxm, cym, dxt, dyt, dxhy, dyhx, tiny, strength; };
+struct Sig { double sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, s121, s122, s123, s124; };
+struct Str8 { double s1, s2, s3, s4, s5, s6, s7, s8; };
+struct Diag { double divu, rdg_conv, rdg_shear, shear, prs; };
+
+__device__ __forceinline__ TMet load_tmet(const char *rb, size_t pp, unsigned lo) {
+    const double2 cp = ldp(rb, pp, F_CXP, lo), cm = ldp(rb, pp, F_CXM, lo);
+    const double2 dd = ldp(rb, pp, F_DXT, lo), dh = ldp(rb, pp, F_DXHY, lo);
+    const double2 ts = ldp(rb, pp, F_TINYAREA, lo);
+    return TMet{cp.x, cp.y, cm.x, cm.y, dd.x, dd.y, dh.x, dh.y, ts.x, ts.y};
+}
+__device__ __forceinline__ Sig load_sig(const char *rb, size_t pp, int SB, unsigned lo) {
+    const double2 q0 = ldp(rb, pp, SB + S_SP, lo), q1 = ldp(rb, pp, SB + S_SP + 2, lo);
+    const double2 q2 = ldp(rb, pp, SB + S_SM, lo), q3 = ldp(rb, pp, SB + S_SM + 2, lo);
+    const double2 q4 = ldp(rb, pp, SB + S_S12, lo), q5 = ldp(rb, pp, SB + S_S12 + 2, lo);
+    return Sig{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y, q4.x, q4.y, q5.x, q5.y};
+}
+__device__ __forceinline__ void store_sig(char *rb, size_t pp, int SB, unsigned lo, const Sig &g) {
+    stp(rb, pp, SB + S_SP, lo, g.sp1, g.sp2);     stp(rb, pp, SB + S_SP + 2, lo, g.sp3, g.sp4);
+    stp(rb, pp, SB + S_SM, lo, g.sm1, g.sm2);     stp(rb, pp, SB + S_SM + 2, lo, g.sm3, g.sm4);
+    stp(rb, pp, SB + S_S12, lo, g.s121, g.s122);  stp(rb, pp, SB + S_S12 + 2, lo, g.s123, g.s124);
+}
+
+// ---- stress of one T cell (ice_dyn_evp.F90:618-847), the reference's operation order ----
+// u/v naming: _ij = (i,j), _mj = (i-1,j), _im = (i,j-1), _mm = (i-1,j-1).  g: sigma in -> sigma out.
+template <bool DIAG>
+__device__ __forceinline__ void stress_cell(const TMet &m, double u_ij, double u_mj, double u_im, double u_mm,
+                                            double v_ij, double v_mj, double v_im, double v_mm,
+                                            double ecci, double arlx1i, double denom1, double tarear,
+                                            Sig &g, Str8 &o, Diag &dg) {
+    const double p111 = 1.0 / 9.0, p055 = p111 * 0.5, p027 = p055 * 0.5;
+    const double p166 = 1.0 / 6.0, p222 = 2.0 / 9.0, p333 = 1.0 / 3.0;
+    const double cxp = m.cxp, cyp = m.cyp, cxm = m.cxm, cym = m.cym, dxt = m.dxt, dyt = m.dyt, dxhy = m.dxhy, dyhx = m.dyhx;
+
+    // strain rates * area (:627-654)
+    const double divune = cyp * u_ij - dyt * u_mj + cxp * v_ij - dxt * v_im;
+    const double divunw = cym * u_mj + dyt * u_ij + cxp * v_mj - dxt * v_mm;
+    const double divusw = cym * u_mm + dyt * u_im + cxm * v_mm + dxt * v_mj;
+    const double divuse = cyp * u_im - dyt * u_mm + cxm * v_im + dxt * v_ij;
+
+    const double tensionne = -cym * u_ij - dyt * u_mj + cxm * v_ij + dxt * v_im;
+    const double tensionnw = -cyp * u_mj + dyt * u_ij + cxm * v_mj + dxt * v_mm;
+    const double tensionsw = -cyp * u_mm + dyt * u_im + cxp * v_mm - dxt * v_mj;
+    const double tensionse = -cym * u_im - dyt * u_mm + cxp * v_im - dxt * v_ij;
+
+    const double shearne = -cym * v_ij - dyt * v_mj - cxm * u_ij - dxt * u_im;
+    const double shearnw = -cyp * v_mj + dyt * v_ij - cxm * u_mj - dxt * u_mm;
+    const double shearsw = -cyp * v_mm + dyt * v_im - cxp * u_mm + dxt * u_mj;
+    const double shearse = -cym * v_im - dyt * v_mm - cxp * u_im + dxt * u_ij;
+
+    // Delta (:657-660)
+    const double Deltane = sqrt(divune * divune + ecci * (tensionne * tensionne + shearne * shearne));
+    const double Deltanw = sqrt(divunw * divunw + ecci * (tensionnw * tensionnw + shearnw * shearnw));
+    const double Deltase = sqrt(divuse * divuse + ecci * (tensionse * tensionse + shearse * shearse));
+    const double Deltasw = sqrt(divusw * divusw + ecci * (tensionsw * tensionsw + shearsw * shearsw));
+
+    if (DIAG) {                                                                     // :665-677
+        dg.divu = 0.25 * (divune + divunw + divuse + divusw) * tarear;
+        const double tmp = 0.25 * (Deltane + Deltanw + Deltase + Deltasw) * tarear;
+        dg.rdg_conv = -fmin(dg.divu, 0.0);
+        dg.rdg_shear = 0.5 * (tmp - fabs(dg.divu));
+        const double tt = tensionne + tensionnw + tensionse + tensionsw;
+        const double ss = shearne + shearnw + shearse + shearsw;
+        dg.shear = 0.25 * tarear * sqrt(tt * tt + ss * ss);
+    }
+
+    // replacement pressure / Delta (:683-697)
+    double c0ne = m.strength / fmax(Deltane, m.tiny);
+    double c0nw = m.strength / fmax(Deltanw, m.tiny);
+    double c0sw = m.strength / fmax(Deltasw, m.tiny);
+    double c0se = m.strength / fmax(Deltase, m.tiny);
+    if (DIAG) dg.prs = c0ne * Deltane;
+    const double c1ne = c0ne * arlx1i, c1nw = c0nw * arlx1i, c1sw = c0sw * arlx1i, c1se = c0se * arlx1i;
+    c0ne = c1ne * ecci; c0nw = c1nw * ecci; c0sw = c1sw * ecci; c0se = c1se * ecci;
+
+    // the stresses (:704-721)
+    const double sp1 = (g.sp1 + c1ne * (divune - Deltane)) * denom1;
+    const double sp2 = (g.sp2 + c1nw * (divunw - Deltanw)) * denom1;
+    const double sp3 = (g.sp3 + c1sw * (divusw - Deltasw)) * denom1;
+    const double sp4 = (g.sp4 + c1se * (divuse - Deltase)) * denom1;
+    const double sm1 = (g.sm1 + c0ne * tensionne) * denom1;
+    const double sm2 = (g.sm2 + c0nw * tensionnw) * denom1;
+    const double sm3 = (g.sm3 + c0sw * tensionsw) * denom1;
+    const double sm4 = (g.sm4 + c0se * tensionse) * denom1;
+    const double s121 = (g.s121 + c0ne * shearne * 0.5) * denom1;
+    const double s122 = (g.s122 + c0nw * shearnw * 0.5) * denom1;
+    const double s123 = (g.s123 + c0sw * shearsw * 0.5) * denom1;
+    const double s124 = (g.s124 + c0se * shearse * 0.5) * denom1;
+    g = Sig{sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, s121, s122, s123, s124};
+
+    // combinations for the momentum equation (:752-795)
+    const double ssigpn = sp1 + sp2, ssigps = sp3 + sp4, ssigpe = sp1 + sp4, ssigpw = sp2 + sp3;
+    const double ssigp1 = (sp1 + sp3) * p055, ssigp2 = (sp2 + sp4) * p055;
+    const double ssigmn = sm1 + sm2, ssigms = sm3 + sm4, ssigme = sm1 + sm4, ssigmw = sm2 + sm3;
+    const double ssigm1 = (sm1 + sm3) * p055, ssigm2 = (sm2 + sm4) * p055;
+    const double ssig12n = s121 + s122, ssig12s = s123 + s124, ssig12e = s121 + s124, ssig12w = s122 + s123;
+    const double ssig121 = (s121 + s123) * p111, ssig122 = (s122 + s124) * p111;
+
+    const double csigpne = p111 * sp1 + ssigp2 + p027 * sp3;
+    const double csigpnw = p111 * sp2 + ssigp1 + p027 * sp4;
+    const double csigpsw = p111 * sp3 + ssigp2 + p027 * sp1;
+    const double csigpse = p111 * sp4 + ssigp1 + p027 * sp2;
+    const double csigmne = p111 * sm1 + ssigm2 + p027 * sm3;
+    const double csigmnw = p111 * sm2 + ssigm1 + p027 * sm4;
+    const double csigmsw = p111 * sm3 + ssigm2 + p027 * sm1;
+    const double csigmse = p111 * sm4 + ssigm1 + p027 * sm2;
+    const double csig12ne = p222 * s121 + ssig122 + p055 * s123;
+    const double csig12nw = p222 * s122 + ssig121 + p055 * s124;
+    const double csig12sw = p222 * s123 + ssig122 + p055 * s121;
+    const double csig12se = p222 * s124 + ssig121 + p055 * s122;
+
+    const double str12ew = 0.5 * dxt * (p333 * ssig12e + p166 * ssig12w);
+    const double str12we = 0.5 * dxt * (p333 * ssig12w + p166 * ssig12e);
+    const double str12ns = 0.5 * dyt * (p333 * ssig12n + p166 * ssig12s);
+    const double str12sn = 0.5 * dyt * (p333 * ssig12s + p166 * ssig12n);
+
+    // dF/dx (:800-820)
+    double strp_tmp = 0.25 * dyt * (p333 * ssigpn + p166 * ssigps);
+    double strm_tmp = 0.25 * dyt * (p333 * ssigmn + p166 * ssigms);
+    o.s1 = -strp_tmp - strm_tmp - str12ew + dxhy * (-csigpne + csigmne) + dyhx * csig12ne;
+    o.s2 = strp_tmp + strm_tmp - str12we + dxhy * (-csigpnw + csigmnw) + dyhx * csig12nw;
+    strp_tmp = 0.25 * dyt * (p333 * ssigps + p166 * ssigpn);
+    strm_tmp = 0.25 * dyt * (p333 * ssigms + p166 * ssigmn);
+    o.s3 = -strp_tmp - strm_tmp + str12ew + dxhy * (-csigpse + csigmse) + dyhx * csig12se;
+    o.s4 = strp_tmp + strm_tmp + str12we + dxhy * (-csigpsw + csigmsw) + dyhx * csig12sw;
+    // dF/dy (:825-845)
+    strp_tmp = 0.25 * dxt * (p333 * ssigpe + p166 * ssigpw);
+    strm_tmp = 0.25 * dxt * (p333 * ssigme + p166 * ssigmw);
+    o.s5 = -strp_tmp + strm_tmp - str12ns - dyhx * (csigpne + csigmne) + dxhy * csig12ne;
+    o.s6 = strp_tmp - strm_tmp - str12sn - dyhx * (csigpse + csigmse) + dxhy * csig12se;
+    strp_tmp = 0.25 * dxt * (p333 * ssigpw + p166 * ssigpe);
+    strm_tmp = 0.25 * dxt * (p333 * ssigmw + p166 * ssigme);
+    o.s7 = -strp_tmp + strm_tmp + str12ns - dyhx * (csigpnw + csigmnw) + dxhy * csig12nw;
+    o.s8 = strp_tmp - strm_tmp + str12sn - dyhx * (csigpsw + csigmsw) + dxhy * csig12sw;
+}
+
+// ---- stepu of one U cell (ice_dyn_shared.F90:700-746) ----
+// sx = (((str1(i,j) + str2(i+1,j)) + str3(i,j+1)) + str4(i+1,j+1)), sy likewise with str5,6,7,8 (:725-728)
+struct UStat { double vrelc, uarear, uocn, vocn, forcex, forcey, umassdti, fm; };
+__device__ __forceinline__ UStat load_ustat(const char *ru, size_t pp, unsigned lo) {
+    const double2 va = ldp(ru, pp, F_VRELC, lo), oc = ldp(ru, pp, F_UOCN, lo);
+    const double2 fo = ldp(ru, pp, F_FORCEX, lo), mf = ldp(ru, pp, F_UMASSDTI, lo);
+    return UStat{va.x, va.y, oc.x, oc.y, fo.x, fo.y, mf.x, mf.y};
+}
+__device__ __forceinline__ void stepu_cell(const UStat &q, double uold, double vold, double ui, double vi,
+                                           double sx, double sy, double brlx, double revp, double cosw, double sinw,
+                                           double &un, double &vn, double &strintx, double &strinty) {
+    // waterx/y of evp_prep2 (:592-593) recomputed instead of loaded: same expression, same bits
+    const double sgf = copysign(1.0, q.fm);
+    const double waterx = q.uocn * cosw - q.vocn * sinw * sgf;
+    const double watery = q.vocn * cosw + q.uocn * sinw * sgf;
+    const double du = q.uocn - uold, dv = q.vocn - vold;
+    const double vrel = q.vrelc * sqrt(du * du + dv * dv);                        // :708-709
+    const double taux = vrel * waterx, tauy = vrel * watery;                        // :711-712
+    const double cca = (brlx + revp) * q.umassdti + vrel * cosw;                    // :715
+    const double ccb = q.fm + sgf * vrel * sinw;                                    // :720
+    const double ab2 = cca * cca + ccb * ccb;
+    strintx = q.uarear * sx;                                                        // :725-728
+    strinty = q.uarear * sy;
+    const double cc1 = strintx + q.forcex + taux + q.umassdti * (brlx * uold + revp * ui);   // :731-734
+    const double cc2 = strinty + q.forcey + tauy + q.umassdti * (brlx * vold + revp * vi);
+    un = (cca * cc1 + ccb * cc2) / ab2;                                             // :736-737
+    vn = (cca * cc2 - ccb * cc1) / ab2;
 }
 
 template <bool LAST, bool REVP>
@@ -496,10 +662,6 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     const int SW = a.cur ? F_STATE0 : F_STATE1;       // write buffer
     char *const base = reinterpret_cast<char *>(s.F);
 
-    const double ecci = a.ecci, arlx1i = a.arlx1i, denom1 = a.denom1;
-    const double p111 = 1.0 / 9.0, p055 = p111 * 0.5, p027 = p055 * 0.5;
-    const double p166 = 1.0 / 6.0, p222 = 2.0 / 9.0, p333 = 1.0 / 3.0;
-
     // carried from the previous row (j-1)
     double u_im = 0.0, u_mm = 0.0, v_im = 0.0, v_mm = 0.0;
     if (colT) {
@@ -522,166 +684,43 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
             u_ij = a0.x; v_ij = a0.y; u_mj = a1.x; v_mj = a1.y;
         }
         const bool tact = (m & CM_T) != 0;
-        double str1 = 0.0, str2 = 0.0, str3 = 0.0, str4 = 0.0, str5 = 0.0, str6 = 0.0, str7 = 0.0, str8 = 0.0;
+        Str8 o{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         if (__any(tact)) {
             if (tact) {
-                const double2 cp = ldp(rb, pp, F_CXP, lo), cm = ldp(rb, pp, F_CXM, lo);
-                const double2 dd = ldp(rb, pp, F_DXT, lo), dh = ldp(rb, pp, F_DXHY, lo);
-                const double2 ts = ldp(rb, pp, F_TINYAREA, lo);
-                const double2 q0 = ldp(rb, pp, SR + S_SP, lo), q1 = ldp(rb, pp, SR + S_SP + 2, lo);
-                const double2 q2 = ldp(rb, pp, SR + S_SM, lo), q3 = ldp(rb, pp, SR + S_SM + 2, lo);
-                const double2 q4 = ldp(rb, pp, SR + S_S12, lo), q5 = ldp(rb, pp, SR + S_S12 + 2, lo);
-                const double cxp = cp.x, cyp = cp.y, cxm = cm.x, cym = cm.y;
-                const double dxt = dd.x, dyt = dd.y, dxhy = dh.x, dyhx = dh.y;
-                const double tiny = ts.x, strength = ts.y;
-                double sp1 = q0.x, sp2 = q0.y, sp3 = q1.x, sp4 = q1.y;
-                double sm1 = q2.x, sm2 = q2.y, sm3 = q3.x, sm4 = q3.y;
-                double s121 = q4.x, s122 = q4.y, s123 = q5.x, s124 = q5.y;
-
-                // strain rates * area (ice_dyn_evp.F90:627-654)
-                const double divune = cyp * u_ij - dyt * u_mj + cxp * v_ij - dxt * v_im;
-                const double divunw = cym * u_mj + dyt * u_ij + cxp * v_mj - dxt * v_mm;
-                const double divusw = cym * u_mm + dyt * u_im + cxm * v_mm + dxt * v_mj;
-                const double divuse = cyp * u_im - dyt * u_mm + cxm * v_im + dxt * v_ij;
-
-                const double tensionne = -cym * u_ij - dyt * u_mj + cxm * v_ij + dxt * v_im;
-                const double tensionnw = -cyp * u_mj + dyt * u_ij + cxm * v_mj + dxt * v_mm;
-                const double tensionsw = -cyp * u_mm + dyt * u_im + cxp * v_mm - dxt * v_mj;
-                const double tensionse = -cym * u_im - dyt * u_mm + cxp * v_im - dxt * v_ij;
-
-                const double shearne = -cym * v_ij - dyt * v_mj - cxm * u_ij - dxt * u_im;
-                const double shearnw = -cyp * v_mj + dyt * v_ij - cxm * u_mj - dxt * u_mm;
-                const double shearsw = -cyp * v_mm + dyt * v_im - cxp * u_mm + dxt * u_mj;
-                const double shearse = -cym * v_im - dyt * v_mm - cxp * u_im + dxt * u_ij;
-
-                // Delta (:657-660)
-                const double Deltane = sqrt(divune * divune + ecci * (tensionne * tensionne + shearne * shearne));
-                const double Deltanw = sqrt(divunw * divunw + ecci * (tensionnw * tensionnw + shearnw * shearnw));
-                const double Deltase = sqrt(divuse * divuse + ecci * (tensionse * tensionse + shearse * shearse));
-                const double Deltasw = sqrt(divusw * divusw + ecci * (tensionsw * tensionsw + shearsw * shearsw));
-
+                const TMet mt = load_tmet(rb, pp, lo);
+                Sig g = load_sig(rb, pp, SR, lo);
                 const bool store = ownT && (jj < R);
-                if (LAST) {                                                         // :665-677
-                    if (store) {
-                        const double tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
-                        const double divu = 0.25 * (divune + divunw + divuse + divusw) * tarear;
-                        const double tmp = 0.25 * (Deltane + Deltanw + Deltase + Deltasw) * tarear;
-                        st1(rb, pp, F_DIVU, lo, divu);
-                        st1(rb, pp, F_RDGCONV, lo, -fmin(divu, 0.0));
-                        st1(rb, pp, F_RDGSHEAR, lo, 0.5 * (tmp - fabs(divu)));
-                        const double tt = tensionne + tensionnw + tensionse + tensionsw;
-                        const double ss = shearne + shearnw + shearse + shearsw;
-                        st1(rb, pp, F_SHEAR, lo, 0.25 * tarear * sqrt(tt * tt + ss * ss));
+                double tarear = 0.0;
+                if (LAST) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
+                Diag dg;
+                stress_cell<LAST>(mt, u_ij, u_mj, u_im, u_mm, v_ij, v_mj, v_im, v_mm, a.ecci, a.arlx1i, a.denom1, tarear, g, o, dg);
+                if (store) {
+                    store_sig(rb, pp, SW, lo, g);
+                    if (LAST) {
+                        st1(rb, pp, F_DIVU, lo, dg.divu);       st1(rb, pp, F_RDGCONV, lo, dg.rdg_conv);
+                        st1(rb, pp, F_RDGSHEAR, lo, dg.rdg_shear); st1(rb, pp, F_SHEAR, lo, dg.shear);
+                        st1(rb, pp, F_PRSSIG, lo, dg.prs);
                     }
                 }
-
-                // replacement pressure / Delta (:683-697)
-                double c0ne = strength / fmax(Deltane, tiny);
-                double c0nw = strength / fmax(Deltanw, tiny);
-                double c0sw = strength / fmax(Deltasw, tiny);
-                double c0se = strength / fmax(Deltase, tiny);
-                if (LAST) { if (store) st1(rb, pp, F_PRSSIG, lo, c0ne * Deltane); }
-                const double c1ne = c0ne * arlx1i, c1nw = c0nw * arlx1i, c1sw = c0sw * arlx1i, c1se = c0se * arlx1i;
-                c0ne = c1ne * ecci; c0nw = c1nw * ecci; c0sw = c1sw * ecci; c0se = c1se * ecci;
-
-                // the stresses (:704-721)
-                sp1 = (sp1 + c1ne * (divune - Deltane)) * denom1;
-                sp2 = (sp2 + c1nw * (divunw - Deltanw)) * denom1;
-                sp3 = (sp3 + c1sw * (divusw - Deltasw)) * denom1;
-                sp4 = (sp4 + c1se * (divuse - Deltase)) * denom1;
-                sm1 = (sm1 + c0ne * tensionne) * denom1;
-                sm2 = (sm2 + c0nw * tensionnw) * denom1;
-                sm3 = (sm3 + c0sw * tensionsw) * denom1;
-                sm4 = (sm4 + c0se * tensionse) * denom1;
-                s121 = (s121 + c0ne * shearne * 0.5) * denom1;
-                s122 = (s122 + c0nw * shearnw * 0.5) * denom1;
-                s123 = (s123 + c0sw * shearsw * 0.5) * denom1;
-                s124 = (s124 + c0se * shearse * 0.5) * denom1;
-
-                if (store) {
-                    stp(rb, pp, SW + S_SP, lo, sp1, sp2);    stp(rb, pp, SW + S_SP + 2, lo, sp3, sp4);
-                    stp(rb, pp, SW + S_SM, lo, sm1, sm2);    stp(rb, pp, SW + S_SM + 2, lo, sm3, sm4);
-                    stp(rb, pp, SW + S_S12, lo, s121, s122); stp(rb, pp, SW + S_S12 + 2, lo, s123, s124);
-                }
-
-                // combinations for the momentum equation (:752-795)
-                const double ssigpn = sp1 + sp2, ssigps = sp3 + sp4, ssigpe = sp1 + sp4, ssigpw = sp2 + sp3;
-                const double ssigp1 = (sp1 + sp3) * p055, ssigp2 = (sp2 + sp4) * p055;
-                const double ssigmn = sm1 + sm2, ssigms = sm3 + sm4, ssigme = sm1 + sm4, ssigmw = sm2 + sm3;
-                const double ssigm1 = (sm1 + sm3) * p055, ssigm2 = (sm2 + sm4) * p055;
-                const double ssig12n = s121 + s122, ssig12s = s123 + s124, ssig12e = s121 + s124, ssig12w = s122 + s123;
-                const double ssig121 = (s121 + s123) * p111, ssig122 = (s122 + s124) * p111;
-
-                const double csigpne = p111 * sp1 + ssigp2 + p027 * sp3;
-                const double csigpnw = p111 * sp2 + ssigp1 + p027 * sp4;
-                const double csigpsw = p111 * sp3 + ssigp2 + p027 * sp1;
-                const double csigpse = p111 * sp4 + ssigp1 + p027 * sp2;
-                const double csigmne = p111 * sm1 + ssigm2 + p027 * sm3;
-                const double csigmnw = p111 * sm2 + ssigm1 + p027 * sm4;
-                const double csigmsw = p111 * sm3 + ssigm2 + p027 * sm1;
-                const double csigmse = p111 * sm4 + ssigm1 + p027 * sm2;
-                const double csig12ne = p222 * s121 + ssig122 + p055 * s123;
-                const double csig12nw = p222 * s122 + ssig121 + p055 * s124;
-                const double csig12sw = p222 * s123 + ssig122 + p055 * s121;
-                const double csig12se = p222 * s124 + ssig121 + p055 * s122;
-
-                const double str12ew = 0.5 * dxt * (p333 * ssig12e + p166 * ssig12w);
-                const double str12we = 0.5 * dxt * (p333 * ssig12w + p166 * ssig12e);
-                const double str12ns = 0.5 * dyt * (p333 * ssig12n + p166 * ssig12s);
-                const double str12sn = 0.5 * dyt * (p333 * ssig12s + p166 * ssig12n);
-
-                // dF/dx (:800-820)
-                double strp_tmp = 0.25 * dyt * (p333 * ssigpn + p166 * ssigps);
-                double strm_tmp = 0.25 * dyt * (p333 * ssigmn + p166 * ssigms);
-                str1 = -strp_tmp - strm_tmp - str12ew + dxhy * (-csigpne + csigmne) + dyhx * csig12ne;
-                str2 = strp_tmp + strm_tmp - str12we + dxhy * (-csigpnw + csigmnw) + dyhx * csig12nw;
-                strp_tmp = 0.25 * dyt * (p333 * ssigps + p166 * ssigpn);
-                strm_tmp = 0.25 * dyt * (p333 * ssigms + p166 * ssigmn);
-                str3 = -strp_tmp - strm_tmp + str12ew + dxhy * (-csigpse + csigmse) + dyhx * csig12se;
-                str4 = strp_tmp + strm_tmp + str12we + dxhy * (-csigpsw + csigmsw) + dyhx * csig12sw;
-                // dF/dy (:825-845)
-                strp_tmp = 0.25 * dxt * (p333 * ssigpe + p166 * ssigpw);
-                strm_tmp = 0.25 * dxt * (p333 * ssigme + p166 * ssigmw);
-                str5 = -strp_tmp + strm_tmp - str12ns - dyhx * (csigpne + csigmne) + dxhy * csig12ne;
-                str6 = strp_tmp - strm_tmp - str12sn - dyhx * (csigpse + csigmse) + dxhy * csig12se;
-                strp_tmp = 0.25 * dxt * (p333 * ssigpw + p166 * ssigpe);
-                strm_tmp = 0.25 * dxt * (p333 * ssigmw + p166 * ssigme);
-                str7 = -strp_tmp + strm_tmp + str12ns - dyhx * (csigpnw + csigmnw) + dxhy * csig12nw;
-                str8 = strp_tmp - strm_tmp + str12sn - dyhx * (csigpsw + csigmsw) + dxhy * csig12sw;
             }
         }
 
         // east neighbour's contributions of this T row
-        const double s2n = shfl_dn1(str2), s4n = shfl_dn1(str4), s7n = shfl_dn1(str7), s8n = shfl_dn1(str8);
+        const double s2n = shfl_dn1(o.s2), s4n = shfl_dn1(o.s4), s7n = shfl_dn1(o.s7), s8n = shfl_dn1(o.s8);
 
-        // stepu for U(i, j-1)  (ice_dyn_shared.F90:700-746)
+        // stepu for U(i, j-1)
         if (jj >= 1) {
             const bool uact = colU && ((mprev & CM_U) != 0);
             if (__any(uact)) {
                 if (uact) {
                     char *const ru = rb - rowb;
-                    const double uold = u_im, vold = v_im;
-                    const double2 va = ldp(ru, pp, F_VRELC, lo), oc = ldp(ru, pp, F_UOCN, lo);
-                    const double2 wa = ldp(ru, pp, F_WATERX, lo), fo = ldp(ru, pp, F_FORCEX, lo);
-                    const double2 mf = ldp(ru, pp, F_UMASSDTI, lo);
-                    const double vrelc = va.x, uarear = va.y, uocn = oc.x, vocn = oc.y;
-                    const double waterx = wa.x, watery = wa.y, forcex = fo.x, forcey = fo.y;
-                    const double umassdti = mf.x, fm = mf.y;
-                    const double du = uocn - uold, dv = vocn - vold;
-                    const double vrel = vrelc * sqrt(du * du + dv * dv);            // :708-709
-                    const double taux = vrel * waterx, tauy = vrel * watery;        // :711-712
-                    const double cca = (a.brlx + a.revp) * umassdti + vrel * a.cosw;   // :715
-                    const double ccb = fm + copysign(1.0, fm) * vrel * a.sinw;      // :720
-                    const double ab2 = cca * cca + ccb * ccb;
-                    const double strintx = uarear * (((s1c + s2r) + str3) + s4n);   // :725-728
-                    const double strinty = uarear * (((s5c + str6) + s7r) + s8n);
+                    const UStat q = load_ustat(ru, pp, lo);
                     double ui = 0.0, vi = 0.0;
                     if (REVP) { const double2 iv = ldp(ru, pp, F_UVEL_INIT, lo); ui = iv.x; vi = iv.y; }
-                    const double cc1 = strintx + forcex + taux + umassdti * (a.brlx * uold + a.revp * ui);   // :731-734
-                    const double cc2 = strinty + forcey + tauy + umassdti * (a.brlx * vold + a.revp * vi);
-                    const double un = (cca * cc1 + ccb * cc2) / ab2;                // :736-737
-                    const double vn = (cca * cc2 - ccb * cc1) / ab2;
+                    double un, vn, strintx, strinty;
+                    stepu_cell(q, u_im, v_im, ui, vi, ((s1c + s2r) + o.s3) + s4n, ((s5c + o.s6) + s7r) + s8n,
+                               a.brlx, a.revp, a.cosw, a.sinw, un, vn, strintx, strinty);
                     stp(ru, pp, SW + S_U, lo, un, vn);
                     if (a.wrap) {   // single-rank cyclic E-W: the owner also writes the ghost image
                         if (i == 1) stp(ru, pp, SW + S_U, lo + (unsigned)s.nxl * 16u, un, vn);
@@ -695,7 +734,7 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
             }
         }
         // carry
-        s1c = str1; s5c = str5; s2r = s2n; s7r = s7n;
+        s1c = o.s1; s5c = o.s5; s2r = s2n; s7r = s7n;
         u_im = u_ij; u_mm = u_mj; v_im = v_ij; v_mm = v_mj;
         mprev = m;
     }
@@ -705,6 +744,198 @@ template __global__ void k_subcycle<false, false>(SubArgs);
 template __global__ void k_subcycle<true, false>(SubArgs);
 template __global__ void k_subcycle<false, true>(SubArgs);
 template __global__ void k_subcycle<true, true>(SubArgs);
+
+// ------------------------------------------------------------------------------------
+// TWO subcycles per launch (temporal blocking): sigma, the grid metrics and the stepu input planes
+// cross HBM once per two subcycles.  Single rank, no tripole fold (the fold needs the mirrored
+// columns between the two subcycles).  One wave = 61 U columns x R U rows of the SECOND subcycle:
+//   stage 1  T1(c,r) on 64 lanes, U1(c,r-1) on lanes 0..62      (first subcycle, kept in registers)
+//   stage 2  T2(c,r-1) on lanes 1..62, U2(c,r-2) on lanes 1..61 (second subcycle, stored)
+// marching north with the second stage two rows behind the first.  Columns wrap (cyclic E-W) or fall
+// outside the domain where every cell is inactive and u = 0 (open / closed E-W).
+// ------------------------------------------------------------------------------------
+constexpr int STRIP2_W = 61;
+
+template <bool REVP>
+__global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
+    const Slab &s = a.s;
+    const int lane = threadIdx.x & 63;
+    const int chunk = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
+    if (sid >= a.nstrips) return;
+    const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
+    const int cx = st % a.ncx, ry = st / a.ncx;
+    const int R = a.R, nxl = s.nxl, nyl = s.nyl;
+    const int c = cx * STRIP2_W + lane;               // unwrapped column of this lane (lane 1 = first owned column)
+    const int jb = ry * R + 1;
+    const bool cyc = a.wrap != 0;
+
+    // storage columns of (c) and (c-1); outside a non-cyclic domain the lane is dead for that access
+    int ci = c, cm1 = c - 1;
+    bool okc, okm;
+    if (cyc) {
+        ci = (c - 1) % nxl; if (ci < 0) ci += nxl; ci += 1;
+        cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
+        okc = okm = true;
+    } else {
+        okc = (c >= 0 && c <= nxl + 1);
+        okm = (cm1 >= 0 && cm1 <= nxl + 1);
+        if (!okc) ci = 0;
+        if (!okm) cm1 = 0;
+    }
+    const bool tcol = cyc ? true : (c >= 1 && c <= nxl + 1);       // column can hold an active T cell
+    const bool ucol = cyc ? true : (c >= 1 && c <= nxl);           // ... an active U cell
+    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 && c <= nxl);   // columns this lane stores
+
+    const size_t pp = (size_t)s.pitch * 16;
+    const size_t rowb = (size_t)s.rstride * 16;
+    const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
+    const int SR = a.cur ? F_STATE1 : F_STATE0;
+    const int SW = a.cur ? F_STATE0 : F_STATE1;
+    char *const base = reinterpret_cast<char *>(s.F);
+
+    // ---- carried state ----
+    // first subcycle
+    double uo_c = 0.0, vo_c = 0.0, uo_m = 0.0, vo_m = 0.0;        // u_old at (c, r-1), (c-1, r-1)
+    double a1c = 0.0, a5c = 0.0, a2r = 0.0, a7r = 0.0;            // str terms of T1(r-1)
+    Sig g1p{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                  // sigma after subcycle 1 at row r-1
+    TMet mtp{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                       // metrics of row r-1
+    unsigned char mp = 0, mpp = 0;                                // cmask of rows r-1, r-2
+    // second subcycle
+    double u1p_c = 0.0, v1p_c = 0.0, u1p_m = 0.0, v1p_m = 0.0;    // u after subcycle 1 at (c, r-2), (c-1, r-2)
+    double b1c = 0.0, b5c = 0.0, b2r = 0.0, b7r = 0.0;            // str terms of T2(r-2)
+    UStat qp{0, 0, 0, 0, 0, 0, 0, 0};                             // stepu inputs of row r-2
+    double uip = 0.0, vip = 0.0;
+
+    {   // u_old of the row below the first T1 row
+        const int r0 = jb - 2;
+        if (r0 >= 0) {
+            const char *rb0 = base + (size_t)r0 * rowb;
+            if (okc) { const double2 t = ldp(rb0, pp, SR + S_U, lo); uo_c = t.x; vo_c = t.y; }
+            if (okm) { const double2 t = ldp(rb0, pp, SR + S_U, lom); uo_m = t.x; vo_m = t.y; }
+        }
+    }
+
+    for (int t = 0; t <= R + 2; t++) {
+        const int r = jb - 1 + t;                     // row of T1 in this step
+        if (r > nyl + 2) break;
+        const bool rowok = (r >= 0 && r <= nyl + 1);  // row exists in storage
+        char *const rb = base + (size_t)(rowok ? r : 0) * rowb;
+
+        // ---------------- stage 1: T1(r) ----------------
+        unsigned char m = 0;
+        double un_c = 0.0, vn_c = 0.0, un_m = 0.0, vn_m = 0.0;    // u_old at (c, r), (c-1, r)
+        if (rowok) {
+            if (okc) {
+                m = s.cmask[(size_t)r * s.pitch + C0 + ci];
+                const double2 q = ldp(rb, pp, SR + S_U, lo); un_c = q.x; vn_c = q.y;
+            }
+            if (okm) { const double2 q = ldp(rb, pp, SR + S_U, lom); un_m = q.x; vn_m = q.y; }
+        }
+        const bool t1act = tcol && (m & CM_T) != 0;
+        Str8 o1{0, 0, 0, 0, 0, 0, 0, 0};
+        Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (__any(t1act)) {
+            if (t1act) {
+                mt = load_tmet(rb, pp, lo);
+                g1 = load_sig(rb, pp, SR, lo);
+                Diag dg;
+                stress_cell<false>(mt, un_c, un_m, uo_c, uo_m, vn_c, vn_m, vo_c, vo_m, a.ecci, a.arlx1i, a.denom1, 0.0, g1, o1, dg);
+            }
+        }
+        const double a2n = shfl_dn1(o1.s2), a4n = shfl_dn1(o1.s4), a7n = shfl_dn1(o1.s7), a8n = shfl_dn1(o1.s8);
+
+        // ---------------- stage 1: U1(r-1) ----------------
+        // velocity after the first subcycle; an inactive cell keeps its value
+        double u1_c = uo_c, v1_c = vo_c;
+        UStat q1{0, 0, 0, 0, 0, 0, 0, 0};
+        double ui1 = 0.0, vi1 = 0.0;
+        const bool u1act = (t >= 1) && ucol && (mp & CM_U) != 0 && (r - 1 >= 1) && (r - 1 <= nyl);
+        if (__any(u1act)) {
+            if (u1act) {
+                const char *ru = base + (size_t)(r - 1) * rowb;
+                q1 = load_ustat(ru, pp, lo);
+                if (REVP) { const double2 iv = ldp(ru, pp, F_UVEL_INIT, lo); ui1 = iv.x; vi1 = iv.y; }
+                double sxi, syi;
+                stepu_cell(q1, uo_c, vo_c, ui1, vi1, ((a1c + a2r) + o1.s3) + a4n, ((a5c + o1.s6) + a7r) + a8n,
+                           a.brlx, a.revp, a.cosw, a.sinw, u1_c, v1_c, sxi, syi);
+            }
+        }
+        const double u1_m = shfl_up1(u1_c), v1_m = shfl_up1(v1_c);      // (c-1, r-1); lane 0 is not used below
+
+        // ---------------- stage 2: T2(r-1) ----------------
+        const int q2 = r - 1;
+        const bool t2act = (t >= 2) && tcol && (mp & CM_T) != 0 && lane >= 1;
+        Str8 o2{0, 0, 0, 0, 0, 0, 0, 0};
+        if (__any(t2act)) {
+            if (t2act) {
+                Sig g2 = g1p;
+                Diag dg;
+                stress_cell<false>(mtp, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, 0.0, g2, o2, dg);
+                if (own && q2 >= jb && q2 < jb + R) {
+                    char *const rq = base + (size_t)q2 * rowb;
+                    store_sig(rq, pp, SW, lo, g2);
+                    if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);     // east ghost T column = image of column 1
+                }
+            }
+        }
+        const double b2n = shfl_dn1(o2.s2), b4n = shfl_dn1(o2.s4), b7n = shfl_dn1(o2.s7), b8n = shfl_dn1(o2.s8);
+
+        // ---------------- stage 2: U2(r-2) ----------------
+        const int q3 = r - 2;
+        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl;
+        if (__any(u2act)) {
+            if (u2act) {
+                double un, vn, sxi, syi;
+                stepu_cell(qp, u1p_c, v1p_c, uip, vip, ((b1c + b2r) + o2.s3) + b4n, ((b5c + o2.s6) + b7r) + b8n,
+                           a.brlx, a.revp, a.cosw, a.sinw, un, vn, sxi, syi);
+                char *const ru = base + (size_t)q3 * rowb;
+                stp(ru, pp, SW + S_U, lo, un, vn);
+                if (cyc) {
+                    if (c == 1) stp(ru, pp, SW + S_U, lo + (unsigned)nxl * 16u, un, vn);
+                    if (c == nxl) stp(ru, pp, SW + S_U, lo - (unsigned)nxl * 16u, un, vn);
+                }
+            }
+        }
+
+        // ---------------- rotate ----------------
+        b1c = o2.s1; b5c = o2.s5; b2r = b2n; b7r = b7n;
+        u1p_c = u1_c; v1p_c = v1_c; u1p_m = u1_m; v1p_m = v1_m;
+        qp = q1; uip = ui1; vip = vi1;
+        a1c = o1.s1; a5c = o1.s5; a2r = a2n; a7r = a7n;
+        g1p = g1; mtp = mt;
+        uo_c = un_c; vo_c = vn_c; uo_m = un_m; vo_m = vn_m;
+        mpp = mp; mp = m;
+    }
+}
+
+template __global__ void k_subcycle2<false>(SubArgs);
+template __global__ void k_subcycle2<true>(SubArgs);
+
+// strip activity for k_subcycle2: any active T / U cell in the window the strip touches
+// (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
+__global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, unsigned char *flags) {
+    const int sid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (sid >= ncx * nry) return;
+    const int cx = sid % ncx, ry = sid / ncx;
+    const int c = cx * STRIP2_W + lane;
+    int ci = c;
+    bool ok;
+    if (cyc) { ci = (c - 1) % s.nxl; if (ci < 0) ci += s.nxl; ci += 1; ok = true; }
+    else ok = (c >= 1 && c <= s.nxl + 1);
+    const int jb = ry * R + 1;
+    int any = 0;
+    if (ok)
+        for (int r = jb - 1; r <= jb + R + 1; r++) {
+            if (r < 1 || r > s.nyl + 1) continue;
+            if (s.cmask[mcell(s, ci, r)]) any = 1;
+        }
+    const unsigned long long b = __ballot(any);
+    if (lane == 0) flags[sid] = b ? 1 : 0;
+}
 
 // ------------------------------------------------------------------------------------
 // evp_finish (ice_dyn_shared.F90:757-844)

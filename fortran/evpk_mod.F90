@@ -68,6 +68,8 @@
          integer (c_int32_t) :: nstrips, nstrips_total, subcycles_done
          real (c_float) :: loop_ms, kernel_ms
          integer (c_int32_t) :: kernel_launches
+         real (c_float) :: kernel2_ms
+         integer (c_int32_t) :: kernel2_launches
       end type evpk_stats
 
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &

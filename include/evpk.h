@@ -115,8 +115,10 @@ typedef struct {
     int32_t nstrips_total;
     int32_t subcycles_done;  /* since the last evpk_prep */
     float loop_ms;           /* HIP-event time of the last evpk_subcycle call on the compute stream */
-    float kernel_ms;         /* HIP-event time summed over the stress+stepu kernel launches of that call */
-    int32_t kernel_launches;
+    float kernel_ms;         /* HIP-event time summed over the one-subcycle kernel launches (k_subcycle) of that call */
+    int32_t kernel_launches; /* ... and their number */
+    float kernel2_ms;        /* the same for the two-subcycle kernel (k_subcycle2) */
+    int32_t kernel2_launches;
 } evpk_stats;
 
 /* rank 0 creates the RCCL id; the host model broadcasts the bytes (MPI_Bcast in CICE,

@@ -149,6 +149,30 @@ def test_forced_exchange_path(ns, monkeypatch):
     _both(100, 116, 25, 29, ns=ns, land="continents", ndte=30)
 
 
+def test_two_subcycle_kernel_equals_single(monkeypatch):
+    """k_subcycle2 (two subcycles per launch) vs k_subcycle only: bit-identical, including odd ndte,
+    subcycles issued in odd pieces, revised EVP, and a non-cyclic E-W boundary."""
+    for kw, ndte, pieces in [(dict(land="continents"), 31, [31]), (dict(land="continents"), 40, [7, 12, 21]),
+                             (dict(ice="full"), 24, [24])]:
+        case, d, f = util.make_case(130, 96, 130, 96, **kw)
+        xmin = synth.global_min_dx(case)
+        outs = []
+        for dbl in ("0", "1"):
+            monkeypatch.setenv("EVPK_DOUBLE", dbl)
+            g = util.clone(f)
+            s = dyn.EvpDynamics(d, g, ndte=ndte, xmin=xmin, revised_evp=(ndte == 24))
+            s.init_evp(3600.0)
+            s.ctx.upload(g); s.ctx.prep()
+            for n in pieces:
+                s.ctx.subcycle(n)
+            st = s.ctx.stats()
+            assert (st.kernel2_launches > 0) == (dbl == "1")
+            s.ctx.finish(); s.ctx.download(g)
+            s.close()
+            outs.append(g)
+        assert not util.compare(d, outs[1], outs[0])
+
+
 def test_staged_api_equals_run():
     """upload/prep/subcycle/finish/download == evpk_run; subcycles may be issued in pieces."""
     case, d, f = util.make_case(100, 116, 25, 29, land="continents")
