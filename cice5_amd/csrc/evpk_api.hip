@@ -499,11 +499,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
     const dim3 g2 = grid2d(s, B2D);
-    if (c->cur) {   // a previous loop left the state in buffer 1 (odd number of subcycles): prep works on buffer 0
-        for (int q = 0; q < NSTATE; q++)
-            hipLaunchKernelGGL(k_copy_plane, g2, B2D, 0, c->stream, s, (int)(F_STATE1 + q), (int)(F_STATE0 + q));
-        c->cur = 0;
-    }
+    const int SA = c->cur ? F_STATE1 : F_STATE0, SB = c->cur ? F_STATE0 : F_STATE1;   // current / other state buffer
     // evp_prep1 + zero diagnostics (ice_dyn_evp.F90:171-203)
     const int fresh = c->fresh ? 1 : 0;
     hipLaunchKernelGGL(k_prep1a, g2, B2D, 0, c->stream, s, c->p, fresh);
@@ -513,14 +509,14 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     if (!c->p.wind_on_ugrid && halo(c, F_WORK1, 2, false, true, 0.0)) return 1;
     hipLaunchKernelGGL(k_to_ugrid4, g2, B2D, 0, c->stream, s, c->p.wind_on_ugrid ? 0 : 1);
     // evp_prep2 (:247-308); strength is an input (ice_strength, :291-301)
-    hipLaunchKernelGGL(k_prep2, g2, B2D, 0, c->stream, s, c->p, fresh);
+    hipLaunchKernelGGL(k_prep2, g2, B2D, 0, c->stream, s, c->p, fresh, c->cur);
     if (halo(c, F_STRENGTH, 1, false, false, 0.0)) return 1;                      // :311-312
-    if (halo(c, F_STATE0 + S_U, 2, true, true, 0.0)) return 1;                    // :314-315
+    if (halo(c, SA + S_U, 2, true, true, 0.0)) return 1;                          // :314-315
     {   // the top physical row may have been rewritten by a tripole fold, the ring by the halo: mirror into buffer 1
         const int nring = 2 * (s.nxl + 2) + 2 * (s.nyl + 2);
-        hipLaunchKernelGGL(k_ring_copy, dim3((nring + 127) / 128), dim3(128), 0, c->stream, s, (int)(F_STATE0 + S_U), (int)(F_STATE1 + S_U), 2);
+        hipLaunchKernelGGL(k_ring_copy, dim3((nring + 127) / 128), dim3(128), 0, c->stream, s, SA + S_U, SB + S_U, 2);
         if (c->ns == EVPK_BND_TRIPOLE)
-            hipLaunchKernelGGL(k_row_copy, dim3((s.nxl + 2 + 127) / 128), dim3(128), 0, c->stream, s, (int)(F_STATE0 + S_U), (int)(F_STATE1 + S_U), 2, s.nyl);
+            hipLaunchKernelGGL(k_row_copy, dim3((s.nxl + 2 + 127) / 128), dim3(128), 0, c->stream, s, SA + S_U, SB + S_U, 2, s.nyl);
     }
     c->fresh = false;
     // active strips

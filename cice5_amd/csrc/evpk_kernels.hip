@@ -245,26 +245,28 @@ __global__ void k_copy_plane(Slab s, int fsrc, int fdst) {
 }
 
 // ------------------------------------------------------------------------------------
-// evp_prep2 (ice_dyn_shared.F90:377-614) on the slab.  State lives in buffer 0 on entry; both
+// evp_prep2 (ice_dyn_shared.F90:377-614) on the slab.  State lives in buffer `cur` on entry; both
 // buffers are left identical (the velocity ring is completed by the halo update + ring copy that
 // follow in evpk_prep).  Invariant kept for the subcycle kernel, which never touches inactive
 // cells: sigma = 0 in both buffers where icetmask == 0, u = v = 0 in both where iceumask is false,
 // and the stepu input planes are 0 where iceumask is false.  Unless `fresh`, a cell that was
 // inactive at the previous prep already satisfies this and is skipped.
 // ------------------------------------------------------------------------------------
-__global__ void k_prep2(Slab s, DevParams p, int fresh) {
+__global__ void k_prep2(Slab s, DevParams p, int fresh, int cur) {
     SLAB_IJ_ALL
+    const int SA = cur ? F_STATE1 : F_STATE0;      // buffer holding the current state
+    const int SB = cur ? F_STATE0 : F_STATE1;      // the other one, made identical here
     const bool icet = FD(s, F_ICETM, k) == 1.0;          // after its halo update
     const unsigned char cmold = s.cmask[km];
     const bool prevT = fresh || (cmold & CM_T), prevU = fresh || (cmold & CM_U);
     if (p.revp == 1.0 || !icet) {                                                  // :492-518
         if (icet || prevT) {
 #pragma unroll
-            for (int c = S_SP; c < NSTATE; c++) { FD(s, F_STATE0 + c, k) = 0.0; FD(s, F_STATE1 + c, k) = 0.0; }
+            for (int c = S_SP; c < NSTATE; c++) { FD(s, SA + c, k) = 0.0; FD(s, SB + c, k) = 0.0; }
         }
     } else {
 #pragma unroll
-        for (int c = S_SP; c < NSTATE; c++) FD(s, F_STATE1 + c, k) = FD(s, F_STATE0 + c, k);
+        for (int c = S_SP; c < NSTATE; c++) FD(s, SB + c, k) = FD(s, SA + c, k);
     }
     unsigned char cm = icet ? CM_T : 0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {                            // :545-577
@@ -274,11 +276,11 @@ __global__ void k_prep2(Slab s, DevParams p, int fresh) {
         s.iceumask[km] = ium ? 1 : 0;
         if (ium) {
             const double uocn = FD(s, F_UOCN, k), vocn = FD(s, F_VOCN, k);
-            double u = FD(s, F_STATE0 + S_U, k), v = FD(s, F_STATE0 + S_V, k);
+            double u = FD(s, SA + S_U, k), v = FD(s, SA + S_V, k);
             if (!old) { u = uocn; v = vocn; }
             cm |= CM_U;
-            FD(s, F_STATE0 + S_U, k) = u; FD(s, F_STATE0 + S_V, k) = v;
-            FD(s, F_STATE1 + S_U, k) = u; FD(s, F_STATE1 + S_V, k) = v;
+            FD(s, SA + S_U, k) = u; FD(s, SA + S_V, k) = v;
+            FD(s, SB + S_U, k) = u; FD(s, SB + S_V, k) = v;
             FD(s, F_UVEL_INIT, k) = u;    FD(s, F_VVEL_INIT, k) = v;
             const double umdti = umass / p.dt;                                     // :583-612
             const double fm = FD(s, F_FCOR, k) * umass;
@@ -303,8 +305,8 @@ __global__ void k_prep2(Slab s, DevParams p, int fresh) {
             // stepu: vrel = aiu*rhow*Cw*sqrt(..) evaluates (aiu*rhow)*Cw first (ice_dyn_shared.F90:708)
             FD(s, F_VRELC, k) = aiu * p.rhow * FD(s, F_CW, k);
         } else if (prevU || old) {
-            FD(s, F_STATE0 + S_U, k) = 0.0; FD(s, F_STATE0 + S_V, k) = 0.0;
-            FD(s, F_STATE1 + S_U, k) = 0.0; FD(s, F_STATE1 + S_V, k) = 0.0;
+            FD(s, SA + S_U, k) = 0.0; FD(s, SA + S_V, k) = 0.0;
+            FD(s, SB + S_U, k) = 0.0; FD(s, SB + S_V, k) = 0.0;
             FD(s, F_UVEL_INIT, k) = 0.0;    FD(s, F_VVEL_INIT, k) = 0.0;
             FD(s, F_STRINTX, k) = 0.0; FD(s, F_STRINTY, k) = 0.0;
             FD(s, F_STROCNX, k) = 0.0; FD(s, F_STROCNY, k) = 0.0;
