@@ -30,6 +30,7 @@ struct evpk_ctx {
     DevParams p{};
     bool have_params = false, uploaded = false, prepped = false;
     bool fresh = true;          // state planes were (re)loaded from the host since the last prep
+    bool zone_mode = false;     // k_subcycle2 reads two-column ghost zones filled by exchange_cols (x-slabs / forced exchange)
     int nxb = 0, nyb = 0, nblocks = 0;
     std::vector<BlockDesc> bd;
     BlockDesc *d_bd = nullptr;
@@ -55,6 +56,8 @@ struct evpk_ctx {
     double *sendbuf = nullptr, *recvbuf = nullptr;   // [W edge | E edge] and [from east | from west]
     double *sendW = nullptr, *sendE = nullptr, *recvW = nullptr, *recvE = nullptr;
     double *foldbuf = nullptr, *foldloc = nullptr, *foldall = nullptr;
+    double2 *cbuf = nullptr;         // 4 x [25 planes][2 cols][rows] of double2: sendW, sendE, recvE, recvW
+    size_t cslot = 0;
     int wmax = 0;
     std::vector<int> slab_i0;   // nranks+1 global start columns
     int *d_slab_i0 = nullptr;
@@ -241,12 +244,52 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     return 0;
 }
 
+// ---- two-column ghost zones of a list of pair planes (x-slab neighbours, all rows) -----------------
+static int exchange_cols(evpk_ctx *c, const PairList &pl) {
+    Slab &s = c->s;
+    const int tx = 128, grow = (s.nyl + 2 + tx - 1) / tx;
+    const int npl = pl.n + (pl.with_cmask ? 1 : 0);
+    if (npl > 25) FAIL(c, "exchange_cols: too many planes");
+    const size_t cnt = (size_t)npl * 2 * (s.nyl + 2);      // double2 elements per direction
+    double2 *sendW = c->cbuf, *sendE = c->cbuf + cnt, *recvE = c->cbuf + 2 * c->cslot, *recvW = c->cbuf + 2 * c->cslot + cnt;
+    hipLaunchKernelGGL(k_cols_pack, dim3(grow), dim3(tx), 0, c->stream, s, pl, sendW, sendE);
+    if (c->nranks == 1) {              // forced exchange with myself (cyclic ring of one)
+        if (c->west >= 0) {
+            HIPCHK(c, hipMemcpyAsync(recvE, sendW, sizeof(double2) * cnt, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(recvW, sendE, sizeof(double2) * cnt, hipMemcpyDeviceToDevice, c->stream));
+        }
+    } else if (c->west == c->east && c->west >= 0) {
+        // two ranks on a cyclic ring: [W cols | E cols] in one message each way, received as [east ghost | west ghost]
+        NCCLCHK(c, ncclGroupStart());
+        NCCLCHK(c, ncclSend(sendW, 4 * cnt, ncclDouble, c->west, c->comm, c->stream));
+        NCCLCHK(c, ncclRecv(recvE, 4 * cnt, ncclDouble, c->west, c->comm, c->stream));
+        NCCLCHK(c, ncclGroupEnd());
+    } else {
+        NCCLCHK(c, ncclGroupStart());
+        if (c->west >= 0) NCCLCHK(c, ncclSend(sendW, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
+        if (c->east >= 0) NCCLCHK(c, ncclSend(sendE, 2 * cnt, ncclDouble, c->east, c->comm, c->stream));
+        if (c->east >= 0) NCCLCHK(c, ncclRecv(recvE, 2 * cnt, ncclDouble, c->east, c->comm, c->stream));
+        if (c->west >= 0) NCCLCHK(c, ncclRecv(recvW, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
+        NCCLCHK(c, ncclGroupEnd());
+    }
+    hipLaunchKernelGGL(k_cols_unpack, dim3(grow), dim3(tx), 0, c->stream, s, pl, (const double2 *)recvW, (const double2 *)recvE,
+                       c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static PairList state_pairs(int SB) {
+    PairList pl{};
+    for (int q = 0; q < NSTATE / 2; q++) pl.p[pl.n++] = (SB >> 1) + q;
+    return pl;
+}
+
 static void destroy_impl(evpk_ctx *c) {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->d_flags2, c->d_strips2, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->d_flags2, c->d_strips2, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -298,7 +341,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     s.nxl = i1 - i0 + 1; s.nyl = j1 - j0 + 1; s.i0 = i0; s.j0 = j0; s.nxg = g->nx_global; s.nyg = g->ny_global;
     if (g->ns_boundary == EVPK_BND_TRIPOLE && (s.nyl < 2 || (g->nx_global & 1))) FAIL(c, "tripole needs ny >= 2 and even nx_global");
     c->full_cover = (covered == (long long)s.nxl * s.nyl);
-    s.pitch = ((C0 + s.nxl + 2 + 7) / 8) * 8;
+    s.pitch = ((C0 + s.nxl + 3 + 7) / 8) * 8;     // columns -1 .. nxl+2 (two ghost columns per side)
     s.rstride = NP * s.pitch;
 
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -357,6 +400,9 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipMemsetAsync(c->recvbuf, 0, sizeof(double) * 2 * eslot, c->stream));
     c->sendW = c->sendbuf; c->sendE = c->sendbuf + eslot;      // re-pointed per call: [W edge | E edge], nf*(nyl+2) each
     c->recvE = c->recvbuf; c->recvW = c->recvbuf + eslot;      // [east ghost | west ghost]
+    c->cslot = (size_t)25 * 2 * (s.nyl + 2);
+    HIPCHK(c, hipMalloc(&c->cbuf, sizeof(double2) * 4 * c->cslot));
+    HIPCHK(c, hipMemsetAsync(c->cbuf, 0, sizeof(double2) * 4 * c->cslot, c->stream));
     if (g->ns_boundary == EVPK_BND_TRIPOLE) {
         HIPCHK(c, hipMalloc(&c->foldbuf, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg));
         HIPCHK(c, hipMemsetAsync(c->foldbuf, 0, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg, c->stream));
@@ -416,7 +462,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     {   // two subcycles per launch: single rank, no tripole fold between the subcycles (EVPK_DOUBLE=0 disables)
         const char *e = getenv("EVPK_DOUBLE");
-        c->use_double = (g->nranks == 1) && (g->ns_boundary != EVPK_BND_TRIPOLE) && !c->force_exchange && !(e && atoi(e) == 0);
+        c->use_double = (g->ns_boundary != EVPK_BND_TRIPOLE) && !(e && atoi(e) == 0) && s.nxl >= 4;
     }
     const char *tk = getenv("EVPK_TIME_KERNELS");
     c->time_kernels = !(tk && atoi(tk) == 0);
@@ -519,6 +565,15 @@ extern "C" int evpk_prep(evpk_ctx *c) {
             hipLaunchKernelGGL(k_row_copy, dim3((s.nxl + 2 + 127) / 128), dim3(128), 0, c->stream, s, SA + S_U, SB + S_U, 2, s.nyl);
     }
     c->fresh = false;
+    c->zone_mode = c->use_double && (c->nranks > 1 || c->force_exchange);
+    if (c->zone_mode) {
+        // two-column ghost zones for k_subcycle2: every plane it reads, the current state and the masks, once per evp
+        PairList pl = state_pairs(SA);
+        const int stat[] = {F_CXP, F_CXM, F_DXT, F_DXHY, F_TINYAREA, F_VRELC, F_UOCN, F_FORCEX, F_UMASSDTI, F_UVEL_INIT};
+        for (int f : stat) pl.p[pl.n++] = f >> 1;
+        pl.with_cmask = 1;
+        if (exchange_cols(c, pl)) return 1;
+    }
     // active strips
     const int ns_tot = c->ncx * c->nry;
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 2, c->stream));
@@ -528,7 +583,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     std::vector<unsigned char> flags2(c->use_double ? ns_tot2 : 0);
     if (c->use_double) {
         hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry, c->R,
-                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->d_flags2);
+                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, c->d_flags2);
         HIPCHK(c, hipMemcpyAsync(flags2.data(), c->d_flags2, ns_tot2, hipMemcpyDeviceToHost, c->stream));
     }
     std::vector<unsigned char> flags(ns_tot);
@@ -580,7 +635,8 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics)
         if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte) {
-            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.wrap = (c->ew == EVPK_BND_CYCLIC) ? 1 : 0;
+            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2;
+            a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             if (c->nstrips2 > 0) {
                 const dim3 g((((c->nstrips2 + 3) / 4 + 7) / 8) * 8), b(256);
                 if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches], c->stream));
@@ -594,6 +650,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             c->ksub += 2;
             n += 2;
             c->cur ^= 1;
+            if (c->zone_mode && exchange_cols(c, state_pairs(c->cur ? F_STATE1 : F_STATE0))) return 1;
             continue;
         }
         c->ksub++;

@@ -409,6 +409,66 @@ __global__ void k_ew_unpack(Slab s, int f, int nf, const double *recvW, const do
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Two-column ghost zones for the two-subcycle kernel on x-slabs: columns {1,2} go to the west
+// neighbour (its columns nxl+1, nxl+2), columns {nxl-1, nxl} to the east neighbour (its -1, 0),
+// over all rows, for a list of pair planes (+ optionally the byte mask as a pseudo plane).
+// Buffer layout: buf[((p*2 + k)*rows + j)] of double2, k = 0,1 the two columns in ascending order.
+// ------------------------------------------------------------------------------------
+struct PairList { int n; int with_cmask; int p[24]; };
+
+__global__ void k_cols_pack(Slab s, PairList pl, double2 *sendW, double2 *sendE) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > s.nyl + 1) return;
+    const int rows = s.nyl + 2;
+    const double2 *F2 = reinterpret_cast<const double2 *>(s.F);
+    for (int q = 0; q < pl.n; q++) {
+        const double2 *row = F2 + (size_t)j * s.rstride + (size_t)pl.p[q] * s.pitch + C0;
+        sendW[((size_t)q * 2 + 0) * rows + j] = row[1];
+        sendW[((size_t)q * 2 + 1) * rows + j] = row[2];
+        sendE[((size_t)q * 2 + 0) * rows + j] = row[s.nxl - 1];
+        sendE[((size_t)q * 2 + 1) * rows + j] = row[s.nxl];
+    }
+    if (pl.with_cmask) {
+        const unsigned char *m = s.cmask + (size_t)j * s.pitch + C0;
+        const int q = pl.n;
+        sendW[((size_t)q * 2 + 0) * rows + j] = make_double2((double)m[1], 0.0);
+        sendW[((size_t)q * 2 + 1) * rows + j] = make_double2((double)m[2], 0.0);
+        sendE[((size_t)q * 2 + 0) * rows + j] = make_double2((double)m[s.nxl - 1], 0.0);
+        sendE[((size_t)q * 2 + 1) * rows + j] = make_double2((double)m[s.nxl], 0.0);
+    }
+}
+
+__global__ void k_cols_unpack(Slab s, PairList pl, const double2 *recvW, const double2 *recvE, int haveW, int haveE) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > s.nyl + 1) return;
+    const int rows = s.nyl + 2;
+    double2 *F2 = reinterpret_cast<double2 *>(s.F);
+    for (int q = 0; q < pl.n; q++) {
+        double2 *row = F2 + (size_t)j * s.rstride + (size_t)pl.p[q] * s.pitch + C0;
+        if (haveE) {
+            row[s.nxl + 1] = recvE[((size_t)q * 2 + 0) * rows + j];
+            row[s.nxl + 2] = recvE[((size_t)q * 2 + 1) * rows + j];
+        }
+        if (haveW) {
+            row[-1] = recvW[((size_t)q * 2 + 0) * rows + j];
+            row[0] = recvW[((size_t)q * 2 + 1) * rows + j];
+        }
+    }
+    if (pl.with_cmask) {
+        unsigned char *m = s.cmask + (size_t)j * s.pitch + C0;
+        const int q = pl.n;
+        if (haveE) {
+            m[s.nxl + 1] = (unsigned char)recvE[((size_t)q * 2 + 0) * rows + j].x;
+            m[s.nxl + 2] = (unsigned char)recvE[((size_t)q * 2 + 1) * rows + j].x;
+        }
+        if (haveW) {
+            m[-1] = (unsigned char)recvW[((size_t)q * 2 + 0) * rows + j].x;
+            m[0] = (unsigned char)recvW[((size_t)q * 2 + 1) * rows + j].x;
+        }
+    }
+}
+
 // one wave per strip: is there any T work (cols cx*63+1..+64, rows jb..jb+R) or U work?
 // Also counts active cells: T on physical cells, U.
 __global__ void k_strip_flags(Slab s, int ncx, int nry, int R, unsigned char *flags, unsigned long long *counts) {
@@ -428,7 +488,7 @@ __global__ void k_strip_flags(Slab s, int ncx, int nry, int R, unsigned char *fl
                 any = 1;
                 if (lane < STRIP_W && jj < R && i <= s.nxl && j <= s.nyl) nt++;
             }
-            if ((m & CM_U) && lane < STRIP_W && jj < R) { any = 1; nu++; }
+            if ((m & CM_U) && lane < STRIP_W && jj < R && i <= s.nxl && j <= s.nyl) { any = 1; nu++; }
         }
     }
     const unsigned long long b = __ballot(any);
@@ -781,13 +841,15 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
         cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
         okc = okm = true;
     } else {
-        okc = (c >= 0 && c <= nxl + 1);
-        okm = (cm1 >= 0 && cm1 <= nxl + 1);
+        // ghost-zone mode: storage has two ghost columns per side (-1, 0 | nxl+1, nxl+2); on an open / closed
+        // single-rank boundary they hold zeros and inactive masks, between ranks the neighbour's columns
+        okc = (c >= -1 && c <= nxl + 2);
+        okm = (cm1 >= -1 && cm1 <= nxl + 2);
         if (!okc) ci = 0;
         if (!okm) cm1 = 0;
     }
-    const bool tcol = cyc ? true : (c >= 1 && c <= nxl + 1);       // column can hold an active T cell
-    const bool ucol = cyc ? true : (c >= 1 && c <= nxl);           // ... an active U cell
+    const bool tcol = cyc ? true : (c >= 0 && c <= nxl + 2);       // column can hold an active T cell
+    const bool ucol = cyc ? true : (c >= 0 && c <= nxl + 1);       // ... an active U cell
     const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 && c <= nxl);   // columns this lane stores
 
     const size_t pp = (size_t)s.pitch * 16;
@@ -927,7 +989,7 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, unsigne
     int ci = c;
     bool ok;
     if (cyc) { ci = (c - 1) % s.nxl; if (ci < 0) ci += s.nxl; ci += 1; ok = true; }
-    else ok = (c >= 1 && c <= s.nxl + 1);
+    else ok = (c >= 0 && c <= s.nxl + 2);
     const int jb = ry * R + 1;
     int any = 0;
     if (ok)
