@@ -37,6 +37,11 @@ struct evpk_ctx {
     bool full_cover = true;
     int ew = 0, ns = 0, rank = 0, nranks = 1, west = -1, east = -1, device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // interior strips of k_subcycle2 while `stream` exchanges the edge columns
+    hipEvent_t evI = nullptr, evX = nullptr;
+    int *d_strips2e = nullptr, *d_strips2i = nullptr;
+    int nstrips2e = 0, nstrips2i = 0;
+    bool overlap = true;
     ncclComm_t comm = nullptr;
     double *stage = nullptr;   // nblocks*nyb*nxb doubles (also reused as int32)
     size_t stage_n = 0;
@@ -289,10 +294,13 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->d_flags2, c->d_strips2, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->evI) hipEventDestroy(c->evI);
+    if (c->evX) hipEventDestroy(c->evX);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     for (auto e : c->kev) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -345,6 +353,9 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     s.rstride = NP * s.pitch;
 
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->evI, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
     const size_t nd = slab_doubles(s), nm = mask_elems(s);
@@ -384,6 +395,9 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     c->ncx2 = (s.nxl + STRIP2_W - 1) / STRIP2_W;
     HIPCHK(c, hipMalloc(&c->d_flags2, (size_t)c->ncx2 * c->nry));
     HIPCHK(c, hipMalloc(&c->d_strips2, sizeof(int) * (size_t)c->ncx2 * c->nry));
+    HIPCHK(c, hipMalloc(&c->d_strips2e, sizeof(int) * (size_t)c->ncx2 * c->nry));
+    HIPCHK(c, hipMalloc(&c->d_strips2i, sizeof(int) * (size_t)c->ncx2 * c->nry));
+    { const char *e = getenv("EVPK_OVERLAP"); c->overlap = !(e && atoi(e) == 0); }
 
     // neighbours on the slab ring
     int lay[5];
@@ -601,6 +615,16 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         for (int k = 0; k < ns_tot2; k++) if (flags2[k]) list2.push_back(k);
         c->nstrips2 = (int)list2.size();
         if (c->nstrips2) HIPCHK(c, hipMemcpyAsync(c->d_strips2, list2.data(), sizeof(int) * list2.size(), hipMemcpyHostToDevice, c->stream));
+        // edge strips own the columns that the neighbours need (1,2 and nxl-1,nxl); they run first, the rest overlaps the exchange
+        std::vector<int> le, li;
+        for (int k : list2) {
+            const int cx = k % c->ncx2;
+            if (cx == 0 || cx >= c->ncx2 - 2) le.push_back(k); else li.push_back(k);
+        }
+        c->nstrips2e = (int)le.size(); c->nstrips2i = (int)li.size();
+        if (c->nstrips2e) HIPCHK(c, hipMemcpyAsync(c->d_strips2e, le.data(), sizeof(int) * le.size(), hipMemcpyHostToDevice, c->stream));
+        if (c->nstrips2i) HIPCHK(c, hipMemcpyAsync(c->d_strips2i, li.data(), sizeof(int) * li.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // the host vectors go out of scope
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->icellt = (long long)cnt[0];
@@ -627,6 +651,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->double_launches = 0;
+    bool in_overlap = false;
     for (int n = 0; n < nsub;) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
@@ -634,6 +659,48 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         a.R = c->R; a.cur = c->cur;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics)
+        if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte && c->zone_mode && c->overlap) {
+            // x-slabs: edge strips first on `stream`, then the exchange of the two edge columns there, while the interior
+            // strips run on `stream2`.  Step k's kernels need exchange k-1 (ghost zones of the buffer they read) and all of
+            // step k-1's kernels; the exchange writes ghost zones of the buffer being WRITTEN, which no kernel of step k reads.
+            a.ncx = c->ncx2; a.wrap = 0;
+            if (!in_overlap) {          // enter: stream2 picks up after everything queued on stream so far
+                HIPCHK(c, hipEventRecord(c->evX, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evX, 0));
+                HIPCHK(c, hipEventRecord(c->evI, c->stream2));
+                in_overlap = true;
+            }
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));          // interior of step k-1
+            if (c->nstrips2e > 0) {
+                a.strips = c->d_strips2e; a.nstrips = c->nstrips2e;
+                const dim3 g((((c->nstrips2e + 3) / 4 + 7) / 8) * 8), b(256);
+                if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream, a);
+                else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream, a);
+            }
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evX, 0));         // exchange k-1 (and with it edge k-1)
+            if (c->nstrips2i > 0) {
+                a.strips = c->d_strips2i; a.nstrips = c->nstrips2i;
+                const dim3 g((((c->nstrips2i + 3) / 4 + 7) / 8) * 8), b(256);
+                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches], c->stream2));
+                if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream2, a);
+                else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream2, a);
+                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches + 1], c->stream2));
+                c->kev_is_double[c->kernel_launches] = 1;
+                c->kernel_launches++;
+                c->double_launches++;
+            }
+            HIPCHK(c, hipEventRecord(c->evI, c->stream2));
+            c->ksub += 2;
+            n += 2;
+            c->cur ^= 1;
+            if (exchange_cols(c, state_pairs(c->cur ? F_STATE1 : F_STATE0))) return 1;
+            HIPCHK(c, hipEventRecord(c->evX, c->stream));
+            continue;
+        }
+        if (in_overlap) {               // leave: stream waits for the last interior launch
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));
+            in_overlap = false;
+        }
         if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte) {
             a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
@@ -672,6 +739,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             if (halo(c, (c->cur ? F_STATE1 : F_STATE0) + S_U, 2, true, true, 0.0)) return 1;
         }
     }
+    if (in_overlap) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev1));
