@@ -163,7 +163,8 @@ def main():
         "config": {"workload": workload,
                    "active_T_cells": int(icellt), "active_U_cells": int(icellu), "grid_cells": nx * ny,
                    "grid_cell_updates_per_s": nx * ny * a.ndte * a.steps / dt_wall,
-                   "strips_per_launch_rank0": int(st.nstrips), "step": "prep + ndte x (stress+stepu, halo) + finish"},
+                   "strips_per_launch_rank0": int(st.nstrips2 or st.nstrips),
+                   "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows), "step": "prep + ndte x (stress+stepu, halo) + finish"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "alg_bytes_per_launch": alg_bytes_launch,

@@ -48,6 +48,10 @@ struct evpk_ctx {
     // strips
     int ncx = 0, nry = 0, R = 8, nstrips = 0;
     int ncx2 = 0, nstrips2 = 0;      // 61-column strips of the two-subcycle kernel
+    int R2 = 16, nry2 = 0;           // their height, tuned to the active area (tune_R2)
+    long long tuned_icellt = -1;
+    int slots2 = 512;                // resident 256-thread workgroups of k_subcycle2 on the whole chip
+    unsigned int *d_tune = nullptr;
     bool use_double = false;
     unsigned char *d_flags2 = nullptr;
     int *d_strips2 = nullptr;
@@ -294,7 +298,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -393,10 +397,19 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * (size_t)c->ncx * c->nry));
     HIPCHK(c, hipMalloc(&c->d_counts, sizeof(unsigned long long) * 2));
     c->ncx2 = (s.nxl + STRIP2_W - 1) / STRIP2_W;
-    HIPCHK(c, hipMalloc(&c->d_flags2, (size_t)c->ncx2 * c->nry));
-    HIPCHK(c, hipMalloc(&c->d_strips2, sizeof(int) * (size_t)c->ncx2 * c->nry));
-    HIPCHK(c, hipMalloc(&c->d_strips2e, sizeof(int) * (size_t)c->ncx2 * c->nry));
-    HIPCHK(c, hipMalloc(&c->d_strips2i, sizeof(int) * (size_t)c->ncx2 * c->nry));
+    {
+        const size_t n2 = (size_t)c->ncx2 * (s.nyl + 2);           // enough for any strip height >= 1
+        HIPCHK(c, hipMalloc(&c->d_flags2, n2));
+        HIPCHK(c, hipMalloc(&c->d_strips2, sizeof(int) * n2));
+        HIPCHK(c, hipMalloc(&c->d_strips2e, sizeof(int) * n2));
+        HIPCHK(c, hipMalloc(&c->d_strips2i, sizeof(int) * n2));
+        HIPCHK(c, hipMalloc(&c->d_tune, sizeof(unsigned int) * 32));
+        c->R2 = c->R;
+        c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_subcycle2<false>, 256, 0) == hipSuccess && nb > 0)
+            c->slots2 = nb * prop.multiProcessorCount;
+    }
     { const char *e = getenv("EVPK_OVERLAP"); c->overlap = !(e && atoi(e) == 0); }
 
     // neighbours on the slab ring
@@ -553,6 +566,45 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
     return 0;
 }
 
+// Strip height of k_subcycle2.  The kernel's run time is quantised in "rounds" of resident workgroups
+// (2 per CU): a launch with slightly more workgroups than fit pays a whole extra round, while tall strips
+// waste less on the three redundant stage-1 rows.  Count the active strips for a few heights and take the
+// cheapest  rounds x (R+3).  Re-tuned when the active area changed by more than 5 %.
+static int tune_R2(evpk_ctx *c) {
+    const char *e = getenv("EVPK_STRIP_ROWS");
+    if (e && atoi(e) > 0) { c->R2 = std::max(1, std::min(atoi(e), 64)); c->nry2 = (c->s.nyl + 1 + c->R2 - 1) / c->R2; return 0; }
+    // icellt of this prep is not known yet on the host; use the previous one as the trigger
+    if (c->tuned_icellt >= 0 && std::llabs(c->icellt - c->tuned_icellt) * 20 <= c->tuned_icellt) return 0;
+    static const int cand[] = {8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48};
+    const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
+    Slab &s = c->s;
+    HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int) * 32, c->stream));
+    const int cyc = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;
+    for (int k = 0; k < ncand; k++) {
+        const int R = cand[k], nry = (s.nyl + 1 + R - 1) / R, tot = c->ncx2 * nry;
+        hipLaunchKernelGGL(k_strip_flags2, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, nry, R, cyc,
+                           (unsigned char *)nullptr, c->d_tune + k);
+    }
+    unsigned int cnt[32];
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_tune, sizeof(unsigned int) * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double best = 1e300;
+    int bestR = c->R2;
+    for (int k = 0; k < ncand; k++) {
+        const long long nwg = (cnt[k] + 3) / 4;
+        if (nwg == 0) continue;
+        const long long rounds = (nwg + c->slots2 - 1) / c->slots2;
+        // a round that is less than ~70 % full hides memory latency worse: charge it a little
+        const double fill = (double)nwg / (double)(rounds * c->slots2);
+        const double cost = (double)rounds * (cand[k] + 3) * (fill < 0.7 ? 1.0 + 0.5 * (0.7 - fill) : 1.0);
+        if (cost < best * 0.999) { best = cost; bestR = cand[k]; }
+    }
+    c->R2 = bestR;
+    c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
+    c->tuned_icellt = -2;      // set from the counts of this prep below
+    return 0;
+}
+
 extern "C" int evpk_prep(evpk_ctx *c) {
     if (!c) return 1;
     if (!c->uploaded) FAIL(c, "evpk_upload has not been called");
@@ -593,11 +645,12 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 2, c->stream));
     hipLaunchKernelGGL(k_strip_flags, dim3((ns_tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx, c->nry, c->R, c->d_flags, c->d_counts);
     HIPCHK(c, hipGetLastError());
-    const int ns_tot2 = c->ncx2 * c->nry;
+    if (c->use_double && tune_R2(c)) return 1;
+    const int ns_tot2 = c->ncx2 * c->nry2;
     std::vector<unsigned char> flags2(c->use_double ? ns_tot2 : 0);
     if (c->use_double) {
-        hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry, c->R,
-                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, c->d_flags2);
+        hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry2, c->R2,
+                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, c->d_flags2, (unsigned int *)nullptr);
         HIPCHK(c, hipMemcpyAsync(flags2.data(), c->d_flags2, ns_tot2, hipMemcpyDeviceToHost, c->stream));
     }
     std::vector<unsigned char> flags(ns_tot);
@@ -629,6 +682,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->icellt = (long long)cnt[0];
     c->icellu = (long long)cnt[1];
+    if (c->tuned_icellt == -2) c->tuned_icellt = c->icellt;
     c->ksub = 0;
     c->prepped = true;
     return 0;
@@ -663,7 +717,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             // x-slabs: edge strips first on `stream`, then the exchange of the two edge columns there, while the interior
             // strips run on `stream2`.  Step k's kernels need exchange k-1 (ghost zones of the buffer they read) and all of
             // step k-1's kernels; the exchange writes ghost zones of the buffer being WRITTEN, which no kernel of step k reads.
-            a.ncx = c->ncx2; a.wrap = 0;
+            a.ncx = c->ncx2; a.wrap = 0; a.R = c->R2;
             if (!in_overlap) {          // enter: stream2 picks up after everything queued on stream so far
                 HIPCHK(c, hipEventRecord(c->evX, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evX, 0));
@@ -702,7 +756,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             in_overlap = false;
         }
         if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte) {
-            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2;
+            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             if (c->nstrips2 > 0) {
                 const dim3 g((((c->nstrips2 + 3) / 4 + 7) / 8) * 8), b(256);
@@ -844,5 +898,6 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->loop_ms = c->loop_ms;
     o->kernel_ms = c->kernel_ms; o->kernel_launches = c->kernel_launches - c->double_launches;
     o->kernel2_ms = c->kernel2_ms; o->kernel2_launches = c->double_launches;
+    o->strip_rows = c->R; o->strip_rows2 = c->use_double ? c->R2 : 0; o->nstrips2 = c->use_double ? c->nstrips2 : 0;
     return 0;
 }

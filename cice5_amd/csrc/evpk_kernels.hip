@@ -980,7 +980,7 @@ template __global__ void k_subcycle2<true>(SubArgs);
 
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
-__global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, unsigned char *flags) {
+__global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, unsigned char *flags, unsigned int *count) {
     const int sid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (sid >= ncx * nry) return;
@@ -998,7 +998,10 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, unsigne
             if (s.cmask[mcell(s, ci, r)]) any = 1;
         }
     const unsigned long long b = __ballot(any);
-    if (lane == 0) flags[sid] = b ? 1 : 0;
+    if (lane == 0) {
+        if (flags) flags[sid] = b ? 1 : 0;
+        if (count && b) atomicAdd(count, 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------

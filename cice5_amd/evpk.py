@@ -66,7 +66,8 @@ class Stats(ct.Structure):
     _fields_ = [("icellt", ct.c_int64), ("icellu", ct.c_int64), ("ncell_slab", ct.c_int64),
                 ("nstrips", ct.c_int32), ("nstrips_total", ct.c_int32), ("subcycles_done", ct.c_int32),
                 ("loop_ms", ct.c_float), ("kernel_ms", ct.c_float), ("kernel_launches", ct.c_int32),
-                ("kernel2_ms", ct.c_float), ("kernel2_launches", ct.c_int32)]
+                ("kernel2_ms", ct.c_float), ("kernel2_launches", ct.c_int32),
+                ("strip_rows", ct.c_int32), ("strip_rows2", ct.c_int32), ("nstrips2", ct.c_int32)]
 
 
 EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",

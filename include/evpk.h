@@ -119,6 +119,8 @@ typedef struct {
     int32_t kernel_launches; /* ... and their number */
     float kernel2_ms;        /* the same for the two-subcycle kernel (k_subcycle2) */
     int32_t kernel2_launches;
+    int32_t strip_rows, strip_rows2;   /* strip heights in use: k_subcycle, k_subcycle2 (auto-tuned) */
+    int32_t nstrips2;
 } evpk_stats;
 
 /* rank 0 creates the RCCL id; the host model broadcasts the bytes (MPI_Bcast in CICE,
