@@ -71,9 +71,11 @@ def main():
     uid = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # torch.distributed is only the control plane here (rendezvous, barrier, scalar reductions, the 128-byte
+        # RCCL id): gloo on CPU tensors.  The data plane is libevpk's own RCCL communicator (ncclSend/ncclRecv over xGMI).
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         box = [evpk.get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, device=torch.device("cpu"))
+        dist.broadcast_object_list(box, src=0)
         uid = box[0]
 
     nx, ny = (int(v) for v in a.grid.split("x"))

@@ -569,13 +569,13 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
 // Strip height of k_subcycle2.  The kernel's run time is quantised in "rounds" of resident workgroups
 // (2 per CU): a launch with slightly more workgroups than fit pays a whole extra round, while tall strips
 // waste less on the three redundant stage-1 rows.  Count the active strips for a few heights and take the
-// cheapest  rounds x (R+3).  Re-tuned when the active area changed by more than 5 %.
+// cheapest  rounds x (R+5).  Re-tuned when the active area changed by more than 5 %.
 static int tune_R2(evpk_ctx *c) {
     const char *e = getenv("EVPK_STRIP_ROWS");
     if (e && atoi(e) > 0) { c->R2 = std::max(1, std::min(atoi(e), 64)); c->nry2 = (c->s.nyl + 1 + c->R2 - 1) / c->R2; return 0; }
     // icellt of this prep is not known yet on the host; use the previous one as the trigger
     if (c->tuned_icellt >= 0 && std::llabs(c->icellt - c->tuned_icellt) * 20 <= c->tuned_icellt) return 0;
-    static const int cand[] = {8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48};
+    static const int cand[] = {2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48};
     const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
     Slab &s = c->s;
     HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int) * 32, c->stream));
@@ -596,7 +596,8 @@ static int tune_R2(evpk_ctx *c) {
         const long long rounds = (nwg + c->slots2 - 1) / c->slots2;
         // a round that is less than ~70 % full hides memory latency worse: charge it a little
         const double fill = (double)nwg / (double)(rounds * c->slots2);
-        const double cost = (double)rounds * (cand[k] + 3) * (fill < 0.7 ? 1.0 + 0.5 * (0.7 - fill) : 1.0);
+        // a strip marches R+3 rows plus about two rows' worth of prologue / drain
+        const double cost = (double)rounds * (cand[k] + 5) * (fill < 0.7 ? 1.0 + 0.5 * (0.7 - fill) : 1.0);
         if (cost < best * 0.999) { best = cost; bestR = cand[k]; }
     }
     c->R2 = bestR;
