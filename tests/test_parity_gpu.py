@@ -193,18 +193,24 @@ def test_staged_api_equals_run():
     assert not util.compare(d, b, a)
 
 
-def test_device_resident_steps_inputs_only_upload():
+@pytest.mark.parametrize("mode", ["plain", "exchange", "exchange-serial", "single-kernel"])
+def test_device_resident_steps_inputs_only_upload(mode, monkeypatch):
     """The state (u, v, sigma, iceumask) stays on the device between evp() calls; only the inputs are
     re-uploaded (evpk_upload with state == NULL).  Ice retreats and advances between the calls, which
     exercises the skip-if-still-inactive logic of the prep kernels.  Oracle: the same calls back to back."""
-    case, d, f = util.make_case(100, 116, 25, 29, land="continents")
+    if mode.startswith("exchange"):        # x-slab code path on one rank: ghost zones, two streams
+        monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+    if mode == "exchange-serial":
+        monkeypatch.setenv("EVPK_OVERLAP", "0")
+    if mode == "single-kernel":
+        monkeypatch.setenv("EVPK_DOUBLE", "0")
+    case, d, f = util.make_case(200, 116, 50, 29, land="continents")
     xmin = synth.global_min_dx(case)
     fo, fg = util.clone(f), util.clone(f)
     p = orc.make_params(3600.0, 30, xmin)
     s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
     s.init_evp(3600.0)
     ctx = s.ctx
-    I = np.arange(d.nx_block)[None, None, :] + np.zeros(fo["aice"].shape)
     for call in range(4):
         for ff in (fo, fg):
             if call == 1:      # retreat: a band of ice disappears
