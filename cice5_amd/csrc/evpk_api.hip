@@ -40,6 +40,8 @@ struct evpk_ctx {
     hipStream_t stream2 = nullptr;   // interior strips of k_subcycle2 while `stream` exchanges the edge columns
     hipEvent_t evI = nullptr, evX = nullptr;
     int *d_strips2e = nullptr, *d_strips2i = nullptr;
+    int *d_band = nullptr;           // strips 0..ncx-1 of a one-band launch (tripole top band)
+    bool band_mode = false;          // tripole + k_subcycle2: the top rows are redone with two one-subcycle band launches
     int nstrips2e = 0, nstrips2i = 0;
     bool overlap = true;
     ncclComm_t comm = nullptr;
@@ -298,7 +300,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -489,7 +491,16 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     {   // two subcycles per launch: single rank, no tripole fold between the subcycles (EVPK_DOUBLE=0 disables)
         const char *e = getenv("EVPK_DOUBLE");
-        c->use_double = (g->ns_boundary != EVPK_BND_TRIPOLE) && !(e && atoi(e) == 0) && s.nxl >= 4;
+        c->use_double = !(e && atoi(e) == 0) && s.nxl >= 4;
+        if (g->ns_boundary == EVPK_BND_TRIPOLE) {
+            // the fold mixes mirrored columns between the two fused subcycles: only the rows next to the fold are affected,
+            // they are redone by band launches (single rank only; x-slabs would need the fold all-gather in between)
+            c->band_mode = c->use_double = c->use_double && g->nranks == 1 && !c->force_exchange && s.nyl >= 8;
+        }
+        std::vector<int> band(c->ncx);
+        for (int k = 0; k < c->ncx; k++) band[k] = k;
+        HIPCHK(c, hipMalloc(&c->d_band, sizeof(int) * c->ncx));
+        HIPCHK(c, hipMemcpy(c->d_band, band.data(), sizeof(int) * c->ncx, hipMemcpyHostToDevice));
     }
     const char *tk = getenv("EVPK_TIME_KERNELS");
     c->time_kernels = !(tk && atoi(tk) == 0);
@@ -631,6 +642,9 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         if (c->ns == EVPK_BND_TRIPOLE)
             hipLaunchKernelGGL(k_row_copy, dim3((s.nxl + 2 + 127) / 128), dim3(128), 0, c->stream, s, SA + S_U, SB + S_U, 2, s.nyl);
     }
+    if (c->band_mode)       // inactive cells of the scratch state keep the values they have at the start of the loop
+        hipLaunchKernelGGL(k_rows_copy, dim3((s.nxl + 2 + 127) / 128, 6), dim3(128), 0, c->stream, s, SA + S_U, (int)(F_STATE2 + S_U), 2,
+                           s.nyl - 4, s.nyl + 1);
     c->fresh = false;
     c->zone_mode = c->use_double && (c->nranks > 1 || c->force_exchange);
     if (c->zone_mode) {
@@ -711,7 +725,8 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.cur = c->cur;
+        a.R = c->R; a.jb0 = 0;
+        a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics)
         if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte && c->zone_mode && c->overlap) {
@@ -768,6 +783,23 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;
                 c->double_launches++;
+            }
+            if (c->band_mode) {
+                // tripole: rows next to the fold again, one subcycle at a time with the fold in between
+                //   band 1: T rows nyl-2..nyl+1, U rows nyl-2..nyl   state `sr` -> scratch;  fold(scratch)
+                //   band 2: T rows nyl-1..nyl+1, U rows nyl-1..nyl   scratch -> state `sw`;  fold(sw)
+                SubArgs b1 = a;
+                b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0;
+                b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
+                SubArgs b2 = b1;
+                b2.R = 3; b2.jb0 = s.nyl - 1; b2.sr = F_STATE2; b2.sw = a.sw;
+                const dim3 g((((c->ncx + 3) / 4 + 7) / 8) * 8), b(256);
+                if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, b1);
+                else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, b1);
+                if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0)) return 1;
+                if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, b2);
+                else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, b2);
+                if (halo(c, a.sw + S_U, 2, true, true, 0.0)) return 1;
             }
             c->ksub += 2;
             n += 2;

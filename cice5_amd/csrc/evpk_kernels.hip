@@ -214,6 +214,15 @@ __global__ void k_row_copy(Slab s, int fsrc, int fdst, int nf, int j) {
     for (int q = 0; q < nf; q++) FD(s, fdst + q, k) = FD(s, fsrc + q, k);
 }
 
+// rows j0..j1 (all columns incl. ghosts) of nf planes: dst <- src
+__global__ void k_rows_copy(Slab s, int fsrc, int fdst, int nf, int j0, int j1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = j0 + blockIdx.y;
+    if (i > s.nxl + 1 || j > j1) return;
+    const size_t k = cell(s, i, j);
+    for (int q = 0; q < nf; q++) FD(s, fdst + q, k) = FD(s, fsrc + q, k);
+}
+
 // to_tgrid (ice_grid.F90:1924-1958): only physical cells of dst are written
 __global__ void k_to_tgrid(Slab s, int fsrc, int fdst) {
     SLAB_IJ_ALL
@@ -514,7 +523,9 @@ struct SubArgs {
     Slab s;
     double ecci, arlx1i, denom1, brlx, revp, cosw, sinw;
     const int *strips;
-    int nstrips, ncx, R, cur, wrap;
+    int nstrips, ncx, R, wrap;
+    int sr, sw;        // field ids of the state buffer read / written (F_STATE0, F_STATE1 or F_STATE2)
+    int jb0;           // > 0: band launch -- every strip starts at row jb0 (tripole top band), strips[] holds cx only
 };
 
 __device__ __forceinline__ double shfl_dn1(double x) { return __shfl_down(x, 1); }
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R;
     const int i = cx * STRIP_W + 1 + lane;            // T column of this lane
-    const int jb = ry * R + 1;
+    const int jb = a.jb0 > 0 ? a.jb0 : ry * R + 1;
     const bool colT = (i <= s.nxl + 1);               // lane has a T column
     const bool ownT = colT && (lane < STRIP_W);       // ... and owns its sigma stores
     const bool colU = (i <= s.nxl) && (lane < STRIP_W);
@@ -720,8 +731,8 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     const size_t pp = (size_t)s.pitch * 16;           // bytes per row of one pair plane
     const size_t rowb = (size_t)s.rstride * 16;       // bytes per row of all planes
     const unsigned lo = (unsigned)(C0 + i) * 16u;     // lane byte offset inside a pair-plane row
-    const int SR = a.cur ? F_STATE1 : F_STATE0;       // read buffer
-    const int SW = a.cur ? F_STATE0 : F_STATE1;       // write buffer
+    const int SR = a.sr;                              // read buffer
+    const int SW = a.sw;                              // write buffer
     char *const base = reinterpret_cast<char *>(s.F);
 
     // carried from the previous row (j-1)
@@ -855,8 +866,8 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
     const size_t pp = (size_t)s.pitch * 16;
     const size_t rowb = (size_t)s.rstride * 16;
     const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
-    const int SR = a.cur ? F_STATE1 : F_STATE0;
-    const int SW = a.cur ? F_STATE0 : F_STATE1;
+    const int SR = a.sr;
+    const int SW = a.sw;
     char *const base = reinterpret_cast<char *>(s.F);
 
     // ---- carried state ----

@@ -156,7 +156,8 @@ def test_two_subcycle_kernel_equals_single(monkeypatch):
     """k_subcycle2 (two subcycles per launch) vs k_subcycle only: bit-identical, including odd ndte,
     subcycles issued in odd pieces, revised EVP, and a non-cyclic E-W boundary."""
     for kw, ndte, pieces in [(dict(land="continents"), 31, [31]), (dict(land="continents"), 40, [7, 12, 21]),
-                             (dict(ice="full"), 24, [24])]:
+                             (dict(ice="full"), 24, [24]), (dict(land="continents", ns="tripole"), 33, [33]),
+                             (dict(ice="full", ns="tripole"), 26, [9, 17])]:
         case, d, f = util.make_case(130, 96, 130, 96, **kw)
         xmin = synth.global_min_dx(case)
         outs = []
