@@ -494,8 +494,8 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->use_double = !(e && atoi(e) == 0) && s.nxl >= 4;
         if (g->ns_boundary == EVPK_BND_TRIPOLE) {
             // the fold mixes mirrored columns between the two fused subcycles: only the rows next to the fold are affected,
-            // they are redone by band launches (single rank only; x-slabs would need the fold all-gather in between)
-            c->band_mode = c->use_double = c->use_double && g->nranks == 1 && !c->force_exchange && s.nyl >= 8;
+            // they are redone by band launches (x-slabs: without the edge/interior overlap, the fold all-gathers in between)
+            c->band_mode = c->use_double = c->use_double && s.nyl >= 8;
         }
         std::vector<int> band(c->ncx);
         for (int k = 0; k < c->ncx; k++) band[k] = k;
@@ -729,7 +729,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics)
-        if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte && c->zone_mode && c->overlap) {
+        if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte && c->zone_mode && c->overlap && !c->band_mode) {
             // x-slabs: edge strips first on `stream`, then the exchange of the two edge columns there, while the interior
             // strips run on `stream2`.  Step k's kernels need exchange k-1 (ghost zones of the buffer they read) and all of
             // step k-1's kernels; the exchange writes ghost zones of the buffer being WRITTEN, which no kernel of step k reads.

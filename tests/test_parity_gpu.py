@@ -147,9 +147,9 @@ def test_forced_exchange_path(ns, monkeypatch):
     monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
     _both(48, 40, 12, 10, ns=ns, land="continents", ndte=40, ncalls=2)
     _both(100, 116, 25, 29, ns=ns, land="continents", ndte=30)
-    if ns == "open":      # the two-subcycle kernel with two-column ghost zones filled by the exchange, several strips wide
-        _both(200, 96, 50, 48, ns=ns, ice="full", ndte=31, ncalls=2)
-        _both(200, 96, 50, 48, ns=ns, land="continents", ndte=24, revised_evp=True)
+    # the two-subcycle kernel with two-column ghost zones filled by the exchange, several strips wide
+    _both(200, 96, 50, 48, ns=ns, ice="full", ndte=31, ncalls=2)
+    _both(200, 96, 50, 48, ns=ns, land="continents", ndte=24, revised_evp=True)
 
 
 def test_two_subcycle_kernel_equals_single(monkeypatch):
