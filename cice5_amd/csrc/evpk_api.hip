@@ -912,6 +912,16 @@ extern "C" int evpk_run(evpk_ctx *c, const evpk_step_in *in, evpk_state *st) {
     return evpk_download(c, st);
 }
 
+extern "C" int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2) {
+    if (!c || !sig1 || !sig2) return 1;
+    if (!c->prepped) FAIL(c, "evpk_principal_stress needs the state of a finished evp on the device");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_principal_stress, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, c->cur ? (int)F_STATE1 : (int)F_STATE0);
+    HIPCHK(c, hipGetLastError());
+    if (download_f(c, sig1, F_WORK1, MODE_PHYS)) return 1;
+    return download_f(c, sig2, F_WORK2, MODE_PHYS);
+}
+
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
     if (!c) return 1;
     HIPCHK(c, hipSetDevice(c->device));

@@ -1041,4 +1041,22 @@ __global__ void k_finish(Slab s, DevParams p, int cur) {
     FD(s, F_WORK2, k) = yT;
 }
 
+// ------------------------------------------------------------------------------------
+// principal_stress (ice_dyn_shared.F90:853-893): normalised principal stresses of the NE corner,
+// from the resident sigma_1 planes and prs_sig; written into the two work planes
+// ------------------------------------------------------------------------------------
+__global__ void k_principal_stress(Slab s, int SB) {
+    SLAB_IJ_ALL
+    const double puny = 1.0e-11, spval_dbl = 1.0e30;
+    const double sp = FD(s, SB + S_SP, k), sm = FD(s, SB + S_SM, k), s12 = FD(s, SB + S_S12, k), prs = FD(s, F_PRSSIG, k);
+    double s1 = spval_dbl, s2 = spval_dbl;
+    if (prs > puny) {
+        const double r = sqrt(sm * sm + 4.0 * (s12 * s12));
+        s1 = (0.5 * (sp + r)) / prs;
+        s2 = (0.5 * (sp - r)) / prs;
+    }
+    FD(s, F_WORK1, k) = s1;
+    FD(s, F_WORK2, k) = s2;
+}
+
 }  // namespace evpk

@@ -94,5 +94,12 @@ class EvpDynamics:
             self.set_evp_parameters(dt)        # :153-154 ("needed only if dt changes during runtime")
         self.ctx.run(self.fields)
 
+    def principal_stress(self):
+        """ice_dyn_shared.F90:853: (sig1, sig2) block arrays from the state of the last evp() (physical cells)."""
+        shp = self.fields["uvel"].shape
+        sig1, sig2 = np.zeros(shp), np.zeros(shp)
+        self.ctx.principal_stress(sig1, sig2)
+        return sig1, sig2
+
     def close(self):
         self.ctx.close()

@@ -72,7 +72,7 @@ class Stats(ct.Structure):
 
 EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",
            "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
-           "evpk_last_error", "evpk_slab_layout", "evpk_calibrate"]
+           "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress"]
 
 _lib = None
 
@@ -103,6 +103,7 @@ def lib():
         L.evpk_get_stats.argtypes = [ctxp, ct.POINTER(Stats)]
         L.evpk_destroy.argtypes = [ctxp]
         L.evpk_calibrate.argtypes = [ctxp, ct.c_int32]
+        L.evpk_principal_stress.argtypes = [ctxp, c_f64p, c_f64p]
         L.evpk_last_error.argtypes = [ctxp]
         L.evpk_last_error.restype = ct.c_char_p
         L.evpk_slab_layout.argtypes = [ct.c_int32] * 6 + [c_i32p]
@@ -226,6 +227,9 @@ class Context:
         s = Stats()
         self._chk(self._L.evpk_get_stats(self._ctx, ct.byref(s)), "evpk_get_stats")
         return s
+
+    def principal_stress(self, sig1: np.ndarray, sig2: np.ndarray):
+        self._chk(self._L.evpk_principal_stress(self._ctx, _p64(sig1), _p64(sig2)), "evpk_principal_stress")
 
     def calibrate(self, nrep: int = 3):
         self._chk(self._L.evpk_calibrate(self._ctx, int(nrep)), "evpk_calibrate")

@@ -74,7 +74,8 @@
       end type evpk_stats
 
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &
-                evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string
+                evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string, &
+                evpk_principal_stress
 
       interface
          integer (c_int) function evpk_get_unique_id (id) bind(C, name='evpk_get_unique_id')
@@ -101,6 +102,11 @@
             import :: c_int, c_ptr, evpk_stats
             type (c_ptr), value :: ctx
             type (evpk_stats), intent(out) :: s
+         end function
+         ! principal_stress (ice_dyn_shared.F90:853) from the device-resident state of the last evp
+         integer (c_int) function evpk_principal_stress (ctx, sig1, sig2) bind(C, name='evpk_principal_stress')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ctx, sig1, sig2
          end function
          integer (c_int) function evpk_destroy (ctx) bind(C, name='evpk_destroy')
             import :: c_int, c_ptr

@@ -143,6 +143,11 @@ int evpk_sync(evpk_ctx *c);
 
 int evpk_get_stats(evpk_ctx *c, evpk_stats *s);
 
+/* principal_stress (ice_dyn_shared.F90:853-893; called by ice_history for sig1/sig2): normalised principal
+ * stresses from the sigma_1 planes and prs_sig resident on the device after evpk_finish / evpk_run.
+ * Physical cells of sig1, sig2 (block arrays) are written. */
+int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
+
 /* Profiling aid: nrep device-to-device copies of one scratch pair plane with the hot kernel's access
  * shape (16 B per lane, coalesced).  Each moves exactly (nxl+2)*(nyl+2)*16 bytes each way: a known
  * byte count in the PMC trace to calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */

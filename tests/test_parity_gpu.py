@@ -239,6 +239,42 @@ def test_device_resident_steps_inputs_only_upload(mode, monkeypatch):
     s.close()
 
 
+def test_principal_stress():
+    """ice_dyn_shared.F90:853-893 on the device-resident state vs the oracle on the downloaded arrays."""
+    import ctypes as ct
+    case, d, f = util.make_case(100, 116, 50, 58, land="continents")
+    xmin = synth.global_min_dx(case)
+    s = dyn.EvpDynamics(d, f, ndte=40, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    g1, g2 = s.principal_stress()
+    s.close()
+    o1, o2 = np.zeros_like(g1), np.zeros_like(g2)
+    for n in range(d.nblocks):
+        orc.lib().orc_principal_stress(d.nx_block, d.ny_block, *[x[n].ctypes.data_as(orc.c_f64p) for x in
+                                       (f["stressp_1"], f["stressm_1"], f["stress12_1"], f["prs_sig"])],
+                                       o1[n].ctypes.data_as(orc.c_f64p), o2[n].ctypes.data_as(orc.c_f64p))
+    m = util.cell_mask(d, "phys")
+    assert np.array_equal(g1[m], o1[m]) and np.array_equal(g2[m], o2[m])
+    assert (g1[m] < 1e29).sum() > 100
+
+
+def test_context_create_destroy_many_times():
+    case, d, f = util.make_case(100, 116, 50, 58, land="continents")
+    xmin = synth.global_min_dx(case)
+    ref = None
+    for k in range(12):
+        g = util.clone(f)
+        s = dyn.EvpDynamics(d, g, ndte=6, xmin=xmin)
+        s.init_evp(3600.0)
+        s.evp(3600.0)
+        s.close()
+        if ref is None:
+            ref = g
+        else:
+            assert not util.compare(d, g, ref)
+
+
 def test_errors_are_reported_not_fatal():
     case, d, f = util.make_case(100, 116, 100, 116)
     ctx = evpk.Context(d, f)
