@@ -78,7 +78,9 @@ struct evpk_ctx {
     float loop_ms = 0.f, kernel_ms = 0.f, kernel2_ms = 0.f;
     int kernel_launches = 0;
     std::vector<char> kev_is_double;
-    bool time_kernels = true;      // HIP events around every subcycle kernel launch (EVPK_TIME_KERNELS=0 disables)
+    int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around every 8th subcycle kernel launch (default), 2 all
+    std::vector<int> kev_slot;     // launch index -> event pair index, -1 not timed
+    int nkev = 0;
     bool force_exchange = false;   // EVPK_FORCE_EXCHANGE=1: single rank takes the multi-rank pack/exchange/unpack path (tests)
     std::string err;
 };
@@ -503,7 +505,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         HIPCHK(c, hipMemcpy(c->d_band, band.data(), sizeof(int) * c->ncx, hipMemcpyHostToDevice));
     }
     const char *tk = getenv("EVPK_TIME_KERNELS");
-    c->time_kernels = !(tk && atoi(tk) == 0);
+    c->time_kernels = tk ? std::max(0, std::min(atoi(tk), 2)) : 1;
     return 0;
 }
 
@@ -716,8 +718,23 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     c->kernel_launches = 0;
     c->kev_is_double.assign((size_t)nsub + 1, 0);
     if (c->time_kernels) {
-        while ((int)c->kev.size() < 2 * nsub) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
+        while ((int)c->kev.size() < 2 * nsub + 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
     }
+    c->kev_slot.assign((size_t)nsub + 1, -1);
+    c->nkev = 0;
+    // event pairs cost ~8 us per launch: by default only every 8th launch is timed (the launches are alike)
+    auto timed = [&](int launch) { return c->time_kernels == 2 || (c->time_kernels == 1 && (launch & 7) == 3); };
+    auto ev_begin = [&](hipStream_t st) -> int {
+        if (!timed(c->kernel_launches)) return 0;
+        c->kev_slot[c->kernel_launches] = c->nkev;
+        return hipEventRecord(c->kev[2 * c->nkev], st) != hipSuccess;
+    };
+    auto ev_end = [&](hipStream_t st) -> int {
+        if (c->kev_slot[c->kernel_launches] < 0) return 0;
+        const int rc = hipEventRecord(c->kev[2 * c->nkev + 1], st) != hipSuccess;
+        c->nkev++;
+        return rc;
+    };
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->double_launches = 0;
     bool in_overlap = false;
@@ -751,10 +768,10 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             if (c->nstrips2i > 0) {
                 a.strips = c->d_strips2i; a.nstrips = c->nstrips2i;
                 const dim3 g((((c->nstrips2i + 3) / 4 + 7) / 8) * 8), b(256);
-                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches], c->stream2));
+                if (ev_begin(c->stream2)) FAIL(c, "hipEventRecord failed");
                 if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream2, a);
                 else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream2, a);
-                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches + 1], c->stream2));
+                if (ev_end(c->stream2)) FAIL(c, "hipEventRecord failed");
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;
                 c->double_launches++;
@@ -776,10 +793,10 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             if (c->nstrips2 > 0) {
                 const dim3 g((((c->nstrips2 + 3) / 4 + 7) / 8) * 8), b(256);
-                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches], c->stream));
+                if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
                 if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream, a);
                 else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream, a);
-                if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches + 1], c->stream));
+                if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;
                 c->double_launches++;
@@ -813,12 +830,12 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         const bool last = (c->ksub == c->p.ndte);
         if (c->nstrips > 0) {
             const dim3 g((((c->nstrips + 3) / 4 + 7) / 8) * 8), b(256);   // multiple of 8: see the XCD remap in k_subcycle
-            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches], c->stream));
+            if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
             if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, c->stream, a);
             else if (last) hipLaunchKernelGGL((k_subcycle<true, false>), g, b, 0, c->stream, a);
             else if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, a);
             else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, a);
-            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * c->kernel_launches + 1], c->stream));
+            if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
             c->kernel_launches++;
         }
         c->cur ^= 1;
@@ -832,11 +849,18 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
     if (c->time_kernels) {
+        // mean of the timed launches of each kind, scaled to all launches of that kind
+        double sum1 = 0.0, sum2 = 0.0;
+        int n1 = 0, n2 = 0;
         for (int n = 0; n < c->kernel_launches; n++) {
+            const int k = c->kev_slot[n];
+            if (k < 0) continue;
             float ms = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&ms, c->kev[2 * n], c->kev[2 * n + 1]));
-            if (c->kev_is_double[n]) c->kernel2_ms += ms; else c->kernel_ms += ms;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->kev[2 * k], c->kev[2 * k + 1]));
+            if (c->kev_is_double[n]) { sum2 += ms; n2++; } else { sum1 += ms; n1++; }
         }
+        if (n2) c->kernel2_ms = (float)(sum2 / n2 * c->double_launches);
+        if (n1) c->kernel_ms = (float)(sum1 / n1 * (c->kernel_launches - c->double_launches));
     }
     return 0;
 }
