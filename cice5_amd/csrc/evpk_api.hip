@@ -9,6 +9,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +31,84 @@
 using namespace evpk;
 
 static thread_local std::string g_create_err;
+
+// ------------------------------------------------------------------------------------------------------
+// Host-staged shared-memory relay: a second transport with the semantics of the RCCL point-to-point calls
+// (ordered messages per (src, dst) pair), so that several ranks can run the real multi-rank code path on
+// ONE GPU in tests (RCCL refuses two ranks on one device).  Selected by a unique id that starts with
+// "EVPKSHM:<name>".  One mailbox of depth 1 per ordered pair in a POSIX shared-memory segment.
+// ------------------------------------------------------------------------------------------------------
+struct ShmRelay {
+    int rank = 0, nranks = 0;
+    size_t slot = 0, total = 0;
+    char *base = nullptr;
+    std::string name;
+    std::vector<char> host;
+    struct Box { uint64_t wr, rd; char pad[48]; };
+    static constexpr size_t HDR = 64;
+    Box *box(int src, int dst) const { return reinterpret_cast<Box *>(base + HDR + ((size_t)src * nranks + dst) * (sizeof(Box) + slot)); }
+    char *payload(int src, int dst) const { return reinterpret_cast<char *>(box(src, dst)) + sizeof(Box); }
+    static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+    template <typename F> bool wait(F ready) const {
+        const double t0 = now();
+        for (long k = 0; !ready(); k++) {
+            if ((k & 63) == 63) { sched_yield(); if (now() - t0 > 120.0) return false; }
+        }
+        return true;
+    }
+    int open(const std::string &nm, int r, int n, size_t slot_bytes, std::string &err) {
+        rank = r; nranks = n; slot = (slot_bytes + 63) & ~size_t(63); name = "/" + nm;
+        total = HDR + (size_t)n * n * (sizeof(Box) + slot);
+        int fd = -1;
+        if (r == 0) {
+            shm_unlink(name.c_str());
+            fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)total) != 0) { err = "shm relay: cannot create " + name; return 1; }
+        } else {
+            const double t0 = now();
+            while ((fd = shm_open(name.c_str(), O_RDWR, 0600)) < 0) {
+                usleep(1000);
+                if (now() - t0 > 120.0) { err = "shm relay: timeout opening " + name; return 1; }
+            }
+            struct stat st;
+            while (fstat(fd, &st) == 0 && (size_t)st.st_size < total) {
+                usleep(1000);
+                if (now() - t0 > 120.0) { err = "shm relay: segment never sized"; return 1; }
+            }
+        }
+        base = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (base == MAP_FAILED) { base = nullptr; err = "shm relay: mmap failed"; return 1; }
+        uint64_t *magic = reinterpret_cast<uint64_t *>(base);
+        if (r == 0) { memset(base, 0, HDR + (size_t)n * n * sizeof(Box)); for (int a = 0; a < n * n; a++) { Box *b = box(a / n, a % n); b->wr = b->rd = 0; } __atomic_store_n(magic, 0x4556504bULL, __ATOMIC_RELEASE); }
+        else if (!wait([&] { return __atomic_load_n(magic, __ATOMIC_ACQUIRE) == 0x4556504bULL; })) { err = "shm relay: rank 0 never initialised the segment"; return 1; }
+        host.resize(slot);
+        return 0;
+    }
+    void close_() {
+        if (base) munmap(base, total);
+        base = nullptr;
+        if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
+    }
+    int send(int dst, const void *dev, size_t bytes, hipStream_t st) {
+        if (bytes > slot) return 1;
+        if (hipMemcpyAsync(host.data(), dev, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+        Box *b = box(rank, dst);
+        if (!wait([&] { return __atomic_load_n(&b->rd, __ATOMIC_ACQUIRE) == __atomic_load_n(&b->wr, __ATOMIC_RELAXED); })) return 2;
+        memcpy(payload(rank, dst), host.data(), bytes);
+        __atomic_store_n(&b->wr, b->wr + 1, __ATOMIC_RELEASE);
+        return 0;
+    }
+    int recv(int src, void *dev, size_t bytes, hipStream_t st) {
+        if (bytes > slot) return 1;
+        Box *b = box(src, rank);
+        if (!wait([&] { return __atomic_load_n(&b->wr, __ATOMIC_ACQUIRE) > __atomic_load_n(&b->rd, __ATOMIC_RELAXED); })) return 2;
+        memcpy(host.data(), payload(src, rank), bytes);
+        __atomic_store_n(&b->rd, b->rd + 1, __ATOMIC_RELEASE);
+        if (hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+        return 0;
+    }
+};
 
 struct evpk_ctx {
     Slab s{};
@@ -45,6 +130,7 @@ struct evpk_ctx {
     int nstrips2e = 0, nstrips2i = 0;
     bool overlap = true;
     ncclComm_t comm = nullptr;
+    ShmRelay *relay = nullptr;      // test transport instead of RCCL (unique id "EVPKSHM:<name>")
     double *stage = nullptr;   // nblocks*nyb*nxb doubles (also reused as int32)
     size_t stage_n = 0;
     // strips
@@ -179,6 +265,53 @@ static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int 
     return 0;
 }
 
+// ---- transport primitives (device pointers, ordered on c->stream) -----------------------------------
+// ring exchange with the west / east neighbour: n doubles each way.  With two ranks on a cyclic ring the
+// neighbours coincide and one message [sW | sE] goes each way, received as [rE | rW] (buffers contiguous).
+static int xp_ring(evpk_ctx *c, const double *sW, const double *sE, double *rE, double *rW, size_t n) {
+    const bool merged = (c->west == c->east && c->west >= 0);
+    if (c->relay) {
+        int rc = 0;
+        if (merged) {
+            rc |= c->relay->send(c->west, sW, 2 * n * 8, c->stream);
+            rc |= c->relay->recv(c->west, rE, 2 * n * 8, c->stream);
+        } else {
+            if (c->west >= 0) rc |= c->relay->send(c->west, sW, n * 8, c->stream);
+            if (c->east >= 0) rc |= c->relay->send(c->east, sE, n * 8, c->stream);
+            if (c->east >= 0) rc |= c->relay->recv(c->east, rE, n * 8, c->stream);
+            if (c->west >= 0) rc |= c->relay->recv(c->west, rW, n * 8, c->stream);
+        }
+        if (rc) FAIL(c, "shared-memory relay: exchange failed (%s)", rc & 2 ? "timeout" : "copy / size");
+        return 0;
+    }
+    NCCLCHK(c, ncclGroupStart());
+    if (merged) {
+        NCCLCHK(c, ncclSend(sW, 2 * n, ncclDouble, c->west, c->comm, c->stream));
+        NCCLCHK(c, ncclRecv(rE, 2 * n, ncclDouble, c->west, c->comm, c->stream));
+    } else {
+        if (c->west >= 0) NCCLCHK(c, ncclSend(sW, n, ncclDouble, c->west, c->comm, c->stream));
+        if (c->east >= 0) NCCLCHK(c, ncclSend(sE, n, ncclDouble, c->east, c->comm, c->stream));
+        if (c->east >= 0) NCCLCHK(c, ncclRecv(rE, n, ncclDouble, c->east, c->comm, c->stream));
+        if (c->west >= 0) NCCLCHK(c, ncclRecv(rW, n, ncclDouble, c->west, c->comm, c->stream));
+    }
+    NCCLCHK(c, ncclGroupEnd());
+    return 0;
+}
+
+// all-gather of `bytes` per rank (multiple of 4) into dst[rank*bytes ...]
+static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes) {
+    if (c->relay) {
+        int rc = 0;
+        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->send(r, src, bytes, c->stream);
+        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->recv(r, (char *)dst + (size_t)r * bytes, bytes, c->stream);
+        if (rc) FAIL(c, "shared-memory relay: all-gather failed");
+        HIPCHK(c, hipMemcpyAsync((char *)dst + (size_t)c->rank * bytes, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    NCCLCHK(c, ncclAllGather(src, dst, bytes / 4, ncclInt32, c->comm, c->stream));
+    return 0;
+}
+
 // ---- halo update of nf consecutive planes starting at f ---------------------------------
 // fsrc_fold >= 0: ice_HaloUpdate_stress variant (only the tripole north ghost row of the
 // destination planes is written, from the top physical row of the source planes).
@@ -201,9 +334,9 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
             Slab t = s; t.nxg = c->wmax;   // local segment addressed with gofs = 0
             hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, fp, nf, c->foldloc, 0);
             const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
-            if (c->nranks > 1)
-                NCCLCHK(c, ncclAllGather(c->foldloc, c->foldall, seg, ncclDouble, c->comm, c->stream));
-            else
+            if (c->nranks > 1) {
+                if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
+            } else
                 HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
             for (int r = 0; r < c->nranks; r++) {
                 const int w = c->slab_i0[r + 1] - c->slab_i0[r];
@@ -236,19 +369,8 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
                 HIPCHK(c, hipMemcpyAsync(c->recvE, c->sendW, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
                 HIPCHK(c, hipMemcpyAsync(c->recvW, c->sendE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
             }
-        } else if (c->west == c->east && c->west >= 0) {
-            // two ranks on a cyclic ring: one message each way carries both edges
-            NCCLCHK(c, ncclGroupStart());
-            NCCLCHK(c, ncclSend(c->sendbuf, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
-            NCCLCHK(c, ncclRecv(c->recvbuf, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
-            NCCLCHK(c, ncclGroupEnd());
         } else {
-            NCCLCHK(c, ncclGroupStart());
-            if (c->west >= 0) NCCLCHK(c, ncclSend(c->sendW, cnt, ncclDouble, c->west, c->comm, c->stream));
-            if (c->east >= 0) NCCLCHK(c, ncclSend(c->sendE, cnt, ncclDouble, c->east, c->comm, c->stream));
-            if (c->east >= 0) NCCLCHK(c, ncclRecv(c->recvE, cnt, ncclDouble, c->east, c->comm, c->stream));
-            if (c->west >= 0) NCCLCHK(c, ncclRecv(c->recvW, cnt, ncclDouble, c->west, c->comm, c->stream));
-            NCCLCHK(c, ncclGroupEnd());
+            if (xp_ring(c, c->sendW, c->sendE, c->recvE, c->recvW, cnt)) return 1;
         }
         hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->recvW,
                            (const double *)c->recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
@@ -271,19 +393,8 @@ static int exchange_cols(evpk_ctx *c, const PairList &pl) {
             HIPCHK(c, hipMemcpyAsync(recvE, sendW, sizeof(double2) * cnt, hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(recvW, sendE, sizeof(double2) * cnt, hipMemcpyDeviceToDevice, c->stream));
         }
-    } else if (c->west == c->east && c->west >= 0) {
-        // two ranks on a cyclic ring: [W cols | E cols] in one message each way, received as [east ghost | west ghost]
-        NCCLCHK(c, ncclGroupStart());
-        NCCLCHK(c, ncclSend(sendW, 4 * cnt, ncclDouble, c->west, c->comm, c->stream));
-        NCCLCHK(c, ncclRecv(recvE, 4 * cnt, ncclDouble, c->west, c->comm, c->stream));
-        NCCLCHK(c, ncclGroupEnd());
     } else {
-        NCCLCHK(c, ncclGroupStart());
-        if (c->west >= 0) NCCLCHK(c, ncclSend(sendW, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
-        if (c->east >= 0) NCCLCHK(c, ncclSend(sendE, 2 * cnt, ncclDouble, c->east, c->comm, c->stream));
-        if (c->east >= 0) NCCLCHK(c, ncclRecv(recvE, 2 * cnt, ncclDouble, c->east, c->comm, c->stream));
-        if (c->west >= 0) NCCLCHK(c, ncclRecv(recvW, 2 * cnt, ncclDouble, c->west, c->comm, c->stream));
-        NCCLCHK(c, ncclGroupEnd());
+        if (xp_ring(c, (const double *)sendW, (const double *)sendE, (double *)recvE, (double *)recvW, 2 * cnt)) return 1;
     }
     hipLaunchKernelGGL(k_cols_unpack, dim3(grow), dim3(tx), 0, c->stream, s, pl, (const double2 *)recvW, (const double2 *)recvE,
                        c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0);
@@ -301,6 +412,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    if (c->relay) { c->relay->close_(); delete c->relay; }
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
                     c->d_strips, c->d_counts, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -441,15 +553,27 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
 
     if (g->nranks > 1) {
         if (!g->unique_id) FAIL(c, "nranks > 1 needs unique_id");
-        ncclUniqueId u;
-        memcpy(&u, g->unique_id, sizeof(u));
-        NCCLCHK(c, ncclCommInitRank(&c->comm, g->nranks, u, g->rank));
+        if (strncmp((const char *)g->unique_id, "EVPKSHM:", 8) == 0) {
+            // test transport: host-staged relay through POSIX shared memory (several ranks on one GPU)
+            char nm[EVPK_UNIQUE_ID_BYTES + 1];
+            memcpy(nm, (const char *)g->unique_id + 8, EVPK_UNIQUE_ID_BYTES - 8);
+            nm[EVPK_UNIQUE_ID_BYTES - 8] = 0;
+            const size_t slot = std::max<size_t>((size_t)4 * c->cslot * sizeof(double2) / 2,
+                                                 (size_t)c->max_nf * 2 * (size_t)g->nx_global * sizeof(double)) + 4096;
+            c->relay = new ShmRelay();
+            std::string err;
+            if (c->relay->open(nm, g->rank, g->nranks, slot, err)) FAIL(c, "%s", err.c_str());
+        } else {
+            ncclUniqueId u;
+            memcpy(&u, g->unique_id, sizeof(u));
+            NCCLCHK(c, ncclCommInitRank(&c->comm, g->nranks, u, g->rank));
+        }
         // every rank learns all slab starts (for the tripole fold) : all-gather of i0
         int *d_i0 = nullptr, *d_all = nullptr;
         HIPCHK(c, hipMalloc(&d_i0, sizeof(int)));
         HIPCHK(c, hipMalloc(&d_all, sizeof(int) * g->nranks));
         HIPCHK(c, hipMemcpyAsync(d_i0, &i0, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        NCCLCHK(c, ncclAllGather(d_i0, d_all, 1, ncclInt32, c->comm, c->stream));
+        if (xp_allgather(c, d_i0, d_all, sizeof(int))) return 1;
         c->slab_i0.resize(g->nranks + 1);
         HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * g->nranks, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -772,6 +896,10 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream2, a);
                 else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream2, a);
                 if (ev_end(c->stream2)) FAIL(c, "hipEventRecord failed");
+                c->kev_is_double[c->kernel_launches] = 1;
+                c->kernel_launches++;
+                c->double_launches++;
+            } else if (c->nstrips2e > 0) {      // all strips are edge strips (narrow slab): count the step once
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;
                 c->double_launches++;

@@ -1,0 +1,106 @@
+"""Real multi-rank runs of libevpk on ONE GPU: K processes, each with its own x-slab and context, exchanging
+through the host-staged shared-memory relay (unique id "EVPKSHM:<name>") that stands in for the RCCL
+point-to-point calls, which refuse several ranks on one device.  Everything else is the production
+multi-rank path: slabs with i0 > 1, edge-column / two-column ghost-zone exchange, the edge-first overlap on two
+streams, the tripole fold through the all-gather.  Each rank compares its slab with the single-process oracle."""
+import os
+import sys
+import traceback
+import uuid
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
+    try:
+        import time
+        t0 = time.time()
+        sys.path.insert(0, ROOT)
+        os.environ.update(env)
+        os.environ["OMP_NUM_THREADS"] = "2"
+        from cice5_amd import blocks, constants as C, dyn, synth
+        from oracle import orc
+        from tests import util
+
+        case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[ns], land="continents")
+        d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=ns)
+        f = synth.make_block_fields(case, d)
+        xmin = synth.global_min_dx(case)
+        uid = (b"EVPKSHM:" + tag.encode()).ljust(128, b"\0")
+        s = dyn.EvpDynamics(d, f, ndte=ndte, xmin=xmin, device=0, unique_id=uid)
+        s.init_evp(3600.0)
+        # reference: whole domain, same block size, in this process
+        d1 = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns)
+        f1 = synth.make_block_fields(case, d1)
+        p = orc.make_params(3600.0, ndte, xmin)
+        bad = []
+        for call in range(2):
+            if call:
+                for ff in (f, f1):
+                    ff["aice"] *= 0.97
+                    ff["vice"] *= 0.97
+                    ff["strairxT"], ff["strairyT"] = ff["strairyT"].copy(), -ff["strairxT"]
+            s.evp(3600.0)
+            orc.evp(d1, p, f1)
+            ref = {}
+            for n, b in enumerate(d.local_blocks):
+                n1 = next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id)
+                for name in util.ALL_CELLS + util.NE_CELLS + util.PHYS_CELLS:
+                    ref.setdefault(name, np.zeros_like(f[name]))[n] = f1[name][n1]
+            bad += [(call,) + x for x in util.compare(d, f, ref)]
+        st = s.ctx.stats()
+        s.close()
+        q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()), time.time() - t0))
+    except Exception:
+        q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0))
+
+
+def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    tag = "evpk_t_" + uuid.uuid4().hex[:12]
+    procs = [ctx.Process(target=_worker, args=(r, world, tag, ns, nx, ny, bsx, bsy, ndte, env or {}, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=600))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+        try:
+            os.unlink("/dev/shm/" + tag)
+        except OSError:
+            pass
+    assert len(res) == world
+    for rank, bad, icellu, k2, umax, secs in res:
+        assert not bad, f"rank {rank}: {bad}"
+    assert max(r[4] for r in res) > 1e-3
+    print(f"[{world} ranks {ns}] worker seconds: {[round(r[5], 1) for r in res]}")
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_x_slabs_open(world):
+    res = _run(world, "open", 240, 64, 20, 32, ndte=31)
+    assert all(r[3] > 0 for r in res)          # the two-subcycle kernel ran on every rank (ghost-zone mode)
+
+
+def test_x_slabs_tripole():
+    _run(2, "tripole", 240, 64, 20, 32, ndte=24)
+    _run(4, "tripole", 240, 64, 30, 16, ndte=13)
+
+
+def test_x_slabs_one_subcycle_kernel_and_serial_exchange():
+    _run(3, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"})
+    _run(2, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_OVERLAP": "0"})
+    _run(2, "tripole", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"})
