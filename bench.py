@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--xblocks", type=int, default=8, help="blocks across x (one slab each at 8 GPUs)")
     ap.add_argument("--yblocks", type=int, default=10, help="blocks across y")
     ap.add_argument("--cpu-subcycles", type=int, default=120, help="subcycles of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"],
+                    help="shm: host-staged shared-memory relay (functional check of the multi-rank path on one GPU, not a measurement)")
     ap.add_argument("--calib", type=int, default=0, help="untimed calibration copies for rocprofv3 --pmc runs")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_subcycle launch from a separate rocprofv3 --pmc pass (profiles/)")
@@ -74,7 +76,10 @@ def main():
         # torch.distributed is only the control plane here (rendezvous, barrier, scalar reductions, the 128-byte
         # RCCL id): gloo on CPU tensors.  The data plane is libevpk's own RCCL communicator (ncclSend/ncclRecv over xGMI).
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        box = [evpk.get_unique_id() if rank == 0 else None]
+        if a.transport == "shm":
+            box = [(b"EVPKSHM:evpk_bench_%d" % os.getpid()).ljust(128, b"\0") if rank == 0 else None]
+        else:
+            box = [evpk.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
 
