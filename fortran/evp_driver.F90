@@ -19,6 +19,9 @@
       use ice_atmo
       use ice_dyn_shared
       use ice_dyn_evp, only: evp
+#ifdef AusCOM
+      use cpl_arrays_setup, only: sicemass
+#endif
 
       implicit none
       character (len=512) :: fin, fout
@@ -82,9 +85,15 @@
       allocate (aicen(nx_block,ny_block,1,nb), vicen(nx_block,ny_block,1,nb))
       aicen = 0.0_dbl_kind; vicen = 0.0_dbl_kind
 
+#ifdef AusCOM
+      allocate (sicemass(nx_block,ny_block,nb))     ! drivers/auscom/CICE_InitMod.F90 allocates it in the real model
+#endif
       do call_no = 1, ncalls
          call evp (dt)
       enddo
+#ifdef AusCOM
+      write (*,'(a,es12.5)') 'evp_driver: AusCOM sicemass max = ', maxval(sicemass)
+#endif
 
       open (11, file=trim(fout), access='stream', form='unformatted', status='replace')
       write (11) uvel, vvel, stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &

@@ -195,6 +195,19 @@
       end subroutine ice_strength
       end module ice_mechred
 
+      ! AusCOM coupling modules (drivers/auscom/cpl_parameters.F90, cpl_arrays_setup.F90): only what evp touches
+      module cpl_parameters
+      use ice_kinds_mod
+      implicit none
+      logical (kind=log_kind) :: use_ocnslope = .false., use_umask = .false.
+      end module cpl_parameters
+
+      module cpl_arrays_setup
+      use ice_kinds_mod
+      implicit none
+      real (kind=dbl_kind), dimension(:,:,:), allocatable :: sicemass
+      end module cpl_arrays_setup
+
       module ice_dyn_shared
       use ice_kinds_mod
       implicit none

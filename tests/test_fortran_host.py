@@ -50,7 +50,7 @@ def read_output(path, d):
 
 
 def test_fortran_driver_is_built_and_links_libevpk():
-    assert os.path.exists(DRIVER), "run __graft_entry__.build() (make -C fortran)"
+    assert os.path.exists(DRIVER) and os.path.exists(DRIVER + "_auscom"), "run __graft_entry__.build() (make -C fortran)"
     out = subprocess.run(["ldd", DRIVER], capture_output=True, text=True).stdout
     assert "libevpk.so" in out and "not found" not in out.split("libevpk.so")[1].split("\n")[0]
     src = open(os.path.join(ROOT, "fortran", "ice_dyn_evp.F90")).read()
@@ -69,16 +69,20 @@ def test_fortran_driver_aborts_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ns,bs,ncalls", [("open", (100, 116), 1), ("open", (25, 29), 2), ("tripole", (25, 29), 2)])
-def test_fortran_host_matches_oracle(tmp_path, ns, bs, ncalls):
-    """BASELINE config 1 shape (gx3-size 100x116, ndte=120) through the Fortran host."""
+@pytest.mark.parametrize("ns,bs,ncalls,driver", [("open", (100, 116), 1, DRIVER), ("open", (25, 29), 2, DRIVER),
+                                                 ("tripole", (25, 29), 2, DRIVER), ("open", (50, 58), 2, DRIVER + "_auscom")])
+def test_fortran_host_matches_oracle(tmp_path, ns, bs, ncalls, driver):
+    """BASELINE config 1 shape (gx3-size 100x116, ndte=120) through the Fortran host; the `_auscom` driver is the
+    same source compiled with -DAusCOM -DACCESS, the cpp flags the COSIMA fork needs (sicemass = tmass hook)."""
     case, d, f = util.make_case(100, 116, *bs, ns=ns, land="continents")
     xmin = synth.global_min_dx(case)
     p = dyn.set_evp_parameters(3600.0, 120, False, xmin)
     write_fixture(tmp_path / "in.bin", d, f, p, ncalls)
-    r = subprocess.run([DRIVER, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    r = subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "evp_driver:" in r.stdout
+    if driver.endswith("_auscom"):
+        assert "sicemass max" in r.stdout
     got = read_output(tmp_path / "out.bin", d)
     fo = util.clone(f)
     po = orc.make_params(3600.0, 120, xmin)
