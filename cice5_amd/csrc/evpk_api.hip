@@ -115,6 +115,8 @@ struct evpk_ctx {
     DevParams p{};
     bool have_params = false, uploaded = false, prepped = false;
     bool fresh = true;          // state planes were (re)loaded from the host since the last prep
+    unsigned char *tile_buf = nullptr;   // 6 tile-flag arrays: ice/dat x {A, B} (new / previous evp, swapped) + act_ice, act_any
+    int tile_cur = 0;
     bool zone_mode = false;     // k_subcycle2 reads two-column ghost zones filled by exchange_cols (x-slabs / forced exchange)
     int nxb = 0, nyb = 0, nblocks = 0;
     std::vector<BlockDesc> bd;
@@ -414,7 +416,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->relay) { c->relay->close_(); delete c->relay; }
     void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -491,6 +493,15 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipMemsetAsync(s.iceumask, 0, sizeof(int32_t) * nm, c->stream));
     HIPCHK(c, hipMemsetAsync(s.cmask, 0, nm, c->stream));
     HIPCHK(c, hipMemsetAsync(s.tmphm, 0, nm, c->stream));
+    s.ntx = (s.nxl + 2 + TILE_X - 1) / TILE_X;
+    s.nty = (s.nyl + 2 + TILE_Y - 1) / TILE_Y;
+    {
+        const size_t nt = (size_t)s.ntx * s.nty;
+        HIPCHK(c, hipMalloc(&c->tile_buf, 6 * nt));
+        HIPCHK(c, hipMemsetAsync(c->tile_buf, 1, 6 * nt, c->stream));
+        s.act_ice = c->tile_buf + 4 * nt;
+        s.act_any = c->tile_buf + 5 * nt;
+    }
     HIPCHK(c, hipMalloc(&c->d_bd, sizeof(BlockDesc) * g->nblocks));
     HIPCHK(c, hipMemcpyAsync(c->d_bd, c->bd.data(), sizeof(BlockDesc) * g->nblocks, hipMemcpyHostToDevice, c->stream));
     c->stage_n = (size_t)g->nblocks * g->ny_block * g->nx_block;
@@ -752,7 +763,14 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     const int SA = c->cur ? F_STATE1 : F_STATE0, SB = c->cur ? F_STATE0 : F_STATE1;   // current / other state buffer
     // evp_prep1 + zero diagnostics (ice_dyn_evp.F90:171-203)
     const int fresh = c->fresh ? 1 : 0;
+    const size_t ntile = (size_t)s.ntx * s.nty;
+    unsigned char *prev_ice = c->tile_buf + (size_t)(c->tile_cur ? 0 : 2) * ntile, *prev_dat = prev_ice + ntile;
+    s.tile_ice = c->tile_buf + (size_t)(c->tile_cur ? 2 : 0) * ntile;
+    s.tile_dat = s.tile_ice + ntile;
+    c->tile_cur ^= 1;
     hipLaunchKernelGGL(k_prep1a, g2, B2D, 0, c->stream, s, c->p, fresh);
+    hipLaunchKernelGGL(k_tile_dilate, dim3((s.ntx + 63) / 64, s.nty), dim3(64), 0, c->stream, s, (const unsigned char *)prev_ice,
+                       (const unsigned char *)prev_dat, fresh);
     hipLaunchKernelGGL(k_prep1b, g2, B2D, 0, c->stream, s);
     if (halo(c, F_ICETM, 1, false, false, 0.0)) return 1;                         // :210-211
     // to_ugrid (:218-219) and t2ugrid_vector (:240-241; the T-grid wind sits in the work planes)
@@ -1012,7 +1030,7 @@ extern "C" int evpk_finish(evpk_ctx *c) {
     }
     hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
     // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)
-    if (halo(c, F_WORK1, 2, true, true, 0.0)) return 1;
+    if (halo(c, F_WORK3, 2, true, true, 0.0)) return 1;
     hipLaunchKernelGGL(k_to_tgrid2, g2, B2D, 0, c->stream, s);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1070,8 +1088,8 @@ extern "C" int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2) {
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_principal_stress, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, c->cur ? (int)F_STATE1 : (int)F_STATE0);
     HIPCHK(c, hipGetLastError());
-    if (download_f(c, sig1, F_WORK1, MODE_PHYS)) return 1;
-    return download_f(c, sig2, F_WORK2, MODE_PHYS);
+    if (download_f(c, sig1, F_SIG1, MODE_PHYS)) return 1;
+    return download_f(c, sig2, F_SIG2, MODE_PHYS);
 }
 
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {

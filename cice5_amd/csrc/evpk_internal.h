@@ -34,7 +34,7 @@ enum Field : int {
     F_TAREAR, F_TAREA, F_UAREA, F_FCOR,
     F_AICE, F_VICE, F_VSNO, F_AICE_INIT, F_STRAIRXT, F_STRAIRYT, F_SSTLTX, F_SSTLTY, F_CW,
     F_TMASS, F_UMASS, F_AIU, F_STRAIRX, F_STRAIRY, F_STRTLTX, F_STRTLTY,
-    F_WORK1, F_WORK2, F_ICETM,
+    F_WORK1, F_WORK2, F_WORK3, F_WORK4, F_SIG1, F_SIG2, F_ICETM,
     F_DIVU, F_SHEAR, F_RDGCONV, F_RDGSHEAR, F_PRSSIG, F_STRINTX, F_STRINTY,
     F_STROCNX, F_STROCNY, F_STROCNXT, F_STROCNYT,
     F_COUNT
@@ -60,7 +60,13 @@ struct Slab {
     int nxg, nyg;
     int32_t *tmask, *umask, *iceumask;   // int planes, index mcell()
     unsigned char *cmask, *tmphm;        // byte planes, index mcell()
+    // activity of the 64x4-cell tiles the per-evp kernels work in (one thread block each): a tile with no ice / no data
+    // now and at the previous evp already holds its zeros and is skipped.  act_* are dilated by one tile.
+    unsigned char *tile_ice, *tile_dat;  // written by k_prep1a for this evp (undilated)
+    unsigned char *act_ice, *act_any;    // dilate(new | prev): ice-dependent kernels / everything
+    int ntx, nty;
 };
+constexpr int TILE_X = 64, TILE_Y = 4;
 
 // cell index inside pair plane 0; field f adds (f/2)*pitch
 __host__ __device__ inline size_t cell(const Slab &s, int i, int j) { return (size_t)j * s.rstride + C0 + i; }

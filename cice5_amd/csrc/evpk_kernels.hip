@@ -106,24 +106,47 @@ __global__ void k_fill_plane(Slab s, int f, double v) {
     const size_t km = mcell(s, i, j);                          \
     (void)km;
 
+#define TILE_SKIP(flags) if (!(flags)[blockIdx.y * s.ntx + blockIdx.x]) return;
+
 // ------------------------------------------------------------------------------------
 // evp_prep1 (ice_dyn_shared.F90:270-365) on the slab
 // ------------------------------------------------------------------------------------
 // `fresh` = the state planes were just uploaded from the host (anything may be non-zero anywhere).
 // Otherwise cells that were inactive at the previous prep still hold their zeros and are skipped.
 __global__ void k_prep1a(Slab s, DevParams p, int fresh) {
-    SLAB_IJ_ALL
-    const double vice = FD(s, F_VICE, k), vsno = FD(s, F_VSNO, k), aice = FD(s, F_AICE, k);
-    const bool tm = s.tmask[km] != 0;
-    double tmass = 0.0;
-    if (tm) tmass = (p.rhoi * vice + p.rhos * vsno);                              // :322-326
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const bool in = (i <= s.nxl + 1 && j <= s.nyl + 1);
+    const size_t k = in ? cell(s, i, j) : 0, km = in ? mcell(s, i, j) : 0;
+    double tmass = 0.0, wx = 0.0, wy = 0.0;
+    bool hm = false, dat = false;
+    if (in) {
+        const double vice = FD(s, F_VICE, k), vsno = FD(s, F_VSNO, k), aice = FD(s, F_AICE, k);
+        const bool tm = s.tmask[km] != 0;
+        if (tm) tmass = (p.rhoi * vice + p.rhos * vsno);                          // :322-326
+        hm = tm && (aice > p.a_min) && (tmass > p.m_min);                         // :331-332
+        wx = FD(s, F_STRAIRXT, k); wy = FD(s, F_STRAIRYT, k);
+        dat = (tmass != 0.0) || (aice != 0.0) || (FD(s, F_AICE_INIT, k) != 0.0) || (wx != 0.0) || (wy != 0.0);
+    }
+    // tile activity (block-uniform): nothing in, nothing in last time -> every output of this evp is already zero here
+    const int t = blockIdx.y * s.ntx + blockIdx.x;
+    const int any_ice = __syncthreads_or(hm ? 1 : 0), any_dat = __syncthreads_or(dat ? 1 : 0);
+    const bool edge = (blockIdx.x == 0 || blockIdx.x == (unsigned)s.ntx - 1 || blockIdx.y == 0 || blockIdx.y == (unsigned)s.nty - 1);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        s.tile_ice[t] = (any_ice || edge) ? 1 : 0;          // tiles touching the ghost ring always count as active
+        s.tile_dat[t] = (any_dat || edge) ? 1 : 0;
+    }
+    if (!in) return;
+    // s.act_any still holds the previous evp's dilated activity here (k_tile_dilate runs after this kernel): it also
+    // covers tiles that only border ice, whose T cells next to the ice carried diagnostics last time
+    if (!(any_dat || edge || fresh || s.act_any[t])) return;
     FD(s, F_TMASS, k) = tmass;
-    s.tmphm[km] = (tm && (aice > p.a_min) && (tmass > p.m_min)) ? 1 : 0;           // :331-332
+    s.tmphm[km] = hm ? 1 : 0;
     // :339-340 strairx = strairxT; the T->U average that follows (t2ugrid_vector) reads it from the
     // work planes, so the copy lands there directly; U-grid wind (ACCESS) goes straight to strairx/y
-    const int wx = p.wind_on_ugrid ? F_STRAIRX : F_WORK1, wy = p.wind_on_ugrid ? F_STRAIRY : F_WORK2;
-    FD(s, wx, k) = FD(s, F_STRAIRXT, k);
-    FD(s, wy, k) = FD(s, F_STRAIRYT, k);
+    const int fx = p.wind_on_ugrid ? F_STRAIRX : F_WORK1, fy = p.wind_on_ugrid ? F_STRAIRY : F_WORK2;
+    FD(s, fx, k) = wx;
+    FD(s, fy, k) = wy;
     // evp(): zero the diagnostics (ice_dyn_evp.F90:174-182); only T cells active last time can be non-zero
     if (fresh || (s.cmask[km] & CM_T)) {
         FD(s, F_RDGCONV, k) = 0.0; FD(s, F_RDGSHEAR, k) = 0.0; FD(s, F_DIVU, k) = 0.0;
@@ -131,7 +154,33 @@ __global__ void k_prep1a(Slab s, DevParams p, int fresh) {
     }
 }
 
+// act = dilate_3x3(new | prev) per tile; `fresh` (state just uploaded): everything is active
+__global__ void k_tile_dilate(Slab s, const unsigned char *prev_ice, const unsigned char *prev_dat, int fresh) {
+    const int tx = blockIdx.x * blockDim.x + threadIdx.x, ty = blockIdx.y;
+    if (tx >= s.ntx || ty >= s.nty) return;
+    int ice = fresh, any = fresh;
+    for (int dy = -1; dy <= 1 && !ice; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const int x = tx + dx, y = ty + dy;
+            if (x < 0 || x >= s.ntx || y < 0 || y >= s.nty) continue;
+            const int q = y * s.ntx + x;
+            ice |= s.tile_ice[q] | prev_ice[q];
+            any |= s.tile_dat[q] | prev_dat[q];
+        }
+    if (!ice) {     // the loop above stops early only when ice is set; finish `any` otherwise
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = tx + dx, y = ty + dy;
+                if (x < 0 || x >= s.ntx || y < 0 || y >= s.nty) continue;
+                any |= s.tile_dat[y * s.ntx + x] | prev_dat[y * s.ntx + x];
+            }
+    }
+    s.act_ice[ty * s.ntx + tx] = ice ? 1 : 0;
+    s.act_any[ty * s.ntx + tx] = (ice | any) ? 1 : 0;
+}
+
 __global__ void k_prep1b(Slab s) {
+    TILE_SKIP(s.act_ice)
     SLAB_IJ_ALL
     double m = 0.0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {                           // :350-363
@@ -145,24 +194,10 @@ __global__ void k_prep1b(Slab s) {
     FD(s, F_ICETM, k) = m;
 }
 
-// to_ugrid (ice_grid.F90:1834-1878): dst = 0 outside the physical cells
-__global__ void k_to_ugrid(Slab s, int fsrc, int fdst) {
-    SLAB_IJ_ALL
-    double r = 0.0;
-    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
-        const size_t ke = cell(s, i + 1, j), kn = cell(s, i, j + 1), kne = cell(s, i + 1, j + 1);
-#define W_(q) FD(s, fsrc, q)
-#define TA_(q) FD(s, F_TAREA, q)
-        r = 0.25 * (((W_(k) * TA_(k) + W_(ke) * TA_(ke)) + W_(kn) * TA_(kn)) + W_(kne) * TA_(kne)) / FD(s, F_UAREA, k);
-#undef W_
-#undef TA_
-    }
-    FD(s, fdst, k) = r;
-}
-
 // the four T->U averages of evp() in one pass: umass <- tmass, aiu <- aice_init (ice_dyn_evp.F90:218-219) and,
 // unless the wind is already on the U grid, strairx/y <- work1/2 (t2ugrid_vector, :240-241)
 __global__ void k_to_ugrid4(Slab s, int wind) {
+    TILE_SKIP(s.act_any)
     SLAB_IJ_ALL
     double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
@@ -182,14 +217,15 @@ __global__ void k_to_ugrid4(Slab s, int wind) {
 
 // the two U->T averages of u2tgrid_vector (ice_dyn_evp.F90:505-506): strocnxT/yT <- work1/2, physical cells
 __global__ void k_to_tgrid2(Slab s) {
+    TILE_SKIP(s.act_any)
     SLAB_IJ_ALL
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
         const size_t kw = cell(s, i - 1, j), ks = cell(s, i, j - 1), ksw = cell(s, i - 1, j - 1);
         const double u0 = FD(s, F_UAREA, k), u1 = FD(s, F_UAREA, kw), u2 = FD(s, F_UAREA, ks), u3 = FD(s, F_UAREA, ksw);
         const double ta = FD(s, F_TAREA, k);
 #define TG_(f) (0.25 * (((FD(s, f, k) * u0 + FD(s, f, kw) * u1) + FD(s, f, ks) * u2) + FD(s, f, ksw) * u3) / ta)
-        FD(s, F_STROCNXT, k) = TG_(F_WORK1);
-        FD(s, F_STROCNYT, k) = TG_(F_WORK2);
+        FD(s, F_STROCNXT, k) = TG_(F_WORK3);
+        FD(s, F_STROCNYT, k) = TG_(F_WORK4);
 #undef TG_
     }
 }
@@ -223,19 +259,6 @@ __global__ void k_rows_copy(Slab s, int fsrc, int fdst, int nf, int j0, int j1) 
     for (int q = 0; q < nf; q++) FD(s, fdst + q, k) = FD(s, fsrc + q, k);
 }
 
-// to_tgrid (ice_grid.F90:1924-1958): only physical cells of dst are written
-__global__ void k_to_tgrid(Slab s, int fsrc, int fdst) {
-    SLAB_IJ_ALL
-    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
-        const size_t kw = cell(s, i - 1, j), ks = cell(s, i, j - 1), ksw = cell(s, i - 1, j - 1);
-#define W_(q) FD(s, fsrc, q)
-#define UA_(q) FD(s, F_UAREA, q)
-        FD(s, fdst, k) = 0.25 * (((W_(k) * UA_(k) + W_(kw) * UA_(kw)) + W_(ks) * UA_(ks)) + W_(ksw) * UA_(ksw)) / FD(s, F_TAREA, k);
-#undef W_
-#undef UA_
-    }
-}
-
 // profiling aid: copy one pair plane with the hot kernel's access shape (16 B per lane, coalesced);
 // moves exactly (nxl+2)*(nyl+2)*16 bytes each way -- a known byte count to calibrate FETCH_SIZE / WRITE_SIZE
 __global__ void k_calib_copy_pair(Slab s, int fsrc_even, int fdst_even) {
@@ -248,11 +271,6 @@ __global__ void k_calib_copy_pair(Slab s, int fsrc_even, int fdst_even) {
     *dst = *src;
 }
 
-__global__ void k_copy_plane(Slab s, int fsrc, int fdst) {
-    SLAB_IJ_ALL
-    FD(s, fdst, k) = FD(s, fsrc, k);
-}
-
 // ------------------------------------------------------------------------------------
 // evp_prep2 (ice_dyn_shared.F90:377-614) on the slab.  State lives in buffer `cur` on entry; both
 // buffers are left identical (the velocity ring is completed by the halo update + ring copy that
@@ -262,6 +280,7 @@ __global__ void k_copy_plane(Slab s, int fsrc, int fdst) {
 // inactive at the previous prep already satisfies this and is skipped.
 // ------------------------------------------------------------------------------------
 __global__ void k_prep2(Slab s, DevParams p, int fresh, int cur) {
+    TILE_SKIP(s.act_any)
     SLAB_IJ_ALL
     const int SA = cur ? F_STATE1 : F_STATE0;      // buffer holding the current state
     const int SB = cur ? F_STATE0 : F_STATE1;      // the other one, made identical here
@@ -1019,6 +1038,7 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, unsigne
 // evp_finish (ice_dyn_shared.F90:757-844)
 // ------------------------------------------------------------------------------------
 __global__ void k_finish(Slab s, DevParams p, int cur) {
+    TILE_SKIP(s.act_any)
     SLAB_IJ_ALL
     double xT = 0.0, yT = 0.0;                                                     // :806-811
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl && s.iceumask[km]) {
@@ -1037,13 +1057,14 @@ __global__ void k_finish(Slab s, DevParams p, int cur) {
         yT = sy / aiu;
     }
     // strocnxT/yT before the U->T average (u2tgrid_vector works on a copy, ice_grid.F90:1899): work planes
-    FD(s, F_WORK1, k) = xT;
-    FD(s, F_WORK2, k) = yT;
+    // (planes of their own, never used for anything else: tiles that are skipped keep their zeros)
+    FD(s, F_WORK3, k) = xT;
+    FD(s, F_WORK4, k) = yT;
 }
 
 // ------------------------------------------------------------------------------------
 // principal_stress (ice_dyn_shared.F90:853-893): normalised principal stresses of the NE corner,
-// from the resident sigma_1 planes and prs_sig; written into the two work planes
+// from the resident sigma_1 planes and prs_sig
 // ------------------------------------------------------------------------------------
 __global__ void k_principal_stress(Slab s, int SB) {
     SLAB_IJ_ALL
@@ -1055,8 +1076,8 @@ __global__ void k_principal_stress(Slab s, int SB) {
         s1 = (0.5 * (sp + r)) / prs;
         s2 = (0.5 * (sp - r)) / prs;
     }
-    FD(s, F_WORK1, k) = s1;
-    FD(s, F_WORK2, k) = s2;
+    FD(s, F_SIG1, k) = s1;
+    FD(s, F_SIG2, k) = s2;
 }
 
 }  // namespace evpk
