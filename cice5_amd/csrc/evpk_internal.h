@@ -28,7 +28,7 @@ enum Field : int {
     F_STATE0,
     F_STATE1 = F_STATE0 + 14,
     F_STATE2 = F_STATE1 + 14,       // scratch state of the tripole top band between the two fused subcycles
-    F_VRELC = F_STATE2 + 14, F_UAREAR, F_UOCN, F_VOCN, F_WATERX, F_WATERY, F_FORCEX, F_FORCEY,
+    F_VRELC = F_STATE2 + 14, F_UAREAR, F_UOCN, F_VOCN, F_FORCEX, F_FORCEY,
     F_UMASSDTI, F_FM, F_UVEL_INIT, F_VVEL_INIT,
     // ---- cold planes ----
     F_TAREAR, F_TAREA, F_UAREA, F_FCOR,

@@ -292,10 +292,8 @@ __global__ void k_prep2(Slab s, DevParams p, int fresh, int cur) {
 #pragma unroll
             for (int c = S_SP; c < NSTATE; c++) { FD(s, SA + c, k) = 0.0; FD(s, SB + c, k) = 0.0; }
         }
-    } else {
-#pragma unroll
-        for (int c = S_SP; c < NSTATE; c++) FD(s, SB + c, k) = FD(s, SA + c, k);
     }
+    // (an active T cell needs nothing here: the first kernel of the loop reads buffer `cur` and rewrites the other one)
     unsigned char cm = icet ? CM_T : 0;
     if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {                            // :545-577
         const double aiu = FD(s, F_AIU, k), umass = FD(s, F_UMASS, k);
@@ -307,16 +305,12 @@ __global__ void k_prep2(Slab s, DevParams p, int fresh, int cur) {
             double u = FD(s, SA + S_U, k), v = FD(s, SA + S_V, k);
             if (!old) { u = uocn; v = vocn; }
             cm |= CM_U;
-            FD(s, SA + S_U, k) = u; FD(s, SA + S_V, k) = v;
-            FD(s, SB + S_U, k) = u; FD(s, SB + S_V, k) = v;
+            if (!old) { FD(s, SA + S_U, k) = u; FD(s, SA + S_V, k) = v; }   // the other buffer is rewritten by the first kernel
             FD(s, F_UVEL_INIT, k) = u;    FD(s, F_VVEL_INIT, k) = v;
             const double umdti = umass / p.dt;                                     // :583-612
             const double fm = FD(s, F_FCOR, k) * umass;
             FD(s, F_FM, k) = fm;
-            const double sg = copysign(1.0, fm);
-            const double wx = uocn * p.cosw - vocn * p.sinw * sg;
-            const double wy = vocn * p.cosw + uocn * p.sinw * sg;
-            double tx, ty;
+            double tx, ty;      // waterx/watery (:592-593) are recomputed inside stepu_cell
             if (p.tilt_from_slope) {
                 tx = -p.gravit * umass * FD(s, F_SSTLTX, k);
                 ty = -p.gravit * umass * FD(s, F_SSTLTY, k);
@@ -326,7 +320,6 @@ __global__ void k_prep2(Slab s, DevParams p, int fresh, int cur) {
             }
             FD(s, F_STRTLTX, k) = tx;
             FD(s, F_STRTLTY, k) = ty;
-            FD(s, F_WATERX, k) = wx; FD(s, F_WATERY, k) = wy;
             FD(s, F_FORCEX, k) = FD(s, F_STRAIRX, k) + tx;
             FD(s, F_FORCEY, k) = FD(s, F_STRAIRY, k) + ty;
             FD(s, F_UMASSDTI, k) = umdti;
@@ -338,7 +331,6 @@ __global__ void k_prep2(Slab s, DevParams p, int fresh, int cur) {
             FD(s, F_UVEL_INIT, k) = 0.0;    FD(s, F_VVEL_INIT, k) = 0.0;
             FD(s, F_STRINTX, k) = 0.0; FD(s, F_STRINTY, k) = 0.0;
             FD(s, F_STROCNX, k) = 0.0; FD(s, F_STROCNY, k) = 0.0;
-            FD(s, F_WATERX, k) = 0.0; FD(s, F_WATERY, k) = 0.0;
             FD(s, F_FORCEX, k) = 0.0; FD(s, F_FORCEY, k) = 0.0;
             FD(s, F_UMASSDTI, k) = 0.0; FD(s, F_VRELC, k) = 0.0;
         }
