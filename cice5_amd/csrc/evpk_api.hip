@@ -534,7 +534,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->R2 = c->R;
         c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_subcycle2<false>, 256, 0) == hipSuccess && nb > 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_subcycle2<false, false>, 256, 0) == hipSuccess && nb > 0)
             c->slots2 = nb * prop.multiProcessorCount;
     }
     { const char *e = getenv("EVPK_OVERLAP"); c->overlap = !(e && atoi(e) == 0); }
@@ -903,16 +903,16 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             if (c->nstrips2e > 0) {
                 a.strips = c->d_strips2e; a.nstrips = c->nstrips2e;
                 const dim3 g((((c->nstrips2e + 3) / 4 + 7) / 8) * 8), b(256);
-                if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream, a);
-                else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream, a);
+                if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, c->stream, a);
+                else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, c->stream, a);
             }
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evX, 0));         // exchange k-1 (and with it edge k-1)
             if (c->nstrips2i > 0) {
                 a.strips = c->d_strips2i; a.nstrips = c->nstrips2i;
                 const dim3 g((((c->nstrips2i + 3) / 4 + 7) / 8) * 8), b(256);
                 if (ev_begin(c->stream2)) FAIL(c, "hipEventRecord failed");
-                if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream2, a);
-                else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream2, a);
+                if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, c->stream2, a);
+                else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, c->stream2, a);
                 if (ev_end(c->stream2)) FAIL(c, "hipEventRecord failed");
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;
@@ -934,14 +934,21 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));
             in_overlap = false;
         }
-        if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte) {
+        // ... or, outside the tripole band mode, when the second of them is the last one (k_subcycle2<.., LAST2>)
+        const bool pair_ends_evp = (c->ksub + 2 == c->p.ndte) && !c->band_mode;
+        if (c->use_double && nsub - n >= 2 && (c->ksub + 2 < c->p.ndte || pair_ends_evp)) {
             a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             if (c->nstrips2 > 0) {
                 const dim3 g((((c->nstrips2 + 3) / 4 + 7) / 8) * 8), b(256);
                 if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
-                if (revp) hipLaunchKernelGGL((k_subcycle2<true>), g, b, 0, c->stream, a);
-                else hipLaunchKernelGGL((k_subcycle2<false>), g, b, 0, c->stream, a);
+                if (pair_ends_evp) {
+                    if (revp) hipLaunchKernelGGL((k_subcycle2<true, true>), g, b, 0, c->stream, a);
+                    else hipLaunchKernelGGL((k_subcycle2<false, true>), g, b, 0, c->stream, a);
+                } else {
+                    if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, c->stream, a);
+                    else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, c->stream, a);
+                }
                 if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;

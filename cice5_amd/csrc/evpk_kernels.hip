@@ -840,7 +840,7 @@ template __global__ void k_subcycle<true, true>(SubArgs);
 // ------------------------------------------------------------------------------------
 constexpr int STRIP2_W = 61;
 
-template <bool REVP>
+template <bool REVP, bool LAST2>
 __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
     const Slab &s = a.s;
     const int lane = threadIdx.x & 63;
@@ -959,11 +959,18 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
             if (t2act) {
                 Sig g2 = g1p;
                 Diag dg;
-                stress_cell<false>(mtp, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, 0.0, g2, o2, dg);
+                char *const rq = base + (size_t)q2 * rowb;
+                double tarear = 0.0;
+                if (LAST2) tarear = *reinterpret_cast<const double *>(rq + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
+                stress_cell<LAST2>(mtp, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
                 if (own && q2 >= jb && q2 < jb + R) {
-                    char *const rq = base + (size_t)q2 * rowb;
                     store_sig(rq, pp, SW, lo, g2);
                     if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);     // east ghost T column = image of column 1
+                    if (LAST2) {    // the second subcycle is the last one of this evp: ridging diagnostics (ice_dyn_evp.F90:665-677)
+                        st1(rq, pp, F_DIVU, lo, dg.divu);       st1(rq, pp, F_RDGCONV, lo, dg.rdg_conv);
+                        st1(rq, pp, F_RDGSHEAR, lo, dg.rdg_shear); st1(rq, pp, F_SHEAR, lo, dg.shear);
+                        st1(rq, pp, F_PRSSIG, lo, dg.prs);
+                    }
                 }
             }
         }
@@ -983,6 +990,7 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
                     if (c == 1) stp(ru, pp, SW + S_U, lo + (unsigned)nxl * 16u, un, vn);
                     if (c == nxl) stp(ru, pp, SW + S_U, lo - (unsigned)nxl * 16u, un, vn);
                 }
+                if (LAST2) { st1(ru, pp, F_STRINTX, lo, sxi); st1(ru, pp, F_STRINTY, lo, syi); }
             }
         }
 
@@ -997,8 +1005,10 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
     }
 }
 
-template __global__ void k_subcycle2<false>(SubArgs);
-template __global__ void k_subcycle2<true>(SubArgs);
+template __global__ void k_subcycle2<false, false>(SubArgs);
+template __global__ void k_subcycle2<true, false>(SubArgs);
+template __global__ void k_subcycle2<false, true>(SubArgs);
+template __global__ void k_subcycle2<true, true>(SubArgs);
 
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
