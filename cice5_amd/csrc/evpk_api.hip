@@ -131,6 +131,7 @@ struct evpk_ctx {
     bool band_mode = false;          // tripole + k_subcycle2: the top rows are redone with two one-subcycle band launches
     int nstrips2e = 0, nstrips2i = 0;
     bool overlap = true;
+    bool prefetch = true;           // k_subcycle2p (next row through LDS) instead of k_subcycle2; EVPK_PREFETCH=0 disables
     ncclComm_t comm = nullptr;
     ShmRelay *relay = nullptr;      // test transport instead of RCCL (unique id "EVPKSHM:<name>")
     double *stage = nullptr;   // nblocks*nyb*nxb doubles (also reused as int32)
@@ -381,6 +382,18 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     return 0;
 }
 
+// ---- launch of the two-subcycle kernel (plain or LDS-prefetch variant) ------------------------------------
+static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp, bool last2) {
+    const dim3 g((((a.nstrips + 3) / 4 + 7) / 8) * 8), b(256);     // multiple of 8: XCD remap in the kernel
+    if (c->prefetch) {
+        if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2p<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2p<false, true>), g, b, 0, st, a); }
+        else       { if (revp) hipLaunchKernelGGL((k_subcycle2p<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2p<false, false>), g, b, 0, st, a); }
+    } else {
+        if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, true>), g, b, 0, st, a); }
+        else       { if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, st, a); }
+    }
+}
+
 // ---- two-column ghost zones of a list of pair planes (x-slab neighbours, all rows) -----------------
 static int exchange_cols(evpk_ctx *c, const PairList &pl) {
     Slab &s = c->s;
@@ -534,10 +547,11 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->R2 = c->R;
         c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_subcycle2<false, false>, 256, 0) == hipSuccess && nb > 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->prefetch ? (const void *)k_subcycle2p<false, false> : (const void *)k_subcycle2<false, false>, 256, 0) == hipSuccess && nb > 0)
             c->slots2 = nb * prop.multiProcessorCount;
     }
     { const char *e = getenv("EVPK_OVERLAP"); c->overlap = !(e && atoi(e) == 0); }
+    { const char *e = getenv("EVPK_PREFETCH"); c->prefetch = !(e && atoi(e) == 0); }
 
     // neighbours on the slab ring
     int lay[5];
@@ -902,17 +916,13 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));          // interior of step k-1
             if (c->nstrips2e > 0) {
                 a.strips = c->d_strips2e; a.nstrips = c->nstrips2e;
-                const dim3 g((((c->nstrips2e + 3) / 4 + 7) / 8) * 8), b(256);
-                if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, c->stream, a);
-                else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, c->stream, a);
+                launch_sub2(c, a, c->stream, revp, false);
             }
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evX, 0));         // exchange k-1 (and with it edge k-1)
             if (c->nstrips2i > 0) {
                 a.strips = c->d_strips2i; a.nstrips = c->nstrips2i;
-                const dim3 g((((c->nstrips2i + 3) / 4 + 7) / 8) * 8), b(256);
                 if (ev_begin(c->stream2)) FAIL(c, "hipEventRecord failed");
-                if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, c->stream2, a);
-                else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, c->stream2, a);
+                launch_sub2(c, a, c->stream2, revp, false);
                 if (ev_end(c->stream2)) FAIL(c, "hipEventRecord failed");
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;
@@ -940,15 +950,8 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             if (c->nstrips2 > 0) {
-                const dim3 g((((c->nstrips2 + 3) / 4 + 7) / 8) * 8), b(256);
                 if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
-                if (pair_ends_evp) {
-                    if (revp) hipLaunchKernelGGL((k_subcycle2<true, true>), g, b, 0, c->stream, a);
-                    else hipLaunchKernelGGL((k_subcycle2<false, true>), g, b, 0, c->stream, a);
-                } else {
-                    if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, c->stream, a);
-                    else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, c->stream, a);
-                }
+                launch_sub2(c, a, c->stream, revp, pair_ends_evp);
                 if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;

@@ -1005,6 +1005,243 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_subcycle2p: k_subcycle2 with the next row's planes prefetched through LDS.
+// In k_subcycle2 a wave spends half of its life in s_waitcnt (225 VGPRs leave two waves per SIMD to hide HBM
+// latency, and register prefetch has no room).  Here every step first issues direct global->LDS loads
+// (global_load_lds_dwordx4: no VGPR destination, 1 KiB per wave instruction) for the row it will need in the NEXT
+// step -- u/v at the two columns, five metric pairs, six sigma pairs of row r+1 and the stepu input pairs of
+// row r -- then computes the current step from registers; the next step reads its operands from LDS.
+// One 18 KiB ring slot per wave, 72 KiB per 256-thread workgroup, two workgroups per CU.
+// The arithmetic and the results are those of k_subcycle2.
+// ------------------------------------------------------------------------------------
+constexpr int PF_SLOTS = 18;     // 0,1: (u,v) at c, c-1; 2..6: metrics; 7..12: sigma; 13..16: stepu inputs; 17: uvel_init
+
+__device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_slot, 16, 0, 0);
+}
+
+template <bool REVP, bool LAST2>
+__global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
+    __shared__ double2 smem[4 * PF_SLOTS * 64];
+    const Slab &s = a.s;
+    const int lane = threadIdx.x & 63;
+    double2 *const L = smem + (size_t)(threadIdx.x >> 6) * PF_SLOTS * 64;     // this wave's slots
+    const int chunk = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
+    if (sid >= a.nstrips) return;
+    const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
+    const int cx = st % a.ncx, ry = st / a.ncx;
+    const int R = a.R, nxl = s.nxl, nyl = s.nyl;
+    const int c = cx * STRIP2_W + lane;
+    const int jb = ry * R + 1;
+    const bool cyc = a.wrap != 0;
+
+    int ci = c, cm1 = c - 1;
+    bool okc, okm;
+    if (cyc) {
+        ci = (c - 1) % nxl; if (ci < 0) ci += nxl; ci += 1;
+        cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
+        okc = okm = true;
+    } else {
+        okc = (c >= -1 && c <= nxl + 2);
+        okm = (cm1 >= -1 && cm1 <= nxl + 2);
+        if (!okc) ci = 0;
+        if (!okm) cm1 = 0;
+    }
+    const bool tcol = cyc ? true : (c >= 0 && c <= nxl + 2);
+    const bool ucol = cyc ? true : (c >= 0 && c <= nxl + 1);
+    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 && c <= nxl);
+
+    const size_t pp = (size_t)s.pitch * 16;
+    const size_t rowb = (size_t)s.rstride * 16;
+    const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
+    const int SR = a.sr;
+    const int SW = a.sw;
+    char *const base = reinterpret_cast<char *>(s.F);
+
+    auto rowok = [&](int r) { return r >= 0 && r <= nyl + 1; };
+    auto mask_of = [&](int r) -> unsigned char { return (rowok(r) && okc) ? s.cmask[(size_t)r * s.pitch + C0 + ci] : (unsigned char)0; };
+    // prefetch for the step whose T1 row is rn: T planes of row rn, stepu inputs of row rn-1 (mask mu)
+    auto issue = [&](int rn, unsigned char mt_, unsigned char mu_) {
+        if (rowok(rn)) {
+            const char *rbn = base + (size_t)rn * rowb;
+            if (okc) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lo, L + 0 * 64);
+            if (okm) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lom, L + 1 * 64);
+            const bool ta = tcol && (mt_ & CM_T) != 0;
+            if (__any(ta)) {
+                if (ta) {
+                    lds_dma16(rbn + (size_t)(F_CXP >> 1) * pp + lo, L + 2 * 64);
+                    lds_dma16(rbn + (size_t)(F_CXM >> 1) * pp + lo, L + 3 * 64);
+                    lds_dma16(rbn + (size_t)(F_DXT >> 1) * pp + lo, L + 4 * 64);
+                    lds_dma16(rbn + (size_t)(F_DXHY >> 1) * pp + lo, L + 5 * 64);
+                    lds_dma16(rbn + (size_t)(F_TINYAREA >> 1) * pp + lo, L + 6 * 64);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) lds_dma16(rbn + (size_t)((SR + S_SP) / 2 + q) * pp + lo, L + (7 + q) * 64);
+                }
+            }
+        }
+        const int ru_ = rn - 1;
+        const bool ua = ucol && (mu_ & CM_U) != 0 && ru_ >= 1 && ru_ <= nyl;
+        if (__any(ua)) {
+            if (ua) {
+                const char *rbu = base + (size_t)ru_ * rowb;
+                lds_dma16(rbu + (size_t)(F_VRELC >> 1) * pp + lo, L + 13 * 64);
+                lds_dma16(rbu + (size_t)(F_UOCN >> 1) * pp + lo, L + 14 * 64);
+                lds_dma16(rbu + (size_t)(F_FORCEX >> 1) * pp + lo, L + 15 * 64);
+                lds_dma16(rbu + (size_t)(F_UMASSDTI >> 1) * pp + lo, L + 16 * 64);
+                if (REVP) lds_dma16(rbu + (size_t)(F_UVEL_INIT >> 1) * pp + lo, L + 17 * 64);
+            }
+        }
+    };
+
+    // ---- carried state (as in k_subcycle2) ----
+    double uo_c = 0.0, vo_c = 0.0, uo_m = 0.0, vo_m = 0.0;
+    double a1c = 0.0, a5c = 0.0, a2r = 0.0, a7r = 0.0;
+    Sig g1p{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TMet mtp{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned char mp = 0, mpp = 0;
+    double u1p_c = 0.0, v1p_c = 0.0, u1p_m = 0.0, v1p_m = 0.0;
+    double b1c = 0.0, b5c = 0.0, b2r = 0.0, b7r = 0.0;
+    UStat qp{0, 0, 0, 0, 0, 0, 0, 0};
+    double uip = 0.0, vip = 0.0;
+
+    {
+        const int r0 = jb - 2;
+        if (r0 >= 0) {
+            const char *rb0 = base + (size_t)r0 * rowb;
+            if (okc) { const double2 t = ldp(rb0, pp, SR + S_U, lo); uo_c = t.x; vo_c = t.y; }
+            if (okm) { const double2 t = ldp(rb0, pp, SR + S_U, lom); uo_m = t.x; vo_m = t.y; }
+        }
+    }
+    // masks of the first two T1 rows; prefetch of the first one (its U row jb-2 is never advanced)
+    unsigned char m = mask_of(jb - 1), m_n1 = mask_of(jb);
+    issue(jb - 1, m, 0);
+
+    for (int t = 0; t <= R + 2; t++) {
+        const int r = jb - 1 + t;
+        if (r > nyl + 2) break;
+        const bool rok = rowok(r);
+
+        // ---------------- operands of this step: LDS -> registers ----------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        double un_c = 0.0, vn_c = 0.0, un_m = 0.0, vn_m = 0.0;
+        if (rok) {
+            if (okc) { const double2 q = L[0 * 64 + lane]; un_c = q.x; vn_c = q.y; }
+            if (okm) { const double2 q = L[1 * 64 + lane]; un_m = q.x; vn_m = q.y; }
+        }
+        const bool t1act = tcol && (m & CM_T) != 0;
+        Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (__any(t1act)) {
+            if (t1act) {
+                const double2 cp = L[2 * 64 + lane], cm = L[3 * 64 + lane], dd = L[4 * 64 + lane], dh = L[5 * 64 + lane], ts = L[6 * 64 + lane];
+                mt = TMet{cp.x, cp.y, cm.x, cm.y, dd.x, dd.y, dh.x, dh.y, ts.x, ts.y};
+                const double2 q0 = L[7 * 64 + lane], q1 = L[8 * 64 + lane], q2 = L[9 * 64 + lane];
+                const double2 q3 = L[10 * 64 + lane], q4 = L[11 * 64 + lane], q5 = L[12 * 64 + lane];
+                g1 = Sig{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y, q4.x, q4.y, q5.x, q5.y};
+            }
+        }
+        const bool u1act = (t >= 1) && ucol && (mp & CM_U) != 0 && (r - 1 >= 1) && (r - 1 <= nyl);
+        UStat q1{0, 0, 0, 0, 0, 0, 0, 0};
+        double ui1 = 0.0, vi1 = 0.0;
+        if (__any(u1act)) {
+            if (u1act) {
+                const double2 va = L[13 * 64 + lane], oc = L[14 * 64 + lane], fo = L[15 * 64 + lane], mf = L[16 * 64 + lane];
+                q1 = UStat{va.x, va.y, oc.x, oc.y, fo.x, fo.y, mf.x, mf.y};
+                if (REVP) { const double2 iv = L[17 * 64 + lane]; ui1 = iv.x; vi1 = iv.y; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // all LDS reads back before the slots are refilled
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------------- prefetch for the next step, mask two rows ahead ----------------
+        const unsigned char m_n2 = mask_of(r + 2);
+        issue(r + 1, m_n1, m);
+
+        // ---------------- stage 1: T1(r) ----------------
+        Str8 o1{0, 0, 0, 0, 0, 0, 0, 0};
+        if (__any(t1act)) {
+            if (t1act) {
+                Diag dg;
+                stress_cell<false>(mt, un_c, un_m, uo_c, uo_m, vn_c, vn_m, vo_c, vo_m, a.ecci, a.arlx1i, a.denom1, 0.0, g1, o1, dg);
+            }
+        }
+        const double a2n = shfl_dn1(o1.s2), a4n = shfl_dn1(o1.s4), a7n = shfl_dn1(o1.s7), a8n = shfl_dn1(o1.s8);
+
+        // ---------------- stage 1: U1(r-1) ----------------
+        double u1_c = uo_c, v1_c = vo_c;
+        if (__any(u1act)) {
+            if (u1act) {
+                double sxi, syi;
+                stepu_cell(q1, uo_c, vo_c, ui1, vi1, ((a1c + a2r) + o1.s3) + a4n, ((a5c + o1.s6) + a7r) + a8n,
+                           a.brlx, a.revp, a.cosw, a.sinw, u1_c, v1_c, sxi, syi);
+            }
+        }
+        const double u1_m = shfl_up1(u1_c), v1_m = shfl_up1(v1_c);
+
+        // ---------------- stage 2: T2(r-1) ----------------
+        const int q2 = r - 1;
+        const bool t2act = (t >= 2) && tcol && (mp & CM_T) != 0 && lane >= 1;
+        Str8 o2{0, 0, 0, 0, 0, 0, 0, 0};
+        if (__any(t2act)) {
+            if (t2act) {
+                Sig g2 = g1p;
+                Diag dg;
+                char *const rq = base + (size_t)q2 * rowb;
+                double tarear = 0.0;
+                if (LAST2) tarear = *reinterpret_cast<const double *>(rq + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
+                stress_cell<LAST2>(mtp, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
+                if (own && q2 >= jb && q2 < jb + R) {
+                    store_sig(rq, pp, SW, lo, g2);
+                    if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);
+                    if (LAST2) {
+                        st1(rq, pp, F_DIVU, lo, dg.divu);       st1(rq, pp, F_RDGCONV, lo, dg.rdg_conv);
+                        st1(rq, pp, F_RDGSHEAR, lo, dg.rdg_shear); st1(rq, pp, F_SHEAR, lo, dg.shear);
+                        st1(rq, pp, F_PRSSIG, lo, dg.prs);
+                    }
+                }
+            }
+        }
+        const double b2n = shfl_dn1(o2.s2), b4n = shfl_dn1(o2.s4), b7n = shfl_dn1(o2.s7), b8n = shfl_dn1(o2.s8);
+
+        // ---------------- stage 2: U2(r-2) ----------------
+        const int q3 = r - 2;
+        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl;
+        if (__any(u2act)) {
+            if (u2act) {
+                double un, vn, sxi, syi;
+                stepu_cell(qp, u1p_c, v1p_c, uip, vip, ((b1c + b2r) + o2.s3) + b4n, ((b5c + o2.s6) + b7r) + b8n,
+                           a.brlx, a.revp, a.cosw, a.sinw, un, vn, sxi, syi);
+                char *const ru = base + (size_t)q3 * rowb;
+                stp(ru, pp, SW + S_U, lo, un, vn);
+                if (cyc) {
+                    if (c == 1) stp(ru, pp, SW + S_U, lo + (unsigned)nxl * 16u, un, vn);
+                    if (c == nxl) stp(ru, pp, SW + S_U, lo - (unsigned)nxl * 16u, un, vn);
+                }
+                if (LAST2) { st1(ru, pp, F_STRINTX, lo, sxi); st1(ru, pp, F_STRINTY, lo, syi); }
+            }
+        }
+
+        // ---------------- rotate ----------------
+        b1c = o2.s1; b5c = o2.s5; b2r = b2n; b7r = b7n;
+        u1p_c = u1_c; v1p_c = v1_c; u1p_m = u1_m; v1p_m = v1_m;
+        qp = q1; uip = ui1; vip = vi1;
+        a1c = o1.s1; a5c = o1.s5; a2r = a2n; a7r = a7n;
+        g1p = g1; mtp = mt;
+        uo_c = un_c; vo_c = vn_c; uo_m = un_m; vo_m = vn_m;
+        mpp = mp; mp = m; m = m_n1; m_n1 = m_n2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may be in flight when the wave ends
+}
+
+template __global__ void k_subcycle2p<false, false>(SubArgs);
+template __global__ void k_subcycle2p<true, false>(SubArgs);
+template __global__ void k_subcycle2p<false, true>(SubArgs);
+template __global__ void k_subcycle2p<true, true>(SubArgs);
+
 template __global__ void k_subcycle2<false, false>(SubArgs);
 template __global__ void k_subcycle2<true, false>(SubArgs);
 template __global__ void k_subcycle2<false, true>(SubArgs);
