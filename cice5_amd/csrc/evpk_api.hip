@@ -131,6 +131,7 @@ struct evpk_ctx {
     bool band_mode = false;          // tripole + k_subcycle2: the top rows are redone with two one-subcycle band launches
     int nstrips2e = 0, nstrips2i = 0;
     bool overlap = true;
+    bool compact = false;           // k_subcycle2p reads HTN/HTE instead of the eight metric planes (verified at create)
     bool prefetch = true;           // k_subcycle2p (next row through LDS) instead of k_subcycle2; EVPK_PREFETCH=0 disables
     ncclComm_t comm = nullptr;
     ShmRelay *relay = nullptr;      // test transport instead of RCCL (unique id "EVPKSHM:<name>")
@@ -386,8 +387,15 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
 static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp, bool last2) {
     const dim3 g((((a.nstrips + 3) / 4 + 7) / 8) * 8), b(256);     // multiple of 8: XCD remap in the kernel
     if (c->prefetch) {
-        if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2p<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2p<false, true>), g, b, 0, st, a); }
-        else       { if (revp) hipLaunchKernelGGL((k_subcycle2p<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2p<false, false>), g, b, 0, st, a); }
+#define EVPK_L2P(RV, L2, CMX) hipLaunchKernelGGL((k_subcycle2p<RV, L2, CMX>), g, b, 0, st, a)
+        if (c->compact) {
+            if (last2) { if (revp) EVPK_L2P(true, true, true); else EVPK_L2P(false, true, true); }
+            else       { if (revp) EVPK_L2P(true, false, true); else EVPK_L2P(false, false, true); }
+        } else {
+            if (last2) { if (revp) EVPK_L2P(true, true, false); else EVPK_L2P(false, true, false); }
+            else       { if (revp) EVPK_L2P(true, false, false); else EVPK_L2P(false, false, false); }
+        }
+#undef EVPK_L2P
     } else {
         if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, true>), g, b, 0, st, a); }
         else       { if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, st, a); }
@@ -547,7 +555,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->R2 = c->R;
         c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->prefetch ? (const void *)k_subcycle2p<false, false> : (const void *)k_subcycle2<false, false>, 256, 0) == hipSuccess && nb > 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->prefetch ? (const void *)k_subcycle2p<false, false, false> : (const void *)k_subcycle2<false, false>, 256, 0) == hipSuccess && nb > 0)
             c->slots2 = nb * prop.multiProcessorCount;
     }
     { const char *e = getenv("EVPK_OVERLAP"); c->overlap = !(e && atoi(e) == 0); }
@@ -635,6 +643,19 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     if (!g->tmask || !g->umask) FAIL(c, "tmask/umask is NULL");
     if (upload_m(c, g->tmask, s.tmask)) return 1;
     if (upload_m(c, g->umask, s.umask)) return 1;
+    if (g->HTN && g->HTE) {
+        // optional primary lengths: use them in place of the eight metric planes only if they reproduce those bit for bit
+        if (upload_f(c, g->HTN, F_HTN) || upload_f(c, g->HTE, F_HTE)) return 1;
+        const char *e = getenv("EVPK_COMPACT_METRICS");
+        if (!(e && atoi(e) == 0)) {
+            HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int), c->stream));
+            hipLaunchKernelGGL(k_verify_metrics, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 1 + 3) / 4), B2D, 0, c->stream, s, c->d_tune);
+            unsigned int bad = 1;
+            HIPCHK(c, hipMemcpyAsync(&bad, c->d_tune, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->compact = (bad == 0);
+        }
+    }
     if (!c->full_cover) {
         // cells of eliminated land blocks: give the areas a harmless non-zero value
         // (they are divisors in to_ugrid / to_tgrid; the reference never visits them)
@@ -808,7 +829,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     if (c->zone_mode) {
         // two-column ghost zones for k_subcycle2: every plane it reads, the current state and the masks, once per evp
         PairList pl = state_pairs(SA);
-        const int stat[] = {F_CXP, F_CXM, F_DXT, F_DXHY, F_TINYAREA, F_VRELC, F_UOCN, F_FORCEX, F_UMASSDTI, F_UVEL_INIT};
+        const int stat[] = {F_CXP, F_CXM, F_DXT, F_DXHY, F_TINYAREA, F_HTN, F_VRELC, F_UOCN, F_FORCEX, F_UMASSDTI, F_UVEL_INIT};
         for (int f : stat) pl.p[pl.n++] = f >> 1;
         pl.with_cmask = 1;
         if (exchange_cols(c, pl)) return 1;

@@ -24,6 +24,7 @@ namespace evpk {
 enum Field : int {
     // ---- hot planes, in pairs (even, odd) ----
     F_CXP, F_CYP, F_CXM, F_CYM, F_DXT, F_DYT, F_DXHY, F_DYHX, F_TINYAREA, F_STRENGTH,
+    F_HTN, F_HTE,        // primary grid lengths (optional): the eight metric planes above are functions of them (ice_grid.F90:338-369)
     // prognostic state, double buffered: u, v, stressp_1..4, stressm_1..4, stress12_1..4
     F_STATE0,
     F_STATE1 = F_STATE0 + 14,

@@ -1015,6 +1015,36 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
 // One 18 KiB ring slot per wave, 72 KiB per 256-thread workgroup, two workgroups per CU.
 // The arithmetic and the results are those of k_subcycle2.
 // ------------------------------------------------------------------------------------
+// the eight metric planes from the primary grid lengths (ice_grid.F90:356-357, :362-367, :1455, :1533):
+//   hn = HTN(i,j), hs = HTN(i,j-1), he = HTE(i,j), hw = HTE(i-1,j)
+__device__ __forceinline__ TMet tmet_from_lengths(double hn, double hs, double he, double hw, double tiny, double strength) {
+    TMet m;
+    m.dxt = 0.5 * (hn + hs);
+    m.dyt = 0.5 * (he + hw);
+    m.dxhy = 0.5 * (he - hw);
+    m.dyhx = 0.5 * (hn - hs);
+    m.cyp = (1.5 * he - 0.5 * hw);
+    m.cxp = (1.5 * hn - 0.5 * hs);
+    m.cym = -(1.5 * hw - 0.5 * he);
+    m.cxm = -(1.5 * hs - 0.5 * hn);
+    m.tiny = tiny;
+    m.strength = strength;
+    return m;
+}
+
+// do HTN/HTE reproduce the stored metric planes bit for bit on every T cell that can become active?
+__global__ void k_verify_metrics(Slab s, unsigned int *mismatch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;     // T cells 1..nxl+1, 1..nyl+1
+    const int j = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    if (i > s.nxl + 1 || j > s.nyl + 1) return;
+    if (!s.tmask[mcell(s, i, j)]) return;
+    const size_t k = cell(s, i, j);
+    const TMet m = tmet_from_lengths(FD(s, F_HTN, k), FD(s, F_HTN, cell(s, i, j - 1)), FD(s, F_HTE, k), FD(s, F_HTE, k - 1), 0.0, 0.0);
+    const bool ok = m.dxt == FD(s, F_DXT, k) && m.dyt == FD(s, F_DYT, k) && m.dxhy == FD(s, F_DXHY, k) && m.dyhx == FD(s, F_DYHX, k) &&
+                    m.cxp == FD(s, F_CXP, k) && m.cyp == FD(s, F_CYP, k) && m.cxm == FD(s, F_CXM, k) && m.cym == FD(s, F_CYM, k);
+    if (!ok) atomicAdd(mismatch, 1u);
+}
+
 constexpr int PF_SLOTS = 18;     // 0,1: (u,v) at c, c-1; 2..6: metrics; 7..12: sigma; 13..16: stepu inputs; 17: uvel_init
 
 __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
@@ -1022,7 +1052,8 @@ __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
                                      (__attribute__((address_space(3))) void *)lds_slot, 16, 0, 0);
 }
 
-template <bool REVP, bool LAST2>
+// CM (compact metrics): slots 2,3 hold (HTN,HTE) at columns c and c-1 instead of the four metric pairs in slots 2..5
+template <bool REVP, bool LAST2, bool CM>
 __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
     __shared__ double2 smem[4 * PF_SLOTS * 64];
     const Slab &s = a.s;
@@ -1065,18 +1096,26 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
     auto rowok = [&](int r) { return r >= 0 && r <= nyl + 1; };
     auto mask_of = [&](int r) -> unsigned char { return (rowok(r) && okc) ? s.cmask[(size_t)r * s.pitch + C0 + ci] : (unsigned char)0; };
     // prefetch for the step whose T1 row is rn: T planes of row rn, stepu inputs of row rn-1 (mask mu)
-    auto issue = [&](int rn, unsigned char mt_, unsigned char mu_) {
+    auto issue = [&](int rn, unsigned char mt_, unsigned char mu_, unsigned char mt_next) {
         if (rowok(rn)) {
             const char *rbn = base + (size_t)rn * rowb;
             if (okc) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lo, L + 0 * 64);
             if (okm) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lom, L + 1 * 64);
             const bool ta = tcol && (mt_ & CM_T) != 0;
+            if (CM) {   // HTN of this row is also the south length of the next row: fetch it if either is active
+                const bool th = tcol && ((mt_ | mt_next) & CM_T) != 0;
+                if (__any(th)) { if (th) lds_dma16(rbn + (size_t)(F_HTN >> 1) * pp + lo, L + 2 * 64); }
+            }
             if (__any(ta)) {
                 if (ta) {
-                    lds_dma16(rbn + (size_t)(F_CXP >> 1) * pp + lo, L + 2 * 64);
-                    lds_dma16(rbn + (size_t)(F_CXM >> 1) * pp + lo, L + 3 * 64);
-                    lds_dma16(rbn + (size_t)(F_DXT >> 1) * pp + lo, L + 4 * 64);
-                    lds_dma16(rbn + (size_t)(F_DXHY >> 1) * pp + lo, L + 5 * 64);
+                    if (CM) {
+                        if (okm) lds_dma16(rbn + (size_t)(F_HTN >> 1) * pp + lom, L + 3 * 64);
+                    } else {
+                        lds_dma16(rbn + (size_t)(F_CXP >> 1) * pp + lo, L + 2 * 64);
+                        lds_dma16(rbn + (size_t)(F_CXM >> 1) * pp + lo, L + 3 * 64);
+                        lds_dma16(rbn + (size_t)(F_DXT >> 1) * pp + lo, L + 4 * 64);
+                        lds_dma16(rbn + (size_t)(F_DXHY >> 1) * pp + lo, L + 5 * 64);
+                    }
                     lds_dma16(rbn + (size_t)(F_TINYAREA >> 1) * pp + lo, L + 6 * 64);
 #pragma unroll
                     for (int q = 0; q < 6; q++) lds_dma16(rbn + (size_t)((SR + S_SP) / 2 + q) * pp + lo, L + (7 + q) * 64);
@@ -1101,7 +1140,8 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
     double uo_c = 0.0, vo_c = 0.0, uo_m = 0.0, vo_m = 0.0;
     double a1c = 0.0, a5c = 0.0, a2r = 0.0, a7r = 0.0;
     Sig g1p{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    TMet mtp{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TMet mtp{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                       // !CM: metrics of row r-1
+    double hn_p = 0.0, hn_pp = 0.0, he_p = 0.0, hw_p = 0.0, tiny_p = 0.0, str_p = 0.0;   // CM: HTN(c,r-1), HTN(c,r-2), HTE(c,r-1), HTE(c-1,r-1), ...
     unsigned char mp = 0, mpp = 0;
     double u1p_c = 0.0, v1p_c = 0.0, u1p_m = 0.0, v1p_m = 0.0;
     double b1c = 0.0, b5c = 0.0, b2r = 0.0, b7r = 0.0;
@@ -1116,9 +1156,13 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
             if (okm) { const double2 t = ldp(rb0, pp, SR + S_U, lom); uo_m = t.x; vo_m = t.y; }
         }
     }
-    // masks of the first two T1 rows; prefetch of the first one (its U row jb-2 is never advanced)
-    unsigned char m = mask_of(jb - 1), m_n1 = mask_of(jb);
-    issue(jb - 1, m, 0);
+    if (CM) {   // south length of the first T1 row
+        const int r0 = jb - 2;
+        if (r0 >= 0 && okc) hn_p = *reinterpret_cast<const double *>(base + (size_t)r0 * rowb + (size_t)(F_HTN >> 1) * pp + lo);
+    }
+    // masks of the first three T1 rows; prefetch of the first one (its U row jb-2 is never advanced)
+    unsigned char m = mask_of(jb - 1), m_n1 = mask_of(jb), m_n2 = mask_of(jb + 1);
+    issue(jb - 1, m, 0, m_n1);
 
     for (int t = 0; t <= R + 2; t++) {
         const int r = jb - 1 + t;
@@ -1135,10 +1179,22 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
         const bool t1act = tcol && (m & CM_T) != 0;
         Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double hn = 0.0, he = 0.0, hw = 0.0, tiny_c = 0.0, str_c = 0.0;
+        if (CM) {
+            const bool th = tcol && ((m | m_n1) & CM_T) != 0 && rok;
+            if (__any(th)) { if (th) { const double2 h = L[2 * 64 + lane]; hn = h.x; he = h.y; } }
+        }
         if (__any(t1act)) {
             if (t1act) {
-                const double2 cp = L[2 * 64 + lane], cm = L[3 * 64 + lane], dd = L[4 * 64 + lane], dh = L[5 * 64 + lane], ts = L[6 * 64 + lane];
-                mt = TMet{cp.x, cp.y, cm.x, cm.y, dd.x, dd.y, dh.x, dh.y, ts.x, ts.y};
+                if (CM) {
+                    hw = L[3 * 64 + lane].y;
+                    const double2 ts = L[6 * 64 + lane];
+                    tiny_c = ts.x; str_c = ts.y;
+                    mt = tmet_from_lengths(hn, hn_p, he, hw, tiny_c, str_c);
+                } else {
+                    const double2 cp = L[2 * 64 + lane], cm = L[3 * 64 + lane], dd = L[4 * 64 + lane], dh = L[5 * 64 + lane], ts = L[6 * 64 + lane];
+                    mt = TMet{cp.x, cp.y, cm.x, cm.y, dd.x, dd.y, dh.x, dh.y, ts.x, ts.y};
+                }
                 const double2 q0 = L[7 * 64 + lane], q1 = L[8 * 64 + lane], q2 = L[9 * 64 + lane];
                 const double2 q3 = L[10 * 64 + lane], q4 = L[11 * 64 + lane], q5 = L[12 * 64 + lane];
                 g1 = Sig{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y, q4.x, q4.y, q5.x, q5.y};
@@ -1157,9 +1213,9 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // all LDS reads back before the slots are refilled
         __builtin_amdgcn_wave_barrier();
 
-        // ---------------- prefetch for the next step, mask two rows ahead ----------------
-        const unsigned char m_n2 = mask_of(r + 2);
-        issue(r + 1, m_n1, m);
+        // ---------------- prefetch for the next step, mask three rows ahead ----------------
+        const unsigned char m_n3 = mask_of(r + 3);
+        issue(r + 1, m_n1, m, m_n2);
 
         // ---------------- stage 1: T1(r) ----------------
         Str8 o1{0, 0, 0, 0, 0, 0, 0, 0};
@@ -1193,7 +1249,8 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
                 char *const rq = base + (size_t)q2 * rowb;
                 double tarear = 0.0;
                 if (LAST2) tarear = *reinterpret_cast<const double *>(rq + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
-                stress_cell<LAST2>(mtp, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
+                const TMet mt2 = CM ? tmet_from_lengths(hn_p, hn_pp, he_p, hw_p, tiny_p, str_p) : mtp;
+                stress_cell<LAST2>(mt2, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
                 if (own && q2 >= jb && q2 < jb + R) {
                     store_sig(rq, pp, SW, lo, g2);
                     if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);
@@ -1230,17 +1287,22 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
         u1p_c = u1_c; v1p_c = v1_c; u1p_m = u1_m; v1p_m = v1_m;
         qp = q1; uip = ui1; vip = vi1;
         a1c = o1.s1; a5c = o1.s5; a2r = a2n; a7r = a7n;
-        g1p = g1; mtp = mt;
+        g1p = g1;
+        if (CM) { hn_pp = hn_p; hn_p = hn; he_p = he; hw_p = hw; tiny_p = tiny_c; str_p = str_c; } else { mtp = mt; }
         uo_c = un_c; vo_c = vn_c; uo_m = un_m; vo_m = vn_m;
-        mpp = mp; mp = m; m = m_n1; m_n1 = m_n2;
+        mpp = mp; mp = m; m = m_n1; m_n1 = m_n2; m_n2 = m_n3;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may be in flight when the wave ends
 }
 
-template __global__ void k_subcycle2p<false, false>(SubArgs);
-template __global__ void k_subcycle2p<true, false>(SubArgs);
-template __global__ void k_subcycle2p<false, true>(SubArgs);
-template __global__ void k_subcycle2p<true, true>(SubArgs);
+template __global__ void k_subcycle2p<false, false, false>(SubArgs);
+template __global__ void k_subcycle2p<true, false, false>(SubArgs);
+template __global__ void k_subcycle2p<false, true, false>(SubArgs);
+template __global__ void k_subcycle2p<true, true, false>(SubArgs);
+template __global__ void k_subcycle2p<false, false, true>(SubArgs);
+template __global__ void k_subcycle2p<true, false, true>(SubArgs);
+template __global__ void k_subcycle2p<false, true, true>(SubArgs);
+template __global__ void k_subcycle2p<true, true, true>(SubArgs);
 
 template __global__ void k_subcycle2<false, false>(SubArgs);
 template __global__ void k_subcycle2<true, false>(SubArgs);

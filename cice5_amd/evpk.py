@@ -38,7 +38,7 @@ class Geom(ct.Structure):
                  ("iglob_lo", c_i32p), ("jglob_lo", c_i32p),
                  ("rank", ct.c_int32), ("nranks", ct.c_int32), ("device", ct.c_int32),
                  ("unique_id", ct.c_void_p)] +
-                [(n, c_f64p) for n in GEOM_F64] + [("tmask", c_i32p), ("umask", c_i32p)])
+                [(n, c_f64p) for n in GEOM_F64] + [("tmask", c_i32p), ("umask", c_i32p), ("HTN", c_f64p), ("HTE", c_f64p)])
 
 
 class Params(ct.Structure):
@@ -164,6 +164,7 @@ class Context:
         for n in GEOM_F64:
             setattr(g, n, _p64(fields[n]))
         g.tmask, g.umask = _p32(fields["tmask"]), _p32(fields["umask"])
+        g.HTN, g.HTE = _p64(fields.get("HTN")), _p64(fields.get("HTE"))      # optional
         if L.evpk_create(ct.byref(g), ct.byref(self._ctx)):
             raise EvpkError("evpk_create: " + L.evpk_last_error(None).decode())
         self.decomp = decomp

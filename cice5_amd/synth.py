@@ -159,6 +159,10 @@ class SynthCase:
             self_ = self
         Iw = self._wrap(I)
         s = self.seed
+        if name == "HTN":
+            return HTN(I, J)
+        if name == "HTE":
+            return HTE(I, J)
         if name == "dxt":
             return 0.5 * (HTN(I, J) + HTN(I, J - 1))
         if name == "dyt":
@@ -230,7 +234,7 @@ class SynthCase:
 
 
 GRID_FIELDS = ["dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
-               "tarear", "uarear", "tinyarea", "tarea", "uarea", "fcor"]
+               "tarear", "uarear", "tinyarea", "tarea", "uarea", "fcor", "HTN", "HTE"]
 MASK_FIELDS = ["tmask", "umask"]
 INPUT_FIELDS = ["aice", "vice", "vsno", "aice_init", "strairxT", "strairyT", "strax", "stray",
                 "uocn", "vocn", "ss_tltx", "ss_tlty", "Cdn_ocn", "strength"]

@@ -63,7 +63,7 @@
 
       call rd (dxt); call rd (dyt); call rd (dxhy); call rd (dyhx); call rd (cxp); call rd (cyp)
       call rd (cxm); call rd (cym); call rd (tarear); call rd (uarear); call rd (tinyarea)
-      call rd (tarea); call rd (uarea); call rd (fcor_blk)
+      call rd (tarea); call rd (uarea); call rd (fcor_blk); call rd (HTN); call rd (HTE)
       call rd (aice); call rd (vice); call rd (vsno); call rd (aice_init)
       call rd (strairxT); call rd (strairyT); call rd (strax); call rd (stray)
       call rd (uocn); call rd (vocn); call rd (ss_tltx); call rd (ss_tlty); call rd (Cdn_ocn); call rd (strength)

@@ -30,6 +30,7 @@
          type (c_ptr) :: dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym
          type (c_ptr) :: tarear, uarear, tinyarea, tarea, uarea, fcor
          type (c_ptr) :: tmask, umask
+         type (c_ptr) :: HTN, HTE            ! optional (c_null_ptr): see include/evpk.h
       end type evpk_geom
 
       type, bind(C), public :: evpk_params

@@ -67,7 +67,7 @@
       use ice_domain_size, only: nx_global, ny_global, max_blocks
       use ice_exit, only: abort_ice
       use ice_grid, only: tmask, umask, dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, &
-          tarear, uarear, tinyarea, tarea, uarea
+          tarear, uarear, tinyarea, tarea, uarea, HTN, HTE
 #ifdef EVPK_USE_MPI
       use ice_communicate, only: MPI_COMM_ICE
       include 'mpif.h'
@@ -128,6 +128,7 @@
       g%tarear = c_loc(tarear); g%uarear = c_loc(uarear); g%tinyarea = c_loc(tinyarea)
       g%tarea  = c_loc(tarea);  g%uarea  = c_loc(uarea);  g%fcor = c_loc(fcor_blk)
       g%tmask  = c_loc(tmask_i); g%umask = c_loc(umask_i)
+      g%HTN = c_loc(HTN);  g%HTE = c_loc(HTE)      ! lets the library rebuild the eight metric planes on the fly if they match
 
       rc = evpk_create (g, ctx)
       if (rc /= 0) call abort_ice('evp: evpk_create: '//trim(evpk_error_string(c_null_ptr)))

@@ -63,6 +63,11 @@ typedef struct {
     const double *dxt, *dyt, *dxhy, *dyhx, *cxp, *cyp, *cxm, *cym;
     const double *tarear, *uarear, *tinyarea, *tarea, *uarea, *fcor;
     const int32_t *tmask, *umask;
+    /* optional (NULL allowed): the primary grid lengths HTN, HTE (ice_grid.F90:50-53).  dxt, dyt, dxhy, dyhx, cxp, cyp,
+     * cxm, cym are functions of HTN(i,j), HTN(i,j-1), HTE(i,j), HTE(i-1,j) (ice_grid.F90:360-369, :1455, :1533).  If they are
+     * given AND reproduce the eight planes above bit for bit on every ocean T cell, the kernels read the two lengths
+     * instead of the eight planes (less HBM traffic, identical results); otherwise they are ignored. */
+    const double *HTN, *HTE;
 } evpk_geom;
 
 /* Replaces the module scalars of ice_dyn_shared.F90:29-81 set by set_evp_parameters

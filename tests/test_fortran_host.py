@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "fortran", "evp_driver")
 
 IN_F64 = ["dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarear", "uarear", "tinyarea", "tarea", "uarea", "fcor",
+          "HTN", "HTE",
           "aice", "vice", "vsno", "aice_init", "strairxT", "strairyT", "strax", "stray", "uocn", "vocn", "ss_tltx", "ss_tlty",
           "Cdn_ocn", "strength", "uvel", "vvel"] + util.SIGMA
 OUT_F64 = ["uvel", "vvel"] + util.SIGMA + ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx", "strinty",

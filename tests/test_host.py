@@ -29,7 +29,7 @@ def test_struct_layouts_match_header_sizes():
     assert ct.sizeof(evpk.Params) == 8 + 4 + 4 + 8 * 13 + 4 + 4
     assert ct.sizeof(evpk.StepIn) == 8 * 14
     assert ct.sizeof(evpk.State) == 8 * (2 + 12 + 1 + 21 + 1)
-    assert ct.sizeof(evpk.Geom) == 4 * 7 + 4 + 8 * 6 + 4 * 3 + 4 + 8 + 8 * 16
+    assert ct.sizeof(evpk.Geom) == 4 * 7 + 4 + 8 * 6 + 4 * 3 + 4 + 8 + 8 * 16 + 8 * 2
 
 
 def test_no_gpu_means_loud_failure():

@@ -239,6 +239,29 @@ def test_device_resident_steps_inputs_only_upload(mode, monkeypatch):
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["given", "absent", "inconsistent", "disabled"])
+def test_compact_metrics_from_htn_hte(mode, monkeypatch):
+    """HTN/HTE are optional: when they reproduce the eight metric planes bit for bit the kernel reads them instead
+    (same results); when they are absent or do NOT reproduce the planes, the planes are used."""
+    case, d, f = util.make_case(130, 96, 65, 48, land="continents")
+    if mode == "absent":
+        del f["HTN"], f["HTE"]
+    if mode == "inconsistent":
+        f["HTN"] = f["HTN"] * 1.0000001          # a grid whose metric planes were not built by the reference formulas
+    if mode == "disabled":
+        monkeypatch.setenv("EVPK_COMPACT_METRICS", "0")
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, 24, xmin)
+    s = dyn.EvpDynamics(d, fg, ndte=24, xmin=xmin)
+    s.init_evp(3600.0)
+    for _ in range(2):
+        orc.evp(d, p, fo)
+        s.evp(3600.0)
+        assert not util.compare(d, fg, fo)
+    s.close()
+
+
 def test_principal_stress():
     """ice_dyn_shared.F90:853-893 on the device-resident state vs the oracle on the downloaded arrays."""
     import ctypes as ct
