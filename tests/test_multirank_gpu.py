@@ -95,6 +95,17 @@ def test_x_slabs_open(world):
     assert all(r[3] > 0 for r in res)          # the two-subcycle kernel ran on every rank (ghost-zone mode)
 
 
+def test_cfg4_1440x1080_on_four_ranks():
+    """BASELINE config 4 shape: 1440x1080 in 30x27 blocks (bld/config.nci.auscom.1440x1080) on 4 x-slabs;
+    a short loop (ndte = 10) keeps the single-process oracle cheap."""
+    _run(4, "open", 1440, 1080, 30, 27, ndte=10)
+
+
+def test_cfg5_tripole_slabs_eight_wide_grid():
+    """BASELINE config 5 decomposition in miniature: tripole grid, 4 slabs of a 3600-column grid, few rows."""
+    _run(4, "tripole", 3600, 64, 450, 32, ndte=12)
+
+
 def test_x_slabs_tripole():
     _run(2, "tripole", 240, 64, 20, 32, ndte=24)
     _run(4, "tripole", 240, 64, 30, 16, ndte=13)
