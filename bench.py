@@ -61,6 +61,7 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this pool
     import torch
     import torch.distributed as dist
     from cice5_amd import blocks, constants as C, dyn, evpk, synth
@@ -99,7 +100,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         xmin = float(t[0])
 
-    solver = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=local_rank, unique_id=uid)
+    transport = a.transport if world > 1 else "none"
+    try:
+        solver, err = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=local_rank, unique_id=uid), ""
+    except evpk.EvpkError as e:
+        solver, err = None, str(e)
+    if world > 1:
+        # every rank must end up on the same transport: if RCCL could not be brought up anywhere, all ranks fall back to
+        # the host-staged shared-memory relay (correct, slow) instead of losing the run
+        okv = torch.tensor([1 if solver is not None else 0], dtype=torch.int32)
+        dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+        if int(okv[0]) == 0:
+            if a.transport == "shm":
+                raise SystemExit(f"rank {rank}: evpk_create failed: {err}")
+            if solver is not None:
+                solver.close()
+            box = [(b"EVPKSHM:evpk_bench_fb_%d" % os.getpid()).ljust(128, b"\0") if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            solver = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=local_rank, unique_id=box[0])
+            transport = "shm relay (fallback: RCCL communicator could not be created" + (": " + err[:200] if err else "") + ")"
+    elif solver is None:
+        raise SystemExit("evpk_create failed: " + err)
     solver.init_evp(a.dt)
     ctx = solver.ctx
     ctx.upload(f)                       # inputs resident in HBM from here on
@@ -171,7 +192,9 @@ def main():
                    "active_T_cells": int(icellt), "active_U_cells": int(icellu), "grid_cells": nx * ny,
                    "grid_cell_updates_per_s": nx * ny * a.ndte * a.steps / dt_wall,
                    "strips_per_launch_rank0": int(st.nstrips2 or st.nstrips),
-                   "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows), "step": "prep + ndte x (stress+stepu, halo) + finish"},
+                   "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows), "transport": transport,
+                   "ghost_zone_cols": int(st.zone_cols), "zone_exchanges_per_evp": int(st.zone_exchanges),
+                   "zone_bytes_sent_rank0": int(st.zone_bytes), "step": "prep + ndte x (stress+stepu, halo) + finish"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "alg_bytes_per_launch": alg_bytes_launch,

@@ -117,7 +117,20 @@ struct evpk_ctx {
     bool fresh = true;          // state planes were (re)loaded from the host since the last prep
     unsigned char *tile_buf = nullptr;   // 6 tile-flag arrays: ice/dat x {A, B} (new / previous evp, swapped) + act_ice, act_any
     int tile_cur = 0;
-    bool zone_mode = false;     // k_subcycle2 reads two-column ghost zones filled by exchange_cols (x-slabs / forced exchange)
+    bool zone_mode = false;     // k_subcycle2 reads ghost zones filled by exchange_cols (x-slabs / forced exchange)
+    // Ghost zones are zW = 2*zM columns wide: a two-subcycle launch consumes two columns of validity per side, the zone
+    // columns themselves are advanced redundantly, so the neighbours exchange once per zM launches (communication avoiding).
+    int zW = 2, zM = 1;
+    int zone_left = 0;          // launches the zones of the current state buffer are still good for
+    bool inner_ok = false;      // ghost columns 0 / nxl+1 (u, v, sigma) of the current state buffer are valid
+    bool zcompact = false;      // state exchanges carry only the rows with an active cell in the zone window
+    unsigned char *d_zflags = nullptr;
+    int *d_zrows = nullptr;     // 4 row lists (send W, send E, recv E, recv W), nyl+2 ints each
+    int zn[4] = {0, 0, 0, 0};
+    bool zone_metrics_done = false;   // the time-invariant planes of the zones have been exchanged
+    int zone_exchanges = 0;     // in the last evpk_subcycle call
+    long long zone_bytes = 0;
+    hipEvent_t evE = nullptr;   // after the most recent kernel launch on `stream`
     int nxb = 0, nyb = 0, nblocks = 0;
     std::vector<BlockDesc> bd;
     BlockDesc *d_bd = nullptr;
@@ -157,7 +170,7 @@ struct evpk_ctx {
     double *sendbuf = nullptr, *recvbuf = nullptr;   // [W edge | E edge] and [from east | from west]
     double *sendW = nullptr, *sendE = nullptr, *recvW = nullptr, *recvE = nullptr;
     double *foldbuf = nullptr, *foldloc = nullptr, *foldall = nullptr;
-    double2 *cbuf = nullptr;         // 4 x [25 planes][2 cols][rows] of double2: sendW, sendE, recvE, recvW
+    double2 *cbuf = nullptr;         // 4 x [25 planes][rows][8 cols] of double2: sendW, sendE, recvE, recvW
     size_t cslot = 0;
     int wmax = 0;
     std::vector<int> slab_i0;   // nranks+1 global start columns
@@ -270,33 +283,35 @@ static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int 
 }
 
 // ---- transport primitives (device pointers, ordered on c->stream) -----------------------------------
-// ring exchange with the west / east neighbour: n doubles each way.  With two ranks on a cyclic ring the
-// neighbours coincide and one message [sW | sE] goes each way, received as [rE | rW] (buffers contiguous).
-static int xp_ring(evpk_ctx *c, const double *sW, const double *sE, double *rE, double *rW, size_t n) {
+// ring exchange with the west / east neighbour; counts in doubles: nSW to the west, nSE to the east, nRE from the
+// east, nRW from the west.  With two ranks on a cyclic ring the neighbours coincide and one message [sW | sE] goes each
+// way, received as [rE | rW] (sE must follow sW and rW follow rE in memory).
+static int xp_ring(evpk_ctx *c, const double *sW, size_t nSW, const double *sE, size_t nSE, double *rE, size_t nRE, double *rW, size_t nRW) {
     const bool merged = (c->west == c->east && c->west >= 0);
+    if (merged && (sE != sW + nSW || rW != rE + nRE)) FAIL(c, "xp_ring: merged message needs contiguous buffers");
     if (c->relay) {
         int rc = 0;
         if (merged) {
-            rc |= c->relay->send(c->west, sW, 2 * n * 8, c->stream);
-            rc |= c->relay->recv(c->west, rE, 2 * n * 8, c->stream);
+            rc |= c->relay->send(c->west, sW, (nSW + nSE) * 8, c->stream);
+            rc |= c->relay->recv(c->west, rE, (nRE + nRW) * 8, c->stream);
         } else {
-            if (c->west >= 0) rc |= c->relay->send(c->west, sW, n * 8, c->stream);
-            if (c->east >= 0) rc |= c->relay->send(c->east, sE, n * 8, c->stream);
-            if (c->east >= 0) rc |= c->relay->recv(c->east, rE, n * 8, c->stream);
-            if (c->west >= 0) rc |= c->relay->recv(c->west, rW, n * 8, c->stream);
+            if (c->west >= 0) rc |= c->relay->send(c->west, sW, nSW * 8, c->stream);
+            if (c->east >= 0) rc |= c->relay->send(c->east, sE, nSE * 8, c->stream);
+            if (c->east >= 0) rc |= c->relay->recv(c->east, rE, nRE * 8, c->stream);
+            if (c->west >= 0) rc |= c->relay->recv(c->west, rW, nRW * 8, c->stream);
         }
         if (rc) FAIL(c, "shared-memory relay: exchange failed (%s)", rc & 2 ? "timeout" : "copy / size");
         return 0;
     }
     NCCLCHK(c, ncclGroupStart());
     if (merged) {
-        NCCLCHK(c, ncclSend(sW, 2 * n, ncclDouble, c->west, c->comm, c->stream));
-        NCCLCHK(c, ncclRecv(rE, 2 * n, ncclDouble, c->west, c->comm, c->stream));
+        if (nSW + nSE) NCCLCHK(c, ncclSend(sW, nSW + nSE, ncclDouble, c->west, c->comm, c->stream));
+        if (nRE + nRW) NCCLCHK(c, ncclRecv(rE, nRE + nRW, ncclDouble, c->west, c->comm, c->stream));
     } else {
-        if (c->west >= 0) NCCLCHK(c, ncclSend(sW, n, ncclDouble, c->west, c->comm, c->stream));
-        if (c->east >= 0) NCCLCHK(c, ncclSend(sE, n, ncclDouble, c->east, c->comm, c->stream));
-        if (c->east >= 0) NCCLCHK(c, ncclRecv(rE, n, ncclDouble, c->east, c->comm, c->stream));
-        if (c->west >= 0) NCCLCHK(c, ncclRecv(rW, n, ncclDouble, c->west, c->comm, c->stream));
+        if (c->west >= 0 && nSW) NCCLCHK(c, ncclSend(sW, nSW, ncclDouble, c->west, c->comm, c->stream));
+        if (c->east >= 0 && nSE) NCCLCHK(c, ncclSend(sE, nSE, ncclDouble, c->east, c->comm, c->stream));
+        if (c->east >= 0 && nRE) NCCLCHK(c, ncclRecv(rE, nRE, ncclDouble, c->east, c->comm, c->stream));
+        if (c->west >= 0 && nRW) NCCLCHK(c, ncclRecv(rW, nRW, ncclDouble, c->west, c->comm, c->stream));
     }
     NCCLCHK(c, ncclGroupEnd());
     return 0;
@@ -374,7 +389,7 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
                 HIPCHK(c, hipMemcpyAsync(c->recvW, c->sendE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
             }
         } else {
-            if (xp_ring(c, c->sendW, c->sendE, c->recvE, c->recvW, cnt)) return 1;
+            if (xp_ring(c, c->sendW, cnt, c->sendE, cnt, c->recvE, cnt, c->recvW, cnt)) return 1;
         }
         hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->recvW,
                            (const double *)c->recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
@@ -402,25 +417,37 @@ static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp
     }
 }
 
-// ---- two-column ghost zones of a list of pair planes (x-slab neighbours, all rows) -----------------
-static int exchange_cols(evpk_ctx *c, const PairList &pl) {
+// ---- ghost zones (zW columns per side) of a list of pair planes: x-slab neighbours ------------------------
+// compact: only the rows of the four zone windows that hold an active cell (lists made at prep), else all rows
+static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact) {
     Slab &s = c->s;
-    const int tx = 128, grow = (s.nyl + 2 + tx - 1) / tx;
+    const int W = c->zW, rows = s.nyl + 2;
     const int npl = pl.n + (pl.with_cmask ? 1 : 0);
     if (npl > 25) FAIL(c, "exchange_cols: too many planes");
-    const size_t cnt = (size_t)npl * 2 * (s.nyl + 2);      // double2 elements per direction
-    double2 *sendW = c->cbuf, *sendE = c->cbuf + cnt, *recvE = c->cbuf + 2 * c->cslot, *recvW = c->cbuf + 2 * c->cslot + cnt;
-    hipLaunchKernelGGL(k_cols_pack, dim3(grow), dim3(tx), 0, c->stream, s, pl, sendW, sendE);
+    ZoneRows zr;
+    if (compact) {
+        zr.sW = RowSet{c->d_zrows + 0 * rows, c->zn[0]}; zr.sE = RowSet{c->d_zrows + 1 * rows, c->zn[1]};
+        zr.rE = RowSet{c->d_zrows + 2 * rows, c->zn[2]}; zr.rW = RowSet{c->d_zrows + 3 * rows, c->zn[3]};
+    } else
+        zr.sW = zr.sE = zr.rE = zr.rW = RowSet{nullptr, rows};
+    // double2 elements per message; the slots are laid out back to back with the actual sizes (merged messages)
+    const size_t nSW = (size_t)npl * zr.sW.n * W, nSE = (size_t)npl * zr.sE.n * W;
+    const size_t nRE = (size_t)npl * zr.rE.n * W, nRW = (size_t)npl * zr.rW.n * W;
+    double2 *sendW = c->cbuf, *sendE = sendW + nSW, *recvE = c->cbuf + 2 * c->cslot, *recvW = recvE + nRE;
+    const int tx = 256;
+    const int nps = std::max(zr.sW.n, zr.sE.n) * W, npr = std::max(zr.rE.n, zr.rW.n) * W;
+    if (nps > 0) hipLaunchKernelGGL(k_cols_pack, dim3((nps + tx - 1) / tx), dim3(tx), 0, c->stream, s, pl, W, zr, sendW, sendE);
     if (c->nranks == 1) {              // forced exchange with myself (cyclic ring of one)
         if (c->west >= 0) {
-            HIPCHK(c, hipMemcpyAsync(recvE, sendW, sizeof(double2) * cnt, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(recvW, sendE, sizeof(double2) * cnt, hipMemcpyDeviceToDevice, c->stream));
+            if (nSW != nRE || nSE != nRW) FAIL(c, "exchange_cols: self-exchange row sets differ");
+            if (nSW) HIPCHK(c, hipMemcpyAsync(recvE, sendW, sizeof(double2) * nSW, hipMemcpyDeviceToDevice, c->stream));
+            if (nSE) HIPCHK(c, hipMemcpyAsync(recvW, sendE, sizeof(double2) * nSE, hipMemcpyDeviceToDevice, c->stream));
         }
     } else {
-        if (xp_ring(c, (const double *)sendW, (const double *)sendE, (double *)recvE, (double *)recvW, 2 * cnt)) return 1;
+        if (xp_ring(c, (const double *)sendW, 2 * nSW, (const double *)sendE, 2 * nSE, (double *)recvE, 2 * nRE, (double *)recvW, 2 * nRW)) return 1;
     }
-    hipLaunchKernelGGL(k_cols_unpack, dim3(grow), dim3(tx), 0, c->stream, s, pl, (const double2 *)recvW, (const double2 *)recvE,
-                       c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0);
+    if (npr > 0) hipLaunchKernelGGL(k_cols_unpack, dim3((npr + tx - 1) / tx), dim3(tx), 0, c->stream, s, pl, W, zr, (const double2 *)recvW,
+                       (const double2 *)recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -433,19 +460,20 @@ static PairList state_pairs(int SB) {
 
 static void destroy_impl(evpk_ctx *c) {
     if (!c) return;
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->relay) { c->relay->close_(); delete c->relay; }
-    void *ptrs[] = {c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
+    void *ptrs[] = {c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
                     c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
-    for (void *p : ptrs) if (p) hipFree(p);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->evI) hipEventDestroy(c->evI);
-    if (c->evX) hipEventDestroy(c->evX);
-    if (c->stream2) hipStreamDestroy(c->stream2);
-    for (auto e : c->kev) hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evI) (void)hipEventDestroy(c->evI);
+    if (c->evX) (void)hipEventDestroy(c->evX);
+    if (c->evE) (void)hipEventDestroy(c->evE);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (auto e : c->kev) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -492,13 +520,14 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     s.nxl = i1 - i0 + 1; s.nyl = j1 - j0 + 1; s.i0 = i0; s.j0 = j0; s.nxg = g->nx_global; s.nyg = g->ny_global;
     if (g->ns_boundary == EVPK_BND_TRIPOLE && (s.nyl < 2 || (g->nx_global & 1))) FAIL(c, "tripole needs ny >= 2 and even nx_global");
     c->full_cover = (covered == (long long)s.nxl * s.nyl);
-    s.pitch = ((C0 + s.nxl + 3 + 7) / 8) * 8;     // columns -1 .. nxl+2 (two ghost columns per side)
+    s.pitch = ((C0 + s.nxl + ZW_MAX + 1 + 7) / 8) * 8;     // columns 1-ZW_MAX .. nxl+ZW_MAX (ghost zones of up to ZW_MAX columns per side)
     s.rstride = NP * s.pitch;
 
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->evI, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->evE, hipEventDisableTiming));
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
     const size_t nd = slab_doubles(s), nm = mask_elems(s);
@@ -546,7 +575,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipMalloc(&c->d_counts, sizeof(unsigned long long) * 2));
     c->ncx2 = (s.nxl + STRIP2_W - 1) / STRIP2_W;
     {
-        const size_t n2 = (size_t)c->ncx2 * (s.nyl + 2);           // enough for any strip height >= 1
+        const size_t n2 = (size_t)((s.nxl + 2 * (ZW_MAX - 2) + STRIP2_W - 1) / STRIP2_W) * (s.nyl + 2);   // any strip height >= 1, any zone width
         HIPCHK(c, hipMalloc(&c->d_flags2, n2));
         HIPCHK(c, hipMalloc(&c->d_strips2, sizeof(int) * n2));
         HIPCHK(c, hipMalloc(&c->d_strips2e, sizeof(int) * n2));
@@ -576,9 +605,11 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipMemsetAsync(c->recvbuf, 0, sizeof(double) * 2 * eslot, c->stream));
     c->sendW = c->sendbuf; c->sendE = c->sendbuf + eslot;      // re-pointed per call: [W edge | E edge], nf*(nyl+2) each
     c->recvE = c->recvbuf; c->recvW = c->recvbuf + eslot;      // [east ghost | west ghost]
-    c->cslot = (size_t)25 * 2 * (s.nyl + 2);
+    c->cslot = (size_t)25 * ZW_MAX * (s.nyl + 2);
     HIPCHK(c, hipMalloc(&c->cbuf, sizeof(double2) * 4 * c->cslot));
     HIPCHK(c, hipMemsetAsync(c->cbuf, 0, sizeof(double2) * 4 * c->cslot, c->stream));
+    HIPCHK(c, hipMalloc(&c->d_zflags, (size_t)4 * (s.nyl + 2)));
+    HIPCHK(c, hipMalloc(&c->d_zrows, sizeof(int) * 4 * (s.nyl + 2)));
     if (g->ns_boundary == EVPK_BND_TRIPOLE) {
         HIPCHK(c, hipMalloc(&c->foldbuf, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg));
         HIPCHK(c, hipMemsetAsync(c->foldbuf, 0, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg, c->stream));
@@ -591,7 +622,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
             char nm[EVPK_UNIQUE_ID_BYTES + 1];
             memcpy(nm, (const char *)g->unique_id + 8, EVPK_UNIQUE_ID_BYTES - 8);
             nm[EVPK_UNIQUE_ID_BYTES - 8] = 0;
-            const size_t slot = std::max<size_t>((size_t)4 * c->cslot * sizeof(double2) / 2,
+            const size_t slot = std::max<size_t>((size_t)2 * c->cslot * sizeof(double2),
                                                  (size_t)c->max_nf * 2 * (size_t)g->nx_global * sizeof(double)) + 4096;
             c->relay = new ShmRelay();
             std::string err;
@@ -610,7 +641,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->slab_i0.resize(g->nranks + 1);
         HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * g->nranks, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(d_i0); hipFree(d_all);
+        (void)hipFree(d_i0); (void)hipFree(d_all);
         c->slab_i0[g->nranks] = g->nx_global + 1;
         c->wmax = 0;
         for (int r = 0; r < g->nranks; r++) {
@@ -669,6 +700,14 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
             // they are redone by band launches (x-slabs: without the edge/interior overlap, the fold all-gathers in between)
             c->band_mode = c->use_double = c->use_double && s.nyl >= 8;
         }
+        // ghost-zone depth: zM launches per exchange, zones of 2*zM columns; every slab must be able to supply them
+        int minw = s.nxl;
+        for (int r = 0; r < g->nranks; r++) minw = std::min(minw, c->slab_i0[r + 1] - c->slab_i0[r]);
+        const char *zm = getenv("EVPK_ZONE_M");
+        int m = zm ? atoi(zm) : ZW_MAX / 2;
+        m = std::max(1, std::min(m, std::min(ZW_MAX / 2, minw / 2)));
+        if (c->band_mode) m = 1;          // the fold is all-gathered after every subcycle anyway
+        c->zM = m; c->zW = 2 * m;
         std::vector<int> band(c->ncx);
         for (int k = 0; k < c->ncx; k++) band[k] = k;
         HIPCHK(c, hipMalloc(&c->d_band, sizeof(int) * c->ncx));
@@ -763,9 +802,10 @@ static int tune_R2(evpk_ctx *c) {
     Slab &s = c->s;
     HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int) * 32, c->stream));
     const int cyc = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;
+    const int G = c->zone_mode ? c->zW - 2 : 0;
     for (int k = 0; k < ncand; k++) {
         const int R = cand[k], nry = (s.nyl + 1 + R - 1) / R, tot = c->ncx2 * nry;
-        hipLaunchKernelGGL(k_strip_flags2, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, nry, R, cyc,
+        hipLaunchKernelGGL(k_strip_flags2, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, nry, R, cyc, G,
                            (unsigned char *)nullptr, c->d_tune + k);
     }
     unsigned int cnt[32];
@@ -826,13 +866,31 @@ extern "C" int evpk_prep(evpk_ctx *c) {
                            s.nyl - 4, s.nyl + 1);
     c->fresh = false;
     c->zone_mode = c->use_double && (c->nranks > 1 || c->force_exchange);
+    const int G = c->zone_mode ? c->zW - 2 : 0;
+    c->ncx2 = (s.nxl + 2 * G + STRIP2_W - 1) / STRIP2_W;
+    c->zcompact = false;
+    std::vector<unsigned char> zflags;
     if (c->zone_mode) {
-        // two-column ghost zones for k_subcycle2: every plane it reads, the current state and the masks, once per evp
+        // ghost zones for k_subcycle2: every plane it reads, the current state and the masks, all rows, once per evp
         PairList pl = state_pairs(SA);
-        const int stat[] = {F_CXP, F_CXM, F_DXT, F_DXHY, F_TINYAREA, F_HTN, F_VRELC, F_UOCN, F_FORCEX, F_UMASSDTI, F_UVEL_INIT};
-        for (int f : stat) pl.p[pl.n++] = f >> 1;
+        const int per_evp[] = {F_TINYAREA /* + strength */, F_VRELC, F_UOCN, F_FORCEX, F_UMASSDTI, F_UVEL_INIT};
+        const int once[] = {F_CXP, F_CXM, F_DXT, F_DXHY, F_HTN};        // grid metrics: the first evp only
+        for (int f : per_evp) pl.p[pl.n++] = f >> 1;
+        if (!c->zone_metrics_done)
+            for (int f : once) pl.p[pl.n++] = f >> 1;
+        c->zone_metrics_done = true;
         pl.with_cmask = 1;
-        if (exchange_cols(c, pl)) return 1;
+        if (exchange_cols(c, pl, false)) return 1;
+        // the other state buffer starts from the same zone image: cells no kernel writes are alike in both for good
+        const int nz = 2 * c->zW * (s.nyl + 2);
+        hipLaunchKernelGGL(k_zone_copy, dim3((nz + 255) / 256), dim3(256), 0, c->stream, s, c->zW, SA, SB, NSTATE / 2);
+        if (!c->band_mode) {      // (tripole: the fold rewrites the top rows of every column, active or not)
+            hipLaunchKernelGGL(k_zone_rows, dim3((s.nyl + 2 + 127) / 128), dim3(128), 0, c->stream, s, c->zW, c->d_zflags);
+            zflags.resize((size_t)4 * (s.nyl + 2));
+            HIPCHK(c, hipMemcpyAsync(zflags.data(), c->d_zflags, zflags.size(), hipMemcpyDeviceToHost, c->stream));
+        }
+        c->zone_left = c->zM;
+        c->inner_ok = true;
     }
     // active strips
     const int ns_tot = c->ncx * c->nry;
@@ -844,7 +902,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     std::vector<unsigned char> flags2(c->use_double ? ns_tot2 : 0);
     if (c->use_double) {
         hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry2, c->R2,
-                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, c->d_flags2, (unsigned int *)nullptr);
+                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, G, c->d_flags2, (unsigned int *)nullptr);
         HIPCHK(c, hipMemcpyAsync(flags2.data(), c->d_flags2, ns_tot2, hipMemcpyDeviceToHost, c->stream));
     }
     std::vector<unsigned char> flags(ns_tot);
@@ -862,16 +920,30 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         for (int k = 0; k < ns_tot2; k++) if (flags2[k]) list2.push_back(k);
         c->nstrips2 = (int)list2.size();
         if (c->nstrips2) HIPCHK(c, hipMemcpyAsync(c->d_strips2, list2.data(), sizeof(int) * list2.size(), hipMemcpyHostToDevice, c->stream));
-        // edge strips own the columns that the neighbours need (1,2 and nxl-1,nxl); they run first, the rest overlaps the exchange
+        // interior strips neither read a ghost zone nor write a column the neighbours are sent (1..zW, nxl-zW+1..nxl):
+        // lane 0 of strip cx sits at column x0 = cx*61 - G, the strip reads x0-1 .. x0+63 and stores x0+1 .. x0+61.
+        // The edge strips run first, the interior overlaps the exchange.
         std::vector<int> le, li;
         for (int k : list2) {
-            const int cx = k % c->ncx2;
-            if (cx == 0 || cx >= c->ncx2 - 2) le.push_back(k); else li.push_back(k);
+            const int x0 = (k % c->ncx2) * STRIP2_W - G;
+            if (x0 >= c->zW && x0 <= s.nxl - c->zW - STRIP2_W) li.push_back(k); else le.push_back(k);
         }
         c->nstrips2e = (int)le.size(); c->nstrips2i = (int)li.size();
         if (c->nstrips2e) HIPCHK(c, hipMemcpyAsync(c->d_strips2e, le.data(), sizeof(int) * le.size(), hipMemcpyHostToDevice, c->stream));
         if (c->nstrips2i) HIPCHK(c, hipMemcpyAsync(c->d_strips2i, li.data(), sizeof(int) * li.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // the host vectors go out of scope
+    }
+    if (!zflags.empty()) {          // compacted row lists of the four zone windows
+        const int rows = s.nyl + 2;
+        std::vector<int> zl((size_t)4 * rows, 0);
+        for (int w = 0; w < 4; w++) {
+            int n = 0;
+            for (int j = 0; j < rows; j++) if (zflags[(size_t)w * rows + j]) zl[(size_t)w * rows + n++] = j;
+            c->zn[w] = n;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_zrows, zl.data(), sizeof(int) * zl.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->zcompact = true;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->icellt = (long long)cnt[0];
@@ -914,33 +986,67 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     };
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->double_launches = 0;
-    bool in_overlap = false;
+    c->zone_exchanges = 0;
+    c->zone_bytes = 0;
+    bool pendingI = false;      // an interior launch on stream2 that `stream` has not waited for yet
+    bool evE_valid = false;     // evE marks the latest kernel launch on `stream`
+    const int G = c->zone_mode ? c->zW - 2 : 0;
+    auto join = [&]() -> int {  // `stream` continues after the interior strips on stream2
+        if (!pendingI) return 0;
+        pendingI = false;
+        return hipStreamWaitEvent(c->stream, c->evI, 0) != hipSuccess;
+    };
+    // refresh the ghost zones of state buffer `SBUF` from the neighbours (it must hold the current state)
+    auto zone_exchange = [&](int SBUF) -> int {
+        if (exchange_cols(c, state_pairs(SBUF), c->zcompact)) return 1;
+        c->zone_exchanges++;
+        c->zone_bytes += (long long)(NSTATE / 2) * c->zW * 16 *
+                         ((c->west >= 0 ? (c->zcompact ? c->zn[0] : s.nyl + 2) : 0) + (c->east >= 0 ? (c->zcompact ? c->zn[1] : s.nyl + 2) : 0));
+        c->zone_left = c->zM;
+        c->inner_ok = true;
+        return 0;
+    };
     for (int n = 0; n < nsub;) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0;
+        a.R = c->R; a.jb0 = 0; a.G = 0;
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
-        // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics)
-        if (c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte && c->zone_mode && c->overlap && !c->band_mode) {
-            // x-slabs: edge strips first on `stream`, then the exchange of the two edge columns there, while the interior
-            // strips run on `stream2`.  Step k's kernels need exchange k-1 (ghost zones of the buffer they read) and all of
-            // step k-1's kernels; the exchange writes ghost zones of the buffer being WRITTEN, which no kernel of step k reads.
-            a.ncx = c->ncx2; a.wrap = 0; a.R = c->R2;
-            if (!in_overlap) {          // enter: stream2 picks up after everything queued on stream so far
-                HIPCHK(c, hipEventRecord(c->evX, c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evX, 0));
-                HIPCHK(c, hipEventRecord(c->evI, c->stream2));
-                in_overlap = true;
+        // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
+        const bool pair_inside = c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
+        // ... or, outside the tripole band mode, when the second of them is the last one (k_subcycle2<.., LAST2>)
+        const bool pair_ends_evp = c->use_double && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte) && !c->band_mode;
+        if (pair_inside || pair_ends_evp) {
+            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
+            a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
+            if (c->zone_mode && c->zone_left < 1) {         // (a one-subcycle launch or a partial call came before)
+                if (join()) FAIL(c, "hipStreamWaitEvent failed");
+                if (zone_exchange(a.sr)) return 1;
             }
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));          // interior of step k-1
-            if (c->nstrips2e > 0) {
+            // x-slabs: the launch that uses up the zones runs its edge strips first on `stream`, followed by the exchange
+            // of the edge columns there, while the interior strips run on `stream2`
+            const bool split = c->zone_mode && c->overlap && !c->band_mode && pair_inside && c->zone_left == 1 &&
+                               c->nstrips2e > 0 && c->nstrips2i > 0;
+            if (!split) {
+                if (join()) FAIL(c, "hipStreamWaitEvent failed");
+                if (c->nstrips2 > 0) {
+                    if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
+                    launch_sub2(c, a, c->stream, revp, pair_ends_evp);
+                    if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
+                    c->kev_is_double[c->kernel_launches] = 1;
+                    c->kernel_launches++;
+                    c->double_launches++;
+                }
+                evE_valid = false;
+            } else {
+                // edge(k) reads everything round k-1 wrote near the edges: interior(k-1) on stream2, the exchange on stream
+                if (join()) FAIL(c, "hipStreamWaitEvent failed");
+                if (!evE_valid) HIPCHK(c, hipEventRecord(c->evE, c->stream));      // round k-1 was a plain launch on `stream`
                 a.strips = c->d_strips2e; a.nstrips = c->nstrips2e;
                 launch_sub2(c, a, c->stream, revp, false);
-            }
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evX, 0));         // exchange k-1 (and with it edge k-1)
-            if (c->nstrips2i > 0) {
+                // interior(k) needs round k-1's kernels, not its exchange: it reads no ghost zone
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evE, 0));
                 a.strips = c->d_strips2i; a.nstrips = c->nstrips2i;
                 if (ev_begin(c->stream2)) FAIL(c, "hipEventRecord failed");
                 launch_sub2(c, a, c->stream2, revp, false);
@@ -948,42 +1054,17 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 c->kev_is_double[c->kernel_launches] = 1;
                 c->kernel_launches++;
                 c->double_launches++;
-            } else if (c->nstrips2e > 0) {      // all strips are edge strips (narrow slab): count the step once
-                c->kev_is_double[c->kernel_launches] = 1;
-                c->kernel_launches++;
-                c->double_launches++;
-            }
-            HIPCHK(c, hipEventRecord(c->evI, c->stream2));
-            c->ksub += 2;
-            n += 2;
-            c->cur ^= 1;
-            if (exchange_cols(c, state_pairs(c->cur ? F_STATE1 : F_STATE0))) return 1;
-            HIPCHK(c, hipEventRecord(c->evX, c->stream));
-            continue;
-        }
-        if (in_overlap) {               // leave: stream waits for the last interior launch
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));
-            in_overlap = false;
-        }
-        // ... or, outside the tripole band mode, when the second of them is the last one (k_subcycle2<.., LAST2>)
-        const bool pair_ends_evp = (c->ksub + 2 == c->p.ndte) && !c->band_mode;
-        if (c->use_double && nsub - n >= 2 && (c->ksub + 2 < c->p.ndte || pair_ends_evp)) {
-            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2;
-            a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
-            if (c->nstrips2 > 0) {
-                if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
-                launch_sub2(c, a, c->stream, revp, pair_ends_evp);
-                if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
-                c->kev_is_double[c->kernel_launches] = 1;
-                c->kernel_launches++;
-                c->double_launches++;
+                HIPCHK(c, hipEventRecord(c->evI, c->stream2));
+                pendingI = true;
+                HIPCHK(c, hipEventRecord(c->evE, c->stream));
+                evE_valid = true;
             }
             if (c->band_mode) {
                 // tripole: rows next to the fold again, one subcycle at a time with the fold in between
                 //   band 1: T rows nyl-2..nyl+1, U rows nyl-2..nyl   state `sr` -> scratch;  fold(scratch)
                 //   band 2: T rows nyl-1..nyl+1, U rows nyl-1..nyl   scratch -> state `sw`;  fold(sw)
                 SubArgs b1 = a;
-                b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0;
+                b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0; b1.G = 0;
                 b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
                 SubArgs b2 = b1;
                 b2.R = 3; b2.jb0 = s.nyl - 1; b2.sr = F_STATE2; b2.sw = a.sw;
@@ -998,9 +1079,19 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             c->ksub += 2;
             n += 2;
             c->cur ^= 1;
-            if (c->zone_mode && exchange_cols(c, state_pairs(c->cur ? F_STATE1 : F_STATE0))) return 1;
+            if (c->zone_mode) {
+                c->zone_left--;
+                c->inner_ok = c->zone_left >= 1;
+                // the zones are used up (in a split round this overlaps the interior strips), or the evp is complete
+                if (c->zone_left < 1 || pair_ends_evp) {
+                    if (!split && join()) FAIL(c, "hipStreamWaitEvent failed");
+                    if (zone_exchange(c->cur ? F_STATE1 : F_STATE0)) return 1;
+                }
+            }
             continue;
         }
+        if (join()) FAIL(c, "hipStreamWaitEvent failed");
+        if (c->zone_mode && !c->inner_ok && zone_exchange(a.sr)) return 1;
         c->ksub++;
         n++;
         a.strips = c->d_strips; a.nstrips = c->nstrips; a.ncx = c->ncx; a.wrap = wrap ? 1 : 0;
@@ -1015,12 +1106,16 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
             c->kernel_launches++;
         }
+        evE_valid = false;
         c->cur ^= 1;
         if (need_halo) {                                                          // ice_dyn_evp.F90:392-400
             if (halo(c, (c->cur ? F_STATE1 : F_STATE0) + S_U, 2, true, true, 0.0)) return 1;
         }
+        if (c->zone_mode) { c->zone_left = 0; c->inner_ok = true; }     // one ghost column is current, the deeper zone is not
     }
-    if (in_overlap) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evI, 0));
+    if (join()) FAIL(c, "hipStreamWaitEvent failed");
+    // leave the ghost columns 0 / nxl+1 of the state current (download, finish, a later one-subcycle launch)
+    if (c->zone_mode && !c->inner_ok && zone_exchange(c->cur ? F_STATE1 : F_STATE0)) return 1;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -1143,5 +1238,6 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->kernel_ms = c->kernel_ms; o->kernel_launches = c->kernel_launches - c->double_launches;
     o->kernel2_ms = c->kernel2_ms; o->kernel2_launches = c->double_launches;
     o->strip_rows = c->R; o->strip_rows2 = c->use_double ? c->R2 : 0; o->nstrips2 = c->use_double ? c->nstrips2 : 0;
+    o->zone_cols = c->zone_mode ? c->zW : 0; o->zone_exchanges = c->zone_exchanges; o->zone_bytes = c->zone_bytes;
     return 0;
 }

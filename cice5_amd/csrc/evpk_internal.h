@@ -10,7 +10,8 @@
 //  * all planes of one row are contiguous (~2 MB), so a wave marching north touches one
 //    or two pages per row instead of ~50 planes 78 MB apart (TLB reach, DRAM locality);
 //  * i = 0 is the west ghost column, i = 1..nxl physical, i = nxl+1 the east ghost column;
-//    C0 = 7 puts i = 1 on a 128-byte boundary, pitch is a multiple of 8 cells.
+//    C0 = 7 puts i = 1 on a 128-byte boundary, pitch is a multiple of 8 cells; columns 1-ZW_MAX .. -1 and
+//    nxl+2 .. nxl+ZW_MAX are the deeper ghost zones of the two-subcycle kernel between x-slab neighbours.
 // Integer / byte masks are separate planes with the same (pitch, C0) but no interleave.
 // The ice_blocks decomposition is the unit of host<->device transfer (gather/scatter
 // kernels) and of sharding over GPUs; inside a GPU the blocks are fused into the slab so
@@ -46,6 +47,8 @@ constexpr int NP = (F_COUNT + 1) / 2;
 static_assert(F_STATE0 % 2 == 0 && F_VRELC % 2 == 0, "pairs must start on even field ids");
 
 constexpr int C0 = 7;                // column offset of the west ghost (cells)
+constexpr int ZW_MAX = 8;            // widest ghost zone per side (x-slab neighbours): columns 1-ZW_MAX .. 0 and nxl+1 .. nxl+ZW_MAX
+static_assert(C0 >= ZW_MAX - 1, "the west ghost zone must fit in front of column 1");
 constexpr int STRIP_W = 63;          // U columns per wave strip (64 T columns)
 
 // cmask bits

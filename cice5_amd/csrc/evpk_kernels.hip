@@ -437,56 +437,74 @@ __global__ void k_ew_unpack(Slab s, int f, int nf, const double *recvW, const do
 // ------------------------------------------------------------------------------------
 struct PairList { int n; int with_cmask; int p[24]; };
 
-__global__ void k_cols_pack(Slab s, PairList pl, double2 *sendW, double2 *sendE) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > s.nyl + 1) return;
-    const int rows = s.nyl + 2;
+// rows taken by one side of a ghost-zone message: all rows (idx == nullptr, n = nyl+2) or a compacted list
+struct RowSet { const int *idx; int n; };
+struct ZoneRows { RowSet sW, sE, rE, rW; };     // my W edge -> west, my E edge -> east, east zone <- east, west zone <- west
+
+// message layout: buf[(q*n + jj)*W + k] of double2, q = plane, jj = position in the row set, k = column (ascending)
+__global__ void k_cols_pack(Slab s, PairList pl, int W, ZoneRows zr, double2 *sendW, double2 *sendE) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = idx % W, jj = idx / W;
     const double2 *F2 = reinterpret_cast<const double2 *>(s.F);
-    for (int q = 0; q < pl.n; q++) {
-        const double2 *row = F2 + (size_t)j * s.rstride + (size_t)pl.p[q] * s.pitch + C0;
-        sendW[((size_t)q * 2 + 0) * rows + j] = row[1];
-        sendW[((size_t)q * 2 + 1) * rows + j] = row[2];
-        sendE[((size_t)q * 2 + 0) * rows + j] = row[s.nxl - 1];
-        sendE[((size_t)q * 2 + 1) * rows + j] = row[s.nxl];
-    }
-    if (pl.with_cmask) {
-        const unsigned char *m = s.cmask + (size_t)j * s.pitch + C0;
-        const int q = pl.n;
-        sendW[((size_t)q * 2 + 0) * rows + j] = make_double2((double)m[1], 0.0);
-        sendW[((size_t)q * 2 + 1) * rows + j] = make_double2((double)m[2], 0.0);
-        sendE[((size_t)q * 2 + 0) * rows + j] = make_double2((double)m[s.nxl - 1], 0.0);
-        sendE[((size_t)q * 2 + 1) * rows + j] = make_double2((double)m[s.nxl], 0.0);
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const RowSet rs = side ? zr.sE : zr.sW;
+        if (jj >= rs.n) continue;
+        const int j = rs.idx ? rs.idx[jj] : jj;
+        const int col = (side ? s.nxl - W + 1 : 1) + k;
+        double2 *dst = side ? sendE : sendW;
+        for (int q = 0; q < pl.n; q++)
+            dst[((size_t)q * rs.n + jj) * W + k] = F2[(size_t)j * s.rstride + (size_t)pl.p[q] * s.pitch + C0 + col];
+        if (pl.with_cmask)
+            dst[((size_t)pl.n * rs.n + jj) * W + k] = make_double2((double)s.cmask[(size_t)j * s.pitch + C0 + col], 0.0);
     }
 }
 
-__global__ void k_cols_unpack(Slab s, PairList pl, const double2 *recvW, const double2 *recvE, int haveW, int haveE) {
+__global__ void k_cols_unpack(Slab s, PairList pl, int W, ZoneRows zr, const double2 *recvW, const double2 *recvE, int haveW, int haveE) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = idx % W, jj = idx / W;
+    double2 *F2 = reinterpret_cast<double2 *>(s.F);
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        if (!(side ? haveE : haveW)) continue;
+        const RowSet rs = side ? zr.rE : zr.rW;
+        if (jj >= rs.n) continue;
+        const int j = rs.idx ? rs.idx[jj] : jj;
+        const int col = (side ? s.nxl + 1 : 1 - W) + k;
+        const double2 *src = side ? recvE : recvW;
+        for (int q = 0; q < pl.n; q++)
+            F2[(size_t)j * s.rstride + (size_t)pl.p[q] * s.pitch + C0 + col] = src[((size_t)q * rs.n + jj) * W + k];
+        if (pl.with_cmask)
+            s.cmask[(size_t)j * s.pitch + C0 + col] = (unsigned char)src[((size_t)pl.n * rs.n + jj) * W + k].x;
+    }
+}
+
+// rows of the four W-column windows that hold an active cell (flags[4][nyl+2]: send W, send E, recv E, recv W).  A row
+// without one is never written by the subcycle kernels, so its zone image stays what the full exchange at prep made it.
+__global__ void k_zone_rows(Slab s, int W, unsigned char *flags) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > s.nyl + 1) return;
     const int rows = s.nyl + 2;
+    const unsigned char *m = s.cmask + (size_t)j * s.pitch + C0;
+    const int c0[4] = {1, s.nxl - W + 1, s.nxl + 1, 1 - W};
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        unsigned char any = 0;
+        for (int k = 0; k < W; k++) any |= m[c0[w] + k];
+        flags[(size_t)w * rows + j] = any ? 1 : 0;
+    }
+}
+
+// zone columns of nf/2 pair planes, all rows: fdst := fsrc (the other state buffer starts from the same zone image)
+__global__ void k_zone_copy(Slab s, int W, int fsrc, int fdst, int npairs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = idx % (2 * W), j = idx / (2 * W);
+    if (j > s.nyl + 1) return;
+    const int col = k < W ? 1 - W + k : s.nxl + 1 + (k - W);
     double2 *F2 = reinterpret_cast<double2 *>(s.F);
-    for (int q = 0; q < pl.n; q++) {
-        double2 *row = F2 + (size_t)j * s.rstride + (size_t)pl.p[q] * s.pitch + C0;
-        if (haveE) {
-            row[s.nxl + 1] = recvE[((size_t)q * 2 + 0) * rows + j];
-            row[s.nxl + 2] = recvE[((size_t)q * 2 + 1) * rows + j];
-        }
-        if (haveW) {
-            row[-1] = recvW[((size_t)q * 2 + 0) * rows + j];
-            row[0] = recvW[((size_t)q * 2 + 1) * rows + j];
-        }
-    }
-    if (pl.with_cmask) {
-        unsigned char *m = s.cmask + (size_t)j * s.pitch + C0;
-        const int q = pl.n;
-        if (haveE) {
-            m[s.nxl + 1] = (unsigned char)recvE[((size_t)q * 2 + 0) * rows + j].x;
-            m[s.nxl + 2] = (unsigned char)recvE[((size_t)q * 2 + 1) * rows + j].x;
-        }
-        if (haveW) {
-            m[-1] = (unsigned char)recvW[((size_t)q * 2 + 0) * rows + j].x;
-            m[0] = (unsigned char)recvW[((size_t)q * 2 + 1) * rows + j].x;
-        }
-    }
+    for (int q = 0; q < npairs; q++)
+        F2[(size_t)j * s.rstride + (size_t)((fdst >> 1) + q) * s.pitch + C0 + col] =
+            F2[(size_t)j * s.rstride + (size_t)((fsrc >> 1) + q) * s.pitch + C0 + col];
 }
 
 // one wave per strip: is there any T work (cols cx*63+1..+64, rows jb..jb+R) or U work?
@@ -537,6 +555,7 @@ struct SubArgs {
     int nstrips, ncx, R, wrap;
     int sr, sw;        // field ids of the state buffer read / written (F_STATE0, F_STATE1 or F_STATE2)
     int jb0;           // > 0: band launch -- every strip starts at row jb0 (tripole top band), strips[] holds cx only
+    int G;             // k_subcycle2 in ghost-zone mode: columns 1-G .. nxl+G are advanced (zones of G+2 columns per side)
 };
 
 __device__ __forceinline__ double shfl_dn1(double x) { return __shfl_down(x, 1); }
@@ -851,7 +870,8 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
     const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
-    const int c = cx * STRIP2_W + lane;               // unwrapped column of this lane (lane 1 = first owned column)
+    const int G = a.G;
+    const int c = cx * STRIP2_W + lane - G;           // unwrapped column of this lane (lane 1 = first owned column)
     const int jb = ry * R + 1;
     const bool cyc = a.wrap != 0;
 
@@ -863,16 +883,17 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
         cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
         okc = okm = true;
     } else {
-        // ghost-zone mode: storage has two ghost columns per side (-1, 0 | nxl+1, nxl+2); on an open / closed
-        // single-rank boundary they hold zeros and inactive masks, between ranks the neighbour's columns
-        okc = (c >= -1 && c <= nxl + 2);
-        okm = (cm1 >= -1 && cm1 <= nxl + 2);
+        // ghost-zone mode: storage has G+2 ghost columns per side (-1-G .. 0 | nxl+1 .. nxl+2+G); on an open / closed
+        // boundary they hold zeros and inactive masks, between ranks the neighbour's columns.  The zone loses two
+        // valid columns per launch, so it lasts (G+2)/2 launches between exchanges.
+        okc = (c >= -1 - G && c <= nxl + 2 + G);
+        okm = (cm1 >= -1 - G && cm1 <= nxl + 2 + G);
         if (!okc) ci = 0;
         if (!okm) cm1 = 0;
     }
-    const bool tcol = cyc ? true : (c >= 0 && c <= nxl + 2);       // column can hold an active T cell
-    const bool ucol = cyc ? true : (c >= 0 && c <= nxl + 1);       // ... an active U cell
-    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 && c <= nxl);   // columns this lane stores
+    const bool tcol = cyc ? true : (c >= -G && c <= nxl + 2 + G);      // column can hold an active T cell
+    const bool ucol = cyc ? true : (c >= -G && c <= nxl + 1 + G);      // ... an active U cell
+    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);   // columns this lane stores
 
     const size_t pp = (size_t)s.pitch * 16;
     const size_t rowb = (size_t)s.rstride * 16;
@@ -1066,7 +1087,8 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
     const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
-    const int c = cx * STRIP2_W + lane;
+    const int G = a.G;
+    const int c = cx * STRIP2_W + lane - G;
     const int jb = ry * R + 1;
     const bool cyc = a.wrap != 0;
 
@@ -1077,14 +1099,14 @@ __global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
         cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
         okc = okm = true;
     } else {
-        okc = (c >= -1 && c <= nxl + 2);
-        okm = (cm1 >= -1 && cm1 <= nxl + 2);
+        okc = (c >= -1 - G && c <= nxl + 2 + G);
+        okm = (cm1 >= -1 - G && cm1 <= nxl + 2 + G);
         if (!okc) ci = 0;
         if (!okm) cm1 = 0;
     }
-    const bool tcol = cyc ? true : (c >= 0 && c <= nxl + 2);
-    const bool ucol = cyc ? true : (c >= 0 && c <= nxl + 1);
-    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 && c <= nxl);
+    const bool tcol = cyc ? true : (c >= -G && c <= nxl + 2 + G);
+    const bool ucol = cyc ? true : (c >= -G && c <= nxl + 1 + G);
+    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);
 
     const size_t pp = (size_t)s.pitch * 16;
     const size_t rowb = (size_t)s.rstride * 16;
@@ -1311,16 +1333,16 @@ template __global__ void k_subcycle2<true, true>(SubArgs);
 
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
-__global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, unsigned char *flags, unsigned int *count) {
+__global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, unsigned char *flags, unsigned int *count) {
     const int sid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (sid >= ncx * nry) return;
     const int cx = sid % ncx, ry = sid / ncx;
-    const int c = cx * STRIP2_W + lane;
+    const int c = cx * STRIP2_W + lane - G;
     int ci = c;
     bool ok;
     if (cyc) { ci = (c - 1) % s.nxl; if (ci < 0) ci += s.nxl; ci += 1; ok = true; }
-    else ok = (c >= 0 && c <= s.nxl + 2);
+    else ok = (c >= -G && c <= s.nxl + 2 + G);
     const int jb = ry * R + 1;
     int any = 0;
     if (ok)

@@ -67,7 +67,8 @@ class Stats(ct.Structure):
                 ("nstrips", ct.c_int32), ("nstrips_total", ct.c_int32), ("subcycles_done", ct.c_int32),
                 ("loop_ms", ct.c_float), ("kernel_ms", ct.c_float), ("kernel_launches", ct.c_int32),
                 ("kernel2_ms", ct.c_float), ("kernel2_launches", ct.c_int32),
-                ("strip_rows", ct.c_int32), ("strip_rows2", ct.c_int32), ("nstrips2", ct.c_int32)]
+                ("strip_rows", ct.c_int32), ("strip_rows2", ct.c_int32), ("nstrips2", ct.c_int32),
+                ("zone_cols", ct.c_int32), ("zone_exchanges", ct.c_int32), ("zone_bytes", ct.c_int64)]
 
 
 EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",

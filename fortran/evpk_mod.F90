@@ -72,6 +72,8 @@
          real (c_float) :: kernel2_ms
          integer (c_int32_t) :: kernel2_launches
          integer (c_int32_t) :: strip_rows, strip_rows2, nstrips2
+         integer (c_int32_t) :: zone_cols, zone_exchanges
+         integer (c_int64_t) :: zone_bytes
       end type evpk_stats
 
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &

@@ -127,6 +127,9 @@ typedef struct {
     int32_t kernel2_launches;
     int32_t strip_rows, strip_rows2;   /* strip heights in use: k_subcycle, k_subcycle2 (auto-tuned) */
     int32_t nstrips2;
+    int32_t zone_cols;                 /* x-slabs: ghost-zone width per side (2 x launches per exchange); 0 = no ghost zones */
+    int32_t zone_exchanges;            /* ghost-zone exchanges with the slab neighbours in the last evpk_subcycle call */
+    int64_t zone_bytes;                /* bytes this rank sent in them */
 } evpk_stats;
 
 /* rank 0 creates the RCCL id; the host model broadcasts the bytes (MPI_Bcast in CICE,

@@ -55,9 +55,10 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
             bad += [(call,) + x for x in util.compare(d, f, ref)]
         st = s.ctx.stats()
         s.close()
-        q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()), time.time() - t0))
+        q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()), time.time() - t0,
+               int(st.zone_cols), int(st.zone_exchanges)))
     except Exception:
-        q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0))
+        q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0, 0, 0))
 
 
 def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None):
@@ -82,7 +83,7 @@ def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None):
         except OSError:
             pass
     assert len(res) == world
-    for rank, bad, icellu, k2, umax, secs in res:
+    for rank, bad, icellu, k2, umax, secs, zc, zx in res:
         assert not bad, f"rank {rank}: {bad}"
     assert max(r[4] for r in res) > 1e-3
     print(f"[{world} ranks {ns}] worker seconds: {[round(r[5], 1) for r in res]}")
@@ -93,6 +94,25 @@ def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None):
 def test_x_slabs_open(world):
     res = _run(world, "open", 240, 64, 20, 32, ndte=31)
     assert all(r[3] > 0 for r in res)          # the two-subcycle kernel ran on every rank (ghost-zone mode)
+    assert all(r[6] == 8 for r in res)         # default: zones of 8 columns, an exchange every 4th launch
+
+
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_ghost_zone_depth(m):
+    """EVPK_ZONE_M launches of the two-subcycle kernel per exchange (zones of 2*m columns, default 4): the redundant
+    zone columns and the compacted row lists must leave every rank bit-identical to the oracle.  Odd ndte and a
+    second call cover the one-subcycle tail and the re-made row lists."""
+    res = _run(3, "open", 240, 64, 20, 32, ndte=31, env={"EVPK_ZONE_M": str(m)})
+    assert all(r[3] > 0 for r in res)
+    # 15 two-subcycle launches + the one-subcycle tail (its own one-column halo): an exchange after every m-th launch
+    assert all(r[6] == 2 * m and r[7] == 15 // m for r in res), [(r[6], r[7]) for r in res]
+    _run(2, "open", 240, 64, 40, 64, ndte=26, env={"EVPK_ZONE_M": str(m), "EVPK_OVERLAP": "0"})
+
+
+def test_narrow_slabs_limit_the_zone_depth():
+    """Slabs of 6 columns can only feed zones of 6 (m = 3); slabs of 4 columns zones of 4."""
+    assert all(r[6] == 6 for r in _run(4, "open", 24, 40, 6, 20, ndte=22))
+    assert all(r[6] == 4 for r in _run(4, "open", 16, 40, 4, 20, ndte=22))
 
 
 def test_cfg4_1440x1080_on_four_ranks():

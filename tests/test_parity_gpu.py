@@ -139,6 +139,15 @@ def test_strip_rows_do_not_matter():
         assert not util.compare(d, g, out[0])
 
 
+@pytest.mark.parametrize("m", [1, 2, 4])
+def test_forced_exchange_zone_depth(m, monkeypatch):
+    """Self-exchange on a cyclic ring of one rank with ghost zones of 2*m columns (EVPK_ZONE_M)."""
+    monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+    monkeypatch.setenv("EVPK_ZONE_M", str(m))
+    _both(200, 96, 50, 48, land="continents", ndte=31, ncalls=2)
+    _both(130, 60, 130, 60, ice="full", ndte=18, revised_evp=True)
+
+
 @pytest.mark.parametrize("ns", ["open", "tripole"])
 def test_forced_exchange_path(ns, monkeypatch):
     """EVPK_FORCE_EXCHANGE=1 makes a single rank take the multi-rank code path (pack edge columns ->
