@@ -583,9 +583,6 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         HIPCHK(c, hipMalloc(&c->d_tune, sizeof(unsigned int) * 32));
         c->R2 = c->R;
         c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->prefetch ? (const void *)k_subcycle2p<false, false, false> : (const void *)k_subcycle2<false, false>, 256, 0) == hipSuccess && nb > 0)
-            c->slots2 = nb * prop.multiProcessorCount;
     }
     { const char *e = getenv("EVPK_OVERLAP"); c->overlap = !(e && atoi(e) == 0); }
     { const char *e = getenv("EVPK_PREFETCH"); c->prefetch = !(e && atoi(e) == 0); }
@@ -712,6 +709,13 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         for (int k = 0; k < c->ncx; k++) band[k] = k;
         HIPCHK(c, hipMalloc(&c->d_band, sizeof(int) * c->ncx));
         HIPCHK(c, hipMemcpy(c->d_band, band.data(), sizeof(int) * c->ncx, hipMemcpyHostToDevice));
+    }
+    {   // resident workgroups of the two-subcycle kernel variant this context launches (strip-height tuner)
+        int nb = 0;
+        const void *fn = !c->prefetch ? (const void *)k_subcycle2<false, false>
+                                      : (c->compact ? (const void *)k_subcycle2p<false, false, true> : (const void *)k_subcycle2p<false, false, false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0)
+            c->slots2 = nb * prop.multiProcessorCount;
     }
     const char *tk = getenv("EVPK_TIME_KERNELS");
     c->time_kernels = tk ? std::max(0, std::min(atoi(tk), 2)) : 1;

@@ -558,8 +558,21 @@ struct SubArgs {
     int G;             // k_subcycle2 in ghost-zone mode: columns 1-G .. nxl+G are advanced (zones of G+2 columns per side)
 };
 
-__device__ __forceinline__ double shfl_dn1(double x) { return __shfl_down(x, 1); }
-__device__ __forceinline__ double shfl_up1(double x) { return __shfl_up(x, 1); }
+// Neighbour-lane exchange as DPP whole-wave shifts (v_mov_b32_dpp wave_shl:1 / wave_shr:1, VALU only) instead of
+// ds_bpermute through the LDS crossbar: no lgkmcnt wait in the dependent stress -> stepu -> stress chain.  The lane
+// without a source (63 / 0) keeps its own value, as __shfl_down / __shfl_up do.  Call in wave-uniform control flow.
+__device__ __forceinline__ double shfl_dn1(double x) {        // lane i <- lane i+1
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_up1(double x) {        // lane i <- lane i-1
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 
 // pair-plane access with a wave-uniform row base (SGPR) and a 32-bit lane offset (VGPR):
 // rb = byte address of (row j, pair plane 0, column 0); pp = pitch in bytes of one pair plane.
@@ -1075,7 +1088,7 @@ __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
 
 // CM (compact metrics): slots 2,3 hold (HTN,HTE) at columns c and c-1 instead of the four metric pairs in slots 2..5
 template <bool REVP, bool LAST2, bool CM>
-__global__ __launch_bounds__(256) void k_subcycle2p(SubArgs a) {
+__global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two workgroups per CU: at most 256 VGPRs
     __shared__ double2 smem[4 * PF_SLOTS * 64];
     const Slab &s = a.s;
     const int lane = threadIdx.x & 63;
