@@ -234,14 +234,47 @@ extern "C" int evpk_get_unique_id(void *id) {
 
 extern "C" const char *evpk_last_error(const evpk_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// ---- page-locked host arrays -------------------------------------------------------------
+// A host array registered with evpk_pin_host is read / written IN PLACE by the gather / scatter kernels over PCIe
+// (zero copy): no staging copy, and a download touches only the cells it delivers, so the round trip that keeps the
+// caller's other cells is not needed.  Unregistered arrays take the staged path below.
+extern "C" int evpk_pin_host(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return 1;
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+    return 0;
+}
+
+extern "C" int evpk_unpin_host(void *ptr) {
+    if (!ptr) return 1;
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+    return 0;
+}
+
+// device-visible alias of a registered host array, or nullptr
+static void *mapped_alias(const void *host) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void *>(host), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return dp;
+}
+
 // ---- host<->device transfer of one field -------------------------------------------------
+// (asynchronous on c->stream; evpk_upload / evpk_download synchronise once at their end)
 static int upload_f(evpk_ctx *c, const double *host, int f) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const double *src = (const double *)mapped_alias(host);
+    if (!src) {
+        HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        src = c->stage;
+    }
     if (!c->full_cover) hipLaunchKernelGGL(k_fill_plane, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, f, 0.0);
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    hipLaunchKernelGGL(k_gather_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, (const double *)c->stage, f);
+    hipLaunchKernelGGL(k_gather_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, f);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -249,32 +282,46 @@ static int upload_f(evpk_ctx *c, const double *host, int f) {
 static int upload_m(evpk_ctx *c, const int32_t *host, int32_t *dev_plane) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const int32_t *src = (const int32_t *)mapped_alias(host);
+    if (!src) {
+        HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        src = (const int32_t *)c->stage;
+    }
     if (!c->full_cover) HIPCHK(c, hipMemsetAsync(dev_plane, 0, mask_elems(c->s) * sizeof(int32_t), c->stream));
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    hipLaunchKernelGGL(k_gather_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, (const int32_t *)c->stage, dev_plane);
+    hipLaunchKernelGGL(k_gather_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, dev_plane);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
-// downloads start from the caller's bytes so that cells the reference leaves untouched keep their values
+// staged downloads start from the caller's bytes so that cells the reference leaves untouched keep their values
 static int download_f(evpk_ctx *c, double *host, int f, int mode) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    if (double *dst = (double *)mapped_alias(host)) {
+        hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, dst, mode);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, c->stage, mode);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging buffer is reused by the next field
     return 0;
 }
 
 static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int mode) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    if (int32_t *dst = (int32_t *)mapped_alias(host)) {
+        hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, dst, mode);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, (int32_t *)c->stage, mode);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1200,6 +1247,7 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
         if (download_f(c, tmp.data(), F_ICETM, MODE_ALL)) return 1;
         for (size_t k = 0; k < tmp.size(); k++) st->icetmask[k] = (int32_t)tmp[k];
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // scatter kernels into page-locked host arrays
     return 0;
 }
 
@@ -1218,8 +1266,9 @@ extern "C" int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2) {
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_principal_stress, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, c->cur ? (int)F_STATE1 : (int)F_STATE0);
     HIPCHK(c, hipGetLastError());
-    if (download_f(c, sig1, F_SIG1, MODE_PHYS)) return 1;
-    return download_f(c, sig2, F_SIG2, MODE_PHYS);
+    if (download_f(c, sig1, F_SIG1, MODE_PHYS) || download_f(c, sig2, F_SIG2, MODE_PHYS)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {

@@ -66,13 +66,18 @@ class EvpDynamics:
 
     def __init__(self, decomp: Decomp, fields: Dict[str, np.ndarray], *, ndte: int = 120, revised_evp: bool = False,
                  device: int = 0, unique_id: Optional[bytes] = None, cosw: float = C.cosw, sinw: float = C.sinw,
-                 tilt_from_slope: bool = False, wind_on_ugrid: bool = False, xmin: Optional[float] = None):
+                 tilt_from_slope: bool = False, wind_on_ugrid: bool = False, xmin: Optional[float] = None,
+                 pin_host: bool = False):
+        """pin_host: page-lock the arrays of `fields` (evpk_pin_host) as a host model does once for its module arrays;
+        evp() then moves them in place over PCIe.  The arrays must stay the same objects until close()."""
         self.decomp, self.fields = decomp, fields
         self.ndte, self.revised_evp = ndte, revised_evp
         self._opts = dict(cosw=cosw, sinw=sinw, tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
         self._xmin = xmin
         self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id)
         self.params: Optional[evpk.Params] = None
+        self._pinned = [a for a in fields.values() if isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
+                        and evpk.pin_host(a)] if pin_host else []
 
     def set_evp_parameters(self, dt: float):
         xmin = self._xmin if self._xmin is not None else local_min_dx(self.fields, self.decomp)
@@ -103,3 +108,6 @@ class EvpDynamics:
 
     def close(self):
         self.ctx.close()
+        for a in self._pinned:
+            evpk.unpin_host(a)
+        self._pinned = []

@@ -73,7 +73,8 @@ class Stats(ct.Structure):
 
 EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",
            "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
-           "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress"]
+           "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
+           "evpk_unpin_host"]
 
 _lib = None
 
@@ -108,11 +109,23 @@ def lib():
         L.evpk_last_error.argtypes = [ctxp]
         L.evpk_last_error.restype = ct.c_char_p
         L.evpk_slab_layout.argtypes = [ct.c_int32] * 6 + [c_i32p]
+        L.evpk_pin_host.argtypes = [ct.c_void_p, ct.c_size_t]
+        L.evpk_unpin_host.argtypes = [ct.c_void_p]
         for n in EXPORTS:
             if n != "evpk_last_error":
                 getattr(L, n).restype = ct.c_int
         _lib = L
     return _lib
+
+
+def pin_host(a: np.ndarray) -> bool:
+    """Page-lock a host array for in-place transfers (evpk_pin_host); False if the runtime refuses."""
+    assert a.flags["C_CONTIGUOUS"]
+    return lib().evpk_pin_host(ct.c_void_p(a.ctypes.data), a.nbytes) == 0
+
+
+def unpin_host(a: np.ndarray) -> bool:
+    return lib().evpk_unpin_host(ct.c_void_p(a.ctypes.data)) == 0
 
 
 def _p64(a: Optional[np.ndarray]):

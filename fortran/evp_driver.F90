@@ -18,7 +18,7 @@
       use ice_flux
       use ice_atmo
       use ice_dyn_shared
-      use ice_dyn_evp, only: evp
+      use ice_dyn_evp, only: evp, evpk_npinned
 #ifdef AusCOM
       use cpl_arrays_setup, only: sicemass
 #endif
@@ -104,6 +104,7 @@
       where (iceumask) itmp = 1
       write (11) itmp
       close (11)
+      write (*,'(a,i0)') 'evp_driver: page-locked host arrays = ', evpk_npinned
       write (*,'(a,i0,a,i0,a,es12.5)') 'evp_driver: ', ncalls, ' call(s) of evp(dt) on ', nb, ' block(s); max |uvel| = ', maxval(abs(uvel))
 
       contains

@@ -78,7 +78,7 @@
 
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &
                 evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string, &
-                evpk_principal_stress
+                evpk_principal_stress, evpk_pin_host, evpk_unpin_host
 
       interface
          integer (c_int) function evpk_get_unique_id (id) bind(C, name='evpk_get_unique_id')
@@ -110,6 +110,16 @@
          integer (c_int) function evpk_principal_stress (ctx, sig1, sig2) bind(C, name='evpk_principal_stress')
             import :: c_int, c_ptr
             type (c_ptr), value :: ctx, sig1, sig2
+         end function
+         ! page-lock a host array kept for the life of the run: moved in place over PCIe instead of staged
+         integer (c_int) function evpk_pin_host (ptr, bytes) bind(C, name='evpk_pin_host')
+            import :: c_int, c_ptr, c_size_t
+            type (c_ptr), value :: ptr
+            integer (c_size_t), value :: bytes
+         end function
+         integer (c_int) function evpk_unpin_host (ptr) bind(C, name='evpk_unpin_host')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ptr
          end function
          integer (c_int) function evpk_destroy (ctx) bind(C, name='evpk_destroy')
             import :: c_int, c_ptr

@@ -36,7 +36,10 @@
       implicit none
       private
       public :: evp
+      public :: evpk_npinned      ! (diagnostic) host arrays page-locked for in-place PCIe transfers
       save
+
+      integer (kind=int_kind) :: evpk_npinned = 0
 
       type (c_ptr) :: ctx = c_null_ptr          ! libevpk context (one per MPI rank = one GPU)
       logical (kind=log_kind) :: ctx_ready = .false.
@@ -47,6 +50,14 @@
 
       integer (c_int32_t), dimension(:), allocatable, target :: &
          g_ilo, g_ihi, g_jlo, g_jhi, g_iglob, g_jglob
+
+      ! outputs of the library that the reference keeps as locals of evp (allocated once: page-locked below)
+      real (kind=dbl_kind), dimension (:,:,:), allocatable, target :: &
+         tmass, aiu, umass
+      integer (kind=int_kind), dimension (:,:,:), allocatable, target :: &
+         icetmask
+
+      logical (kind=log_kind) :: pinned = .false.
 
       character (kind=c_char), dimension(EVPK_UNIQUE_ID_BYTES), target :: uid
 
@@ -138,6 +149,17 @@
 
 !=======================================================================
 
+      subroutine pin_r8 (a)
+      real (kind=dbl_kind), dimension (:,:,:), intent(in), target, contiguous :: a
+      integer (c_int) :: rc
+      if (size(a) > 0) then
+         rc = evpk_pin_host (c_loc(a), int(size(a), c_size_t) * 8_c_size_t)
+         if (rc == 0) evpk_npinned = evpk_npinned + 1
+      endif
+      end subroutine pin_r8
+
+!=======================================================================
+
       integer (c_int32_t) function bnd_code (name)
       use ice_exit, only: abort_ice
       character (*), intent(in) :: name
@@ -192,12 +214,6 @@
       integer (kind=int_kind), dimension (nx_block*ny_block) :: &
          indxti, indxtj     ! compressed T-cell index list for ice_strength
 
-      real (kind=dbl_kind), dimension (:,:,:), allocatable, target :: &
-         tmass, aiu, umass  ! outputs of the library the reference keeps as locals
-
-      integer (kind=int_kind), dimension (:,:,:), allocatable, target :: &
-         icetmask
-
       type (block) :: this_block
       type (evpk_params)  :: p
       type (evpk_step_in) :: sin
@@ -207,8 +223,9 @@
 
       if (.not. ctx_ready) call evpk_setup
 
-      allocate (tmass(nx_block,ny_block,max_blocks), aiu(nx_block,ny_block,max_blocks), &
-                umass(nx_block,ny_block,max_blocks), icetmask(nx_block,ny_block,max_blocks))
+      if (.not. allocated(tmass)) &
+         allocate (tmass(nx_block,ny_block,max_blocks), aiu(nx_block,ny_block,max_blocks), &
+                   umass(nx_block,ny_block,max_blocks), icetmask(nx_block,ny_block,max_blocks))
 
       !-----------------------------------------------------------------
       ! scalars of set_evp_parameters (ice_dyn_shared.F90:185-259), read
@@ -319,6 +336,27 @@
       st%uvel_init = c_loc(uvel_init);  st%vvel_init = c_loc(vvel_init)
       st%icetmask = c_null_ptr
 
+      if (.not. pinned) then
+         ! The arrays handed over live as long as the run: page-lock them once, so that the library moves them in
+         ! place over PCIe instead of through staging copies (a refusal leaves the staged path in use).
+         call pin_r8 (aice);  call pin_r8 (vice);  call pin_r8 (vsno);  call pin_r8 (aice_init)
+         call pin_r8 (strairxT);  call pin_r8 (strairyT);  call pin_r8 (strax);  call pin_r8 (stray)
+         call pin_r8 (uocn);  call pin_r8 (vocn);  call pin_r8 (ss_tltx);  call pin_r8 (ss_tlty)
+         call pin_r8 (Cdn_ocn);  call pin_r8 (strength)
+         call pin_r8 (uvel);  call pin_r8 (vvel)
+         call pin_r8 (stressp_1);  call pin_r8 (stressp_2);  call pin_r8 (stressp_3);  call pin_r8 (stressp_4)
+         call pin_r8 (stressm_1);  call pin_r8 (stressm_2);  call pin_r8 (stressm_3);  call pin_r8 (stressm_4)
+         call pin_r8 (stress12_1); call pin_r8 (stress12_2); call pin_r8 (stress12_3); call pin_r8 (stress12_4)
+         call pin_r8 (divu);  call pin_r8 (shear);  call pin_r8 (rdg_conv);  call pin_r8 (rdg_shear)
+         call pin_r8 (prs_sig);  call pin_r8 (strintx);  call pin_r8 (strinty)
+         call pin_r8 (strocnx);  call pin_r8 (strocny);  call pin_r8 (strocnxT);  call pin_r8 (strocnyT)
+         call pin_r8 (strairx);  call pin_r8 (strairy);  call pin_r8 (strtltx);  call pin_r8 (strtlty)
+         call pin_r8 (fm);  call pin_r8 (tmass);  call pin_r8 (aiu);  call pin_r8 (umass)
+         call pin_r8 (uvel_init);  call pin_r8 (vvel_init)
+         rc = evpk_pin_host (c_loc(iceumask_i), int(size(iceumask_i), c_size_t) * 4_c_size_t)
+         pinned = .true.
+      endif
+
       rc = evpk_run (ctx, sin, st)
       if (rc /= 0) call abort_ice('evp: evpk_run: '//trim(evpk_error_string(ctx)))
 
@@ -328,7 +366,6 @@
       sicemass(:,:,:) = tmass(:,:,:)          ! ice_dyn_evp.F90:205-207
 #endif
 
-      deallocate (tmass, aiu, umass, icetmask)
 
       call ice_timer_stop(timer_dynamics)    ! dynamics
 

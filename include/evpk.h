@@ -162,6 +162,14 @@ int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
  * byte count in the PMC trace to calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
 int evpk_calibrate(evpk_ctx *c, int32_t nrep);
 int evpk_destroy(evpk_ctx *c);
+
+/* Optional: page-lock a host array the caller keeps for the life of the run (CICE's module arrays of ice_state /
+ * ice_flux / ice_grid, ice_state.F90 / ice_flux.F90) and map it into the device address space.  evpk_upload /
+ * evpk_download / evpk_run then read and write such arrays in place over PCIe instead of staging them, and a download
+ * touches only the cells it delivers.  Arrays that were not registered keep working (staged copies).  Unpin before the
+ * memory is freed.  Returns 0 on success. */
+int evpk_pin_host(void *ptr, size_t bytes);
+int evpk_unpin_host(void *ptr);
 const char *evpk_last_error(const evpk_ctx *c);  /* c may be NULL: error of the last failed evpk_create */
 
 /* Host-only description of this rank's halo exchange (no GPU needed): neighbours in the

@@ -82,6 +82,9 @@ def test_fortran_host_matches_oracle(tmp_path, ns, bs, ncalls, driver):
     r = subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "evp_driver:" in r.stdout
+    print(r.stdout)
+    npin = int(r.stdout.split("page-locked host arrays = ")[1].split()[0])
+    assert npin > 0          # the module arrays are moved in place over PCIe (some may share a page and stay staged)
     if driver.endswith("_auscom"):
         assert "sicemass max" in r.stdout
     got = read_output(tmp_path / "out.bin", d)

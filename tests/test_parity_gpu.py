@@ -15,14 +15,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _both(nx, ny, bsx, bsy, *, ndte=120, dt=3600.0, ncalls=1, revised_evp=False, cosw=1.0, sinw=0.0,
-          tilt_from_slope=False, wind_on_ugrid=False, ns="open", nsub=None, **kw):
+          tilt_from_slope=False, wind_on_ugrid=False, ns="open", nsub=None, pin_host=False, **kw):
     case, d, f = util.make_case(nx, ny, bsx, bsy, ns=ns, **kw)
     xmin = synth.global_min_dx(case)
     fo, fg = util.clone(f), util.clone(f)
     p = orc.make_params(dt, ndte, xmin, revised_evp=revised_evp, cosw=cosw, sinw=sinw,
                         tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
     solver = dyn.EvpDynamics(d, fg, ndte=ndte, revised_evp=revised_evp, xmin=xmin, cosw=cosw, sinw=sinw,
-                             tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
+                             tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid, pin_host=pin_host)
+    assert not pin_host or len(solver._pinned) > 40
     solver.init_evp(dt)
     # host mirror of set_evp_parameters must agree with the oracle's to the bit
     for n in ("revp", "ecci", "denom1", "arlx1i", "brlx"):
@@ -137,6 +138,14 @@ def test_strip_rows_do_not_matter():
     del os.environ["EVPK_STRIP_ROWS"]
     for g in out[1:]:
         assert not util.compare(d, g, out[0])
+
+
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_page_locked_host_arrays(ns):
+    """evpk_pin_host: the gather / scatter kernels read and write the caller's arrays in place over PCIe; a download
+    must leave every cell it does not deliver untouched (the oracle comparison covers ghost cells too)."""
+    _both(100, 116, 25, 29, ns=ns, land="continents", ndte=30, ncalls=2, pin_host=True)
+    _both(130, 60, 130, 60, ns=ns, ice="full", ndte=12, pin_host=True)
 
 
 @pytest.mark.parametrize("m", [1, 2, 4])
