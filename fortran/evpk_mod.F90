@@ -78,7 +78,8 @@
 
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &
                 evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string, &
-                evpk_principal_stress, evpk_pin_host, evpk_unpin_host
+                evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
+                evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download
 
       interface
          integer (c_int) function evpk_get_unique_id (id) bind(C, name='evpk_get_unique_id')
@@ -99,6 +100,32 @@
             import :: c_int, c_ptr, evpk_step_in, evpk_state
             type (c_ptr), value :: ctx
             type (evpk_step_in), intent(in) :: sin
+            type (evpk_state), intent(in) :: st
+         end function
+         ! evpk_run in stages.  st = c_null_ptr in evpk_upload: inputs only, the prognostic state (uvel, vvel, the
+         ! twelve stresses, iceumask) stays as the previous call left it on the device
+         integer (c_int) function evpk_upload (ctx, sin, st) bind(C, name='evpk_upload')
+            import :: c_int, c_ptr, evpk_step_in
+            type (c_ptr), value :: ctx
+            type (evpk_step_in), intent(in) :: sin
+            type (c_ptr), value :: st                      ! c_loc of an evpk_state, or c_null_ptr
+         end function
+         integer (c_int) function evpk_prep (ctx) bind(C, name='evpk_prep')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ctx
+         end function
+         integer (c_int) function evpk_subcycle (ctx, nsub) bind(C, name='evpk_subcycle')
+            import :: c_int, c_ptr, c_int32_t
+            type (c_ptr), value :: ctx
+            integer (c_int32_t), value :: nsub
+         end function
+         integer (c_int) function evpk_finish (ctx) bind(C, name='evpk_finish')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ctx
+         end function
+         integer (c_int) function evpk_download (ctx, st) bind(C, name='evpk_download')
+            import :: c_int, c_ptr, evpk_state
+            type (c_ptr), value :: ctx
             type (evpk_state), intent(in) :: st
          end function
          integer (c_int) function evpk_get_stats (ctx, s) bind(C, name='evpk_get_stats')

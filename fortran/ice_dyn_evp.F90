@@ -37,9 +37,17 @@
       private
       public :: evp
       public :: evpk_npinned      ! (diagnostic) host arrays page-locked for in-place PCIe transfers
+      public :: evpk_resident_state, evpk_state_changed_on_host
       save
 
       integer (kind=int_kind) :: evpk_npinned = 0
+
+      ! uvel, vvel, the twelve stresses and iceumask are written by evp only (ice_dyn_evp.F90:336-410; readers:
+      ! transport, history, restart), so after the first call the copy on the device is current and only the inputs
+      ! are uploaded.  Whoever writes them elsewhere (a restart read after the first step, ...) sets
+      ! evpk_state_changed_on_host = .true.; evpk_resident_state = .false. uploads them every call.
+      logical (kind=log_kind) :: evpk_resident_state = .true.
+      logical (kind=log_kind) :: evpk_state_changed_on_host = .true.
 
       type (c_ptr) :: ctx = c_null_ptr          ! libevpk context (one per MPI rank = one GPU)
       logical (kind=log_kind) :: ctx_ready = .false.
@@ -357,8 +365,17 @@
          pinned = .true.
       endif
 
-      rc = evpk_run (ctx, sin, st)
+      if (evpk_resident_state .and. .not. evpk_state_changed_on_host) then
+         rc = evpk_upload (ctx, sin, c_null_ptr)
+         if (rc == 0) rc = evpk_prep (ctx)
+         if (rc == 0) rc = evpk_subcycle (ctx, int(ndte, c_int32_t))
+         if (rc == 0) rc = evpk_finish (ctx)
+         if (rc == 0) rc = evpk_download (ctx, st)
+      else
+         rc = evpk_run (ctx, sin, st)
+      endif
       if (rc /= 0) call abort_ice('evp: evpk_run: '//trim(evpk_error_string(ctx)))
+      evpk_state_changed_on_host = .false.
 
       iceumask = (iceumask_i == 1)
 
