@@ -570,8 +570,13 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     s.pitch = ((C0 + s.nxl + ZW_MAX + 1 + 7) / 8) * 8;     // columns 1-ZW_MAX .. nxl+ZW_MAX (ghost zones of up to ZW_MAX columns per side)
     s.rstride = NP * s.pitch;
 
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {   // `stream` carries the edge strips and the neighbour exchange (pack, RCCL, unpack): dispatched ahead of the
+        // interior strips on `stream2`, which only have to be done by the next launch
+        int least = 0, greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
+    }
     HIPCHK(c, hipEventCreateWithFlags(&c->evI, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->evE, hipEventDisableTiming));

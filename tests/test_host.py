@@ -116,3 +116,44 @@ def test_host_set_evp_parameters_equals_oracle():
         b = orc.make_params(1800.0, 120, 12345.0, revised_evp=rev)
         for n in ("revp", "ecci", "denom1", "arlx1i", "brlx"):
             assert getattr(a, n) == getattr(b, n)
+
+
+@pytest.mark.parametrize("ew", ["cyclic", "open"])
+def test_restart_records_of_the_dynamics(tmp_path, ew):
+    """ice_restart_driver.F90:118-176 / :290-412: record order (stresses 1,3,2,4), Fortran sequential framing,
+    big-endian real*8 of the gathered global array, iceumask as real 0/1 read back with > 0.5."""
+    import io
+    import struct
+    from cice5_amd import restart
+    from tests import util
+    nx, ny = 24, 20
+    case = synth.SynthCase(nx=nx, ny=ny, ew_boundary=ew, land="continents")
+    d1 = blocks.create_distrb_cart(nx, ny, 24, 20, ew_boundary_type=ew)
+    f1 = synth.make_block_fields(case, d1)
+    rng = np.random.default_rng(5)
+    for name in restart.DYNAMICS_RECORDS[:-1]:
+        f1[name] = rng.standard_normal(f1["uvel"].shape)
+    f1["iceumask"] = (rng.random(f1["uvel"].shape) > 0.5).astype(np.int32)
+    buf = io.BytesIO()
+    restart.write_dynamics_records(buf, d1, f1)
+    raw = buf.getvalue()
+    assert len(raw) == len(restart.DYNAMICS_RECORDS) * (nx * ny * 8 + 8)
+    assert struct.unpack(">i", raw[:4])[0] == nx * ny * 8
+    # third stress record is stressp_2 (order 1,3,2,4), global (j,i) order of physical cells
+    k = restart.DYNAMICS_RECORDS.index("stressp_2")
+    assert restart.DYNAMICS_RECORDS[k - 1] == "stressp_3" and restart.DYNAMICS_RECORDS[k + 1] == "stressp_4"
+    rec = np.frombuffer(raw[k * (nx * ny * 8 + 8) + 4:][:nx * ny * 8], dtype=">f8").reshape(ny, nx)
+    assert np.array_equal(rec, blocks.gather_global(d1, f1["stressp_2"]))
+    # read back on another decomposition: physical cells identical, ghost cells as scatter_global leaves them
+    d2 = blocks.create_distrb_cart(nx, ny, 6, 5, ew_boundary_type=ew)
+    f2 = synth.make_block_fields(case, d2)
+    restart.read_dynamics_records(io.BytesIO(raw), d2, f2)
+    for name in restart.DYNAMICS_RECORDS:
+        assert np.array_equal(blocks.gather_global(d2, f2[name]), blocks.gather_global(d1, f1[name])), name
+    G = blocks.gather_global(d1, f1["uvel"])
+    b = d2.local_blocks[0]                           # south-west block: west ghost column wraps or is zero
+    west = f2["uvel"][0, b.jlo - 1:b.jhi, 0]
+    assert np.array_equal(west, G[:b.jhi - b.jlo + 1, -1] if ew == "cyclic" else np.zeros_like(west))
+    assert not f2["uvel"][0, 0, :].any()             # south ghost row (open)
+    with pytest.raises(ValueError):
+        restart.read_dynamics_records(io.BytesIO(raw), blocks.create_distrb_cart(nx + 2, ny, 26, 20), f2)

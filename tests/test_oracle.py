@@ -113,6 +113,40 @@ def test_stress_linear_velocity_field():
     assert np.abs(fx).max() <= 1e-12 * scale and np.abs(fy).max() <= 1e-12 * scale
 
 
+def test_stress_relaxes_to_the_viscous_plastic_law():
+    """Independent anchor on the published equations (Hunke & Dukowicz 1997; cicedoc 'Internal stress'): with the
+    velocity held fixed, the EVP stress update (ice_dyn_evp.F90:683-721) is a contraction by denom1 = 1/(1+arlx1i) per
+    subcycle whose fixed point is the viscous-plastic law of the elliptical yield curve, e = 2:
+        sigma_1 = P (D_D/Delta - 1),  sigma_2 = P D_T / (e^2 Delta),  sigma_12 = P D_S / (2 e^2 Delta),
+        Delta = sqrt(D_D^2 + (D_T^2 + D_S^2)/e^2)."""
+    nx, ny, L = 10, 9, 4096.0
+    a = _uniform_block(nx, ny, L)
+    ca, cb, cc, cd = 3.0e-7, -1.0e-7, 2.0e-7, 0.5e-7          # u = ca x + cc y, v = cd x + cb y   [1/s]
+    I, J = np.meshgrid(np.arange(1, nx + 1), np.arange(1, ny + 1))
+    a["uvel"][...] = (ca * I + cc * J) * L
+    a["vvel"][...] = (cd * I + cb * J) * L
+    P = 2.5e4
+    a["strength"][...] = P
+    idx = [(i, j) for j in range(2, ny) for i in range(2, nx)]
+    ti = np.array([i for i, _ in idx], dtype=np.int32)
+    tj = np.array([j for _, j in idx], dtype=np.int32)
+    p = orc.make_params(3600.0, 120, 1.0)
+    nit = 3200
+    assert (1.0 / (1.0 + p.arlx1i)) ** nit < 1e-15
+    for _ in range(nit):
+        orc.stress_block(nx, ny, 1, 120, ti, tj, a, p)
+    DD, DT, DS, e2 = ca + cb, ca - cb, cc + cd, 4.0
+    delta = np.sqrt(DD ** 2 + (DT ** 2 + DS ** 2) / e2)
+    inner = (slice(1, ny - 1), slice(1, nx - 1))
+    for k in (1, 2, 3, 4):
+        assert np.allclose(a[f"stressp_{k}"][inner], P * (DD / delta - 1.0), rtol=1e-11, atol=0)
+        assert np.allclose(a[f"stressm_{k}"][inner], P * DT / (e2 * delta), rtol=1e-11, atol=0)
+        assert np.allclose(a[f"stress12_{k}"][inner], P * DS / (2.0 * e2 * delta), rtol=1e-11, atol=0)
+    # the state lies on the yield curve: (sigma_1/P + 1)^2 + e^2 (sigma_2^2 + 4 sigma_12^2)/P^2 = 1
+    s1, s2, s12 = a["stressp_1"][inner] / P, a["stressm_1"][inner] / P, a["stress12_1"][inner] / P
+    assert np.allclose((s1 + 1.0) ** 2 + e2 * (s2 ** 2 + 4.0 * s12 ** 2), 1.0, rtol=1e-11)
+
+
 def test_stress_rigid_translation_has_no_strain():
     nx, ny, L = 8, 8, 2048.0
     a = _uniform_block(nx, ny, L)
