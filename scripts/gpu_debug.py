@@ -1,4 +1,4 @@
-"""Ad-hoc GPU check (not a pytest file): python tests/gpu_debug.py"""
+"""Ad-hoc GPU check (not a pytest file): python scripts/gpu_debug.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
