@@ -388,6 +388,14 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     const bool stress_mode = fsrc_fold >= 0;
     if (nf > c->max_nf) FAIL(c, "halo: nf=%d exceeds buffer", nf);
     if (c->ns == EVPK_BND_CYCLIC) FAIL(c, "ns_boundary_type cyclic is not supported");
+    if (c->ns == EVPK_BND_TRIPOLE && c->nranks == 1 && !c->force_exchange && necorner && !stress_mode && s.nyl >= 3) {
+        // single rank: the whole update of an NE-corner field in one launch
+        const int n = std::max(std::max(s.nxg / 2 + 1, s.nxl + 2), s.nyl);
+        hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, c->stream, s, f, nf,
+                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     // N-S
     if (c->ns == EVPK_BND_TRIPOLE) {
         if (!stress_mode) hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 0);

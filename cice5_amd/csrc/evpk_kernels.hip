@@ -398,6 +398,52 @@ __global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int nec
     }
 }
 
+// Whole halo update of an NE-corner vector field on a single-rank tripole grid in ONE launch (the subcycle loop calls
+// it twice per launch pair): south ghost row, the u-fold of k_fold_apply straight from the planes, and the E-W ghost
+// columns.  The symmetrised top row of column g depends on the old values at g and nx-g only, so one thread owns that
+// pair and no staging buffer is needed; every other value read lies in a cell this kernel does not write.
+//   blockIdx.y == 0: fold (thread k: columns k and nx-k; k = 0 stands for column nx), rows nyl and nyl+1
+//   blockIdx.y == 1: rows 0 .. nyl-1: south fill and the two ghost columns
+__global__ void k_halo_tripole_ne1(Slab s, int f, int nf, int cyclic, double fill, double sgn) {
+    const int nx = s.nxg, h = nx / 2, nyl = s.nyl;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 1) {
+        if (t <= s.nxl + 1)
+            for (int q = 0; q < nf; q++) FD(s, f + q, cell(s, t, 0)) = fill;
+        if (t >= 1 && t <= nyl - 1)
+            for (int q = 0; q < nf; q++) {
+                FD(s, f + q, cell(s, 0, t)) = cyclic ? FD(s, f + q, cell(s, s.nxl, t)) : fill;
+                FD(s, f + q, cell(s, s.nxl + 1, t)) = cyclic ? FD(s, f + q, cell(s, 1, t)) : fill;
+            }
+        return;
+    }
+    if (t > h) return;
+    // new values of column g: top row = sgn * v(src), ghost row = sgn * (row nyl-1)(src), src = nx - g (0 -> nx)
+    auto put = [&](int q, int g, double top, double ghost) {
+        FD(s, f + q, cell(s, g, nyl)) = top;
+        FD(s, f + q, cell(s, g, nyl + 1)) = ghost;
+        // E-W ghost columns of the two rows (k_halo_ew_local ran after the fold): copies of columns nx and 1
+        if (g == nx) { FD(s, f + q, cell(s, 0, nyl)) = cyclic ? top : fill; FD(s, f + q, cell(s, 0, nyl + 1)) = cyclic ? ghost : fill; }
+        if (g == 1) { FD(s, f + q, cell(s, nx + 1, nyl)) = cyclic ? top : fill; FD(s, f + q, cell(s, nx + 1, nyl + 1)) = cyclic ? ghost : fill; }
+    };
+    for (int q = 0; q < nf; q++) {
+        if (t == 0 || t == h) {
+            const int g = t == 0 ? nx : h;                  // src == g: the value itself
+            const double T = FD(s, f + q, cell(s, g, nyl)), R = FD(s, f + q, cell(s, g, nyl - 1));
+            put(q, g, sgn * T, sgn * R);
+        } else {
+            const int ga = t, gb = nx - t;                   // ga in 1..h-1, gb in h+1..nx-1
+            const double Ta = FD(s, f + q, cell(s, ga, nyl)), Tb = FD(s, f + q, cell(s, gb, nyl));
+            const double Ra = FD(s, f + q, cell(s, ga, nyl - 1)), Rb = FD(s, f + q, cell(s, gb, nyl - 1));
+            // column ga: src = gb >= h+1:  v = sgn*(0.5*(B2[nx-src] + sgn*B2[src]));  column gb: src = ga:  v = 0.5*(B2[src] + sgn*B2[nx-src])
+            const double va = sgn * (0.5 * (Ta + sgn * Tb));
+            const double vb = 0.5 * (Ta + sgn * Tb);
+            put(q, ga, sgn * va, sgn * Rb);
+            put(q, gb, sgn * vb, sgn * Ra);
+        }
+    }
+}
+
 __global__ void k_halo_ew_local(Slab s, int f, int nf, int cyclic, double fill) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > s.nyl + 1) return;
