@@ -170,9 +170,10 @@ def main():
     alg_bytes_sub = (ALG_BYTES_STRESS * icellt + ALG_BYTES_STEPU * icellu) / world   # per GPU per subcycle
     # dominant kernel: the two-subcycle kernel when it ran (one launch = two subcycles of algorithmic work)
     if k2_n > 0:
-        kname, nsub_per_launch, kern_ms, launches = "k_subcycle2 (stress+stepu, two subcycles per launch)", 2, k2_ms / k2_n, k2_n
+        k2 = "evpk::k_subcycle2" if os.environ.get("EVPK_PREFETCH") == "0" else "evpk::k_subcycle2p"    # name in the rocprofv3 trace
+        kname, nsub_per_launch, kern_ms, launches = k2 + " (stress+stepu fused, two subcycles per launch)", 2, k2_ms / k2_n, k2_n
     else:
-        kname, nsub_per_launch, kern_ms, launches = "k_subcycle (fused stress+stepu)", 1, k1_ms / max(k1_n, 1), k1_n
+        kname, nsub_per_launch, kern_ms, launches = "evpk::k_subcycle (stress+stepu fused)", 1, k1_ms / max(k1_n, 1), k1_n
     alg_bytes_launch = nsub_per_launch * alg_bytes_sub
     achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
