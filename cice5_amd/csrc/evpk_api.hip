@@ -131,6 +131,7 @@ struct evpk_ctx {
     int zone_exchanges = 0;     // in the last evpk_subcycle call
     long long zone_bytes = 0;
     hipEvent_t evE = nullptr;   // after the most recent kernel launch on `stream`
+    hipEvent_t evB0 = nullptr, evB1 = nullptr;   // tripole, single rank: band 1 + its fold on stream2 beside the main launch
     int nxb = 0, nyb = 0, nblocks = 0;
     std::vector<BlockDesc> bd;
     BlockDesc *d_bd = nullptr;
@@ -381,7 +382,7 @@ static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes) {
 // ---- halo update of nf consecutive planes starting at f ---------------------------------
 // fsrc_fold >= 0: ice_HaloUpdate_stress variant (only the tripole north ghost row of the
 // destination planes is written, from the top physical row of the source planes).
-static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1) {
+static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t one_launch_stream = nullptr) {
     Slab &s = c->s;
     const int tx = 128;
     const int gcol = (s.nxl + 2 + tx - 1) / tx, grow = (s.nyl + 2 + tx - 1) / tx;
@@ -391,8 +392,8 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     if (c->ns == EVPK_BND_TRIPOLE && c->nranks == 1 && !c->force_exchange && necorner && !stress_mode && s.nyl >= 3) {
         // single rank: the whole update of an NE-corner field in one launch
         const int n = std::max(std::max(s.nxg / 2 + 1, s.nxl + 2), s.nyl);
-        hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, c->stream, s, f, nf,
-                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0);
+        hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, one_launch_stream ? one_launch_stream : c->stream,
+                           s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0);
         HIPCHK(c, hipGetLastError());
         return 0;
     }
@@ -526,6 +527,8 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->evI) (void)hipEventDestroy(c->evI);
     if (c->evX) (void)hipEventDestroy(c->evX);
     if (c->evE) (void)hipEventDestroy(c->evE);
+    if (c->evB0) (void)hipEventDestroy(c->evB0);
+    if (c->evB1) (void)hipEventDestroy(c->evB1);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (auto e : c->kev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -583,8 +586,11 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         int least = 0, greatest = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
-        HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
+        // (single rank: stream2 carries the first tripole band launch beside the main launch -- few, short, urgent)
+        HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, g->nranks > 1 ? least : greatest));
     }
+    HIPCHK(c, hipEventCreateWithFlags(&c->evB0, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->evB1, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->evI, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->evE, hipEventDisableTiming));
@@ -1084,6 +1090,30 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         if (pair_inside || pair_ends_evp) {
             a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
+            // tripole: rows next to the fold are redone one subcycle at a time with the fold in between
+            //   band 1: T rows nyl-2..nyl+1, U rows nyl-2..nyl   state `sr` -> scratch;  fold(scratch)
+            //   band 2: T rows nyl-1..nyl+1, U rows nyl-1..nyl   scratch -> state `sw`;  fold(sw)
+            // Band 1 reads the state this launch reads, so on a single rank it runs beside the main launch on stream2.
+            SubArgs b1 = a, b2 = a;
+            const bool band_ahead = c->band_mode && !c->zone_mode;
+            auto launch_band = [&](const SubArgs &bb, hipStream_t st) {
+                const dim3 g((((c->ncx + 3) / 4 + 7) / 8) * 8), b(256);
+                if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, st, bb);
+                else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, st, bb);
+            };
+            if (c->band_mode) {
+                b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0; b1.G = 0;
+                b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
+                b2 = b1;
+                b2.R = 3; b2.jb0 = s.nyl - 1; b2.sr = F_STATE2; b2.sw = a.sw;
+                if (band_ahead) {
+                    HIPCHK(c, hipEventRecord(c->evB0, c->stream));          // the previous pair is complete
+                    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evB0, 0));
+                    launch_band(b1, c->stream2);
+                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, c->stream2)) return 1;
+                    HIPCHK(c, hipEventRecord(c->evB1, c->stream2));
+                }
+            }
             if (c->zone_mode && c->zone_left < 1) {         // (a one-subcycle launch or a partial call came before)
                 if (join()) FAIL(c, "hipStreamWaitEvent failed");
                 if (zone_exchange(a.sr)) return 1;
@@ -1124,20 +1154,12 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 evE_valid = true;
             }
             if (c->band_mode) {
-                // tripole: rows next to the fold again, one subcycle at a time with the fold in between
-                //   band 1: T rows nyl-2..nyl+1, U rows nyl-2..nyl   state `sr` -> scratch;  fold(scratch)
-                //   band 2: T rows nyl-1..nyl+1, U rows nyl-1..nyl   scratch -> state `sw`;  fold(sw)
-                SubArgs b1 = a;
-                b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0; b1.G = 0;
-                b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
-                SubArgs b2 = b1;
-                b2.R = 3; b2.jb0 = s.nyl - 1; b2.sr = F_STATE2; b2.sw = a.sw;
-                const dim3 g((((c->ncx + 3) / 4 + 7) / 8) * 8), b(256);
-                if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, b1);
-                else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, b1);
-                if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0)) return 1;
-                if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, b2);
-                else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, b2);
+                if (!band_ahead) {
+                    launch_band(b1, c->stream);
+                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0)) return 1;
+                } else
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
+                launch_band(b2, c->stream);
                 if (halo(c, a.sw + S_U, 2, true, true, 0.0)) return 1;
             }
             c->ksub += 2;
