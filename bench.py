@@ -219,12 +219,31 @@ def main():
             out["config"]["tripole_variant"] = tripole_variant(a, nx, ny, bsx, bsy, local_rank)
         except Exception as e:           # never lose the bench line over the extra
             out["config"]["tripole_variant"] = {"error": str(e)[:200]}
+        # informational: one whole evp(dt) through evpk_run INCLUDING the PCIe transfers of all arrays (never `value`)
+        try:
+            out["config"]["evp_incl_pcie_ms"] = evp_incl_pcie(d, f, a, xmin, local_rank)
+        except Exception as e:
+            out["config"]["evp_incl_pcie_ms"] = {"error": str(e)[:200]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if solver is not None:
         solver.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def evp_incl_pcie(d, f, a, xmin, device):
+    from cice5_amd import dyn
+    res = {}
+    for key, pin in (("pageable_host_arrays", False), ("page_locked_host_arrays", True)):
+        s = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=device, pin_host=pin)
+        s.init_evp(a.dt)
+        s.evp(a.dt)
+        t = time.perf_counter()
+        s.evp(a.dt)
+        res[key] = 1e3 * (time.perf_counter() - t)
+        s.close()
+    return res
 
 
 def tripole_variant(a, nx, ny, bsx, bsy, device):

@@ -382,7 +382,9 @@ static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes) {
 // ---- halo update of nf consecutive planes starting at f ---------------------------------
 // fsrc_fold >= 0: ice_HaloUpdate_stress variant (only the tripole north ghost row of the
 // destination planes is written, from the top physical row of the source planes).
-static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t one_launch_stream = nullptr) {
+// skip_ew: the caller refreshes the E-W ghost columns itself right after (exchange_cols carries them, all rows)
+static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t one_launch_stream = nullptr,
+                bool skip_ew = false) {
     Slab &s = c->s;
     const int tx = 128;
     const int gcol = (s.nxl + 2 + tx - 1) / tx, grow = (s.nyl + 2 + tx - 1) / tx;
@@ -430,6 +432,10 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 1);
     }
     // E-W over all rows (ghost rows included, which carries the corners)
+    if (skip_ew) {
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     if (c->nranks == 1 && !c->force_exchange) {
         hipLaunchKernelGGL(k_halo_ew_local, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill);
     } else {
@@ -923,8 +929,10 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     hipLaunchKernelGGL(k_to_ugrid4, g2, B2D, 0, c->stream, s, c->p.wind_on_ugrid ? 0 : 1);
     // evp_prep2 (:247-308); strength is an input (ice_strength, :291-301)
     hipLaunchKernelGGL(k_prep2, g2, B2D, 0, c->stream, s, c->p, fresh, c->cur);
-    if (halo(c, F_STRENGTH, 1, false, false, 0.0)) return 1;                      // :311-312
-    if (halo(c, SA + S_U, 2, true, true, 0.0)) return 1;                          // :314-315
+    // (x-slabs with ghost zones: the zone exchange below carries the E-W ghost columns of strength and of the state)
+    const bool zm = c->use_double && (c->nranks > 1 || c->force_exchange);
+    if (halo(c, F_STRENGTH, 1, false, false, 0.0, -1, nullptr, zm)) return 1;     // :311-312
+    if (halo(c, SA + S_U, 2, true, true, 0.0, -1, nullptr, zm)) return 1;         // :314-315
     {   // the top physical row may have been rewritten by a tripole fold, the ring by the halo: mirror into buffer 1
         const int nring = 2 * (s.nxl + 2) + 2 * (s.nyl + 2);
         hipLaunchKernelGGL(k_ring_copy, dim3((nring + 127) / 128), dim3(128), 0, c->stream, s, SA + S_U, SB + S_U, 2);
@@ -935,7 +943,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         hipLaunchKernelGGL(k_rows_copy, dim3((s.nxl + 2 + 127) / 128, 6), dim3(128), 0, c->stream, s, SA + S_U, (int)(F_STATE2 + S_U), 2,
                            s.nyl - 4, s.nyl + 1);
     c->fresh = false;
-    c->zone_mode = c->use_double && (c->nranks > 1 || c->force_exchange);
+    c->zone_mode = zm;
     const int G = c->zone_mode ? c->zW - 2 : 0;
     c->ncx2 = (s.nxl + 2 * G + STRIP2_W - 1) / STRIP2_W;
     c->zcompact = false;
@@ -1160,7 +1168,8 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 } else
                     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
                 launch_band(b2, c->stream);
-                if (halo(c, a.sw + S_U, 2, true, true, 0.0)) return 1;
+                // (x-slabs: the ghost-zone exchange below delivers the E-W ghost columns of the new state, all rows)
+                if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, nullptr, c->zone_mode)) return 1;
             }
             c->ksub += 2;
             n += 2;
