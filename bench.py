@@ -200,7 +200,11 @@ def main():
                    "zone_bytes_sent_rank0": int(st.zone_bytes), "step": "prep + ndte x (stress+stepu, halo) + finish"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "alg_bytes_per_launch": alg_bytes_launch,
+                     "traffic": traffic,
+                     # real HBM rate of that kernel: PMC bytes per launch (profiles/) over the launch time measured here
+                     "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
+                     "traffic_frac_of_peak": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
+                     "alg_bytes_per_launch": alg_bytes_launch,
                      "avg_launch_ms": kern_ms, "launches_timed": int(launches), "subcycles_per_launch": nsub_per_launch,
                      "loop_ms_per_step": loop_ms / a.steps,
                      "other_kernel": {"name": "k_subcycle", "launches": int(k1_n), "avg_launch_ms": k1_ms / max(k1_n, 1)}},
