@@ -127,6 +127,11 @@ struct evpk_ctx {
     unsigned char *d_zflags = nullptr;
     int *d_zrows = nullptr;     // 4 row lists (send W, send E, recv E, recv W), nyl+2 ints each
     int zn[4] = {0, 0, 0, 0};
+    // ice_strength on the device (evpk_step_in.strength == NULL)
+    bool strength_dev = false;
+    double *itd = nullptr;            // 2*ncat+1 plain planes: aicen, vicen, aice0
+    double *stage_itd = nullptr;      // staging of one (nx_block, ny_block, ncat, nblocks) host array
+    int itd_ncat = 0;
     bool zone_metrics_done = false;   // the time-invariant planes of the zones have been exchanged
     int zone_exchanges = 0;     // in the last evpk_subcycle call
     long long zone_bytes = 0;
@@ -525,7 +530,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->relay) { c->relay->close_(); delete c->relay; }
-    void *ptrs[] = {c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
+    void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
                     c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -816,6 +821,8 @@ extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
     d.rhow = p->rhow; d.rhoi = p->rhoi; d.rhos = p->rhos; d.gravit = p->gravit;
     d.a_min = p->a_min; d.m_min = p->m_min;
     d.tilt_from_slope = p->tilt_from_slope; d.wind_on_ugrid = p->wind_on_ugrid;
+    d.kstrength = p->kstrength; d.krdg_partic = p->krdg_partic; d.krdg_redist = p->krdg_redist; d.ncat = p->ncat;
+    d.mu_rdg = p->mu_rdg; d.Cf = p->Cf;
     if ((p->revised_evp != 0) != (p->revp == 1.0)) FAIL(c, "revised_evp and revp disagree");
     c->have_params = true;
     return 0;
@@ -829,7 +836,7 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
     HIPCHK(c, hipSetDevice(c->device));
     struct { const double *h; int f; bool need; } ip[] = {
         {in->aice, F_AICE, true}, {in->vice, F_VICE, true}, {in->vsno, F_VSNO, true}, {in->aice_init, F_AICE_INIT, true},
-        {in->uocn, F_UOCN, true}, {in->vocn, F_VOCN, true}, {in->Cdn_ocn, F_CW, true}, {in->strength, F_STRENGTH, true},
+        {in->uocn, F_UOCN, true}, {in->vocn, F_VOCN, true}, {in->Cdn_ocn, F_CW, true}, {in->strength, F_STRENGTH, false},
         {in->ss_tltx, F_SSTLTX, c->p.tilt_from_slope != 0}, {in->ss_tlty, F_SSTLTY, c->p.tilt_from_slope != 0},
         // wind: either T-grid stress (t2ugrid_vector) or U-grid stress (ACCESS); both land in STRAIRXT/YT
         {c->p.wind_on_ugrid ? in->strax : in->strairxT, F_STRAIRXT, true},
@@ -837,6 +844,37 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
     for (auto &e : ip) {
         if (!e.h) { if (e.need) FAIL(c, "a required input pointer is NULL"); continue; }
         if (upload_f(c, e.h, e.f)) return 1;
+    }
+    c->strength_dev = (in->strength == nullptr);
+    if (c->strength_dev && c->p.kstrength == 1) {
+        // thickness distribution for ice_strength on the device: (nx_block, ny_block, ncat, nblocks) arrays, one plane per category
+        const int ncat = c->p.ncat;
+        if (ncat < 1 || ncat > MAXCAT) FAIL(c, "ice_strength on the device: ncat = %d not in 1..%d", ncat, MAXCAT);
+        if (!in->aicen || !in->vicen || !in->aice0) FAIL(c, "strength == NULL with kstrength == 1 needs aicen, vicen and aice0");
+        const size_t np = mask_elems(s), nblk = (size_t)c->nyb * c->nxb;
+        if (c->itd_ncat != ncat) {
+            if (c->itd) (void)hipFree(c->itd);
+            if (c->stage_itd) (void)hipFree(c->stage_itd);
+            c->itd = c->stage_itd = nullptr;
+            HIPCHK(c, hipMalloc(&c->itd, sizeof(double) * np * (2 * ncat + 1)));
+            HIPCHK(c, hipMemsetAsync(c->itd, 0, sizeof(double) * np * (2 * ncat + 1), c->stream));
+            HIPCHK(c, hipMalloc(&c->stage_itd, sizeof(double) * c->stage_n * ncat));
+            c->itd_ncat = ncat;
+        }
+        const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+        const double *hosts[3] = {in->aicen, in->vicen, in->aice0};
+        for (int a = 0; a < 3; a++) {
+            const int nc = a < 2 ? ncat : 1;
+            const double *src = (const double *)mapped_alias(hosts[a]);
+            if (!src) {
+                HIPCHK(c, hipMemcpyAsync(c->stage_itd, hosts[a], sizeof(double) * c->stage_n * nc, hipMemcpyHostToDevice, c->stream));
+                src = c->stage_itd;
+            }
+            for (int n = 0; n < nc; n++)
+                hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, src + (size_t)n * nblk, (size_t)nc * nblk,
+                                   c->itd + (size_t)(a * ncat + n) * np);
+        }
+        HIPCHK(c, hipGetLastError());
     }
     if (!st) {      // inputs only: the prognostic state stays resident on the device
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -924,6 +962,8 @@ extern "C" int evpk_prep(evpk_ctx *c) {
                        (const unsigned char *)prev_dat, fresh);
     hipLaunchKernelGGL(k_prep1b, g2, B2D, 0, c->stream, s);
     if (halo(c, F_ICETM, 1, false, false, 0.0)) return 1;                         // :210-211
+    if (c->strength_dev)                                                          // ice_strength, :291-301
+        hipLaunchKernelGGL(k_ice_strength, g2, B2D, 0, c->stream, s, c->p, (const double *)c->itd);
     // to_ugrid (:218-219) and t2ugrid_vector (:240-241; the T-grid wind sits in the work planes)
     if (!c->p.wind_on_ugrid && halo(c, F_WORK1, 2, false, true, 0.0)) return 1;
     hipLaunchKernelGGL(k_to_ugrid4, g2, B2D, 0, c->stream, s, c->p.wind_on_ugrid ? 0 : 1);
@@ -1285,6 +1325,7 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
         {st->tmass, F_TMASS}, {st->aiu, F_AIU}, {st->umass, F_UMASS}, {st->uvel_init, F_UVEL_INIT}, {st->vvel_init, F_VVEL_INIT}};
     for (auto &e : op)
         if (download_f(c, e.h, e.f, MODE_PHYS)) return 1;
+    if (c->strength_dev && download_f(c, st->strength, F_STRENGTH, MODE_ALL)) return 1;
     if (st->icetmask) {
         // icetmask travels as a 0/1 double plane on the device; convert through the staging buffer
         std::vector<double> tmp((size_t)c->nblocks * c->nyb * c->nxb, 0.0);

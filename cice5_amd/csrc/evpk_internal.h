@@ -84,6 +84,8 @@ __host__ __device__ inline size_t mask_elems(const Slab &s) { return (size_t)s.p
 struct DevParams {
     double dt, revp, ecci, denom1, arlx1i, brlx, cosw, sinw, rhow, rhoi, rhos, gravit, a_min, m_min;
     int ndte, tilt_from_slope, wind_on_ugrid;
+    int kstrength, krdg_partic, krdg_redist, ncat;
+    double mu_rdg, Cf;
 };
 
 // block descriptors on the device (gather / scatter)

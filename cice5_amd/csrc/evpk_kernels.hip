@@ -59,6 +59,21 @@ __global__ void k_gather_m(Slab s, const BlockDesc *bd, int nxb, int nyb, const 
     dst[mcell(s, si, sj)] = src[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)];
 }
 
+// one (nx_block, ny_block) slice per block, blocks `bstride` doubles apart (a category of aicen / vicen), into a plain
+// plane with the mask planes' indexing
+__global__ void k_gather_plane(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, size_t bstride, double *dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
+    const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
+    if (!gather_take(s, d, i, j, si, sj)) return;
+    dst[mcell(s, si, sj)] = src[(size_t)b * bstride + (size_t)(j - 1) * nxb + (i - 1)];
+}
+
 __device__ __forceinline__ bool scatter_take(const Slab &s, const BlockDesc &d, int i, int j, int mode, int &si, int &sj) {
     si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
     sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
@@ -192,6 +207,119 @@ __global__ void k_prep1b(Slab s) {
         if (!s.tmask[km]) m = 0.0;
     }
     FD(s, F_ICETM, k) = m;
+}
+
+// ------------------------------------------------------------------------------------
+// ice_strength (ice_mechred.F90:2111-2269) with ridge_itd (:936-1285), one thread per T cell.
+// exp(): Cody-Waite reduction + the degree-5 minimax in r^2 of fdlibm's e_exp.c (< 1 ulp), un-fused: the same operations
+// in the same order as the CPU restatement the tests compare with.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double dev_exp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const double ax = fabs(x);
+    double hi = 0.0, lo = 0.0;
+    int k = 0;
+    if (ax > 0.34657359027997264) {
+        if (ax < 1.0397207708399179) {
+            k = x < 0.0 ? -1 : 1;
+            hi = x - (double)k * ln2HI;
+            lo = (double)k * ln2LO;
+        } else {
+            k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+            const double t = (double)k;
+            hi = x - t * ln2HI;
+            lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (ax < 3.725290298461914e-09) {
+        return 1.0 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    return ldexp(y, k);
+}
+
+constexpr int MAXCAT = 16;
+
+// itd: planes [0..ncat) aicen, [ncat..2 ncat) vicen, [2 ncat] aice0, each mask_elems(s) doubles, index mcell()
+__global__ void k_ice_strength(Slab s, DevParams p, const double *itd) {
+    TILE_SKIP(s.act_any)
+    SLAB_IJ_ALL
+    const double puny = 1.0e-11, c0 = 0.0, c1 = 1.0, c2 = 2.0, p5 = 0.5, p333 = 1.0 / 3.0;
+    const double Gstar = 0.15, astar = 0.05, maxraft = 1.0, Hstar = 25.0, Pstar = 2.75e4, Cstar = 20.0;     // :72-82
+    double str = c0;                                                                                        // :2183
+    if (p.kstrength != 1) {                                                                                 // :2258-2265
+        if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl)
+            str = Pstar * FD(s, F_VICE, k) * dev_exp(-Cstar * (c1 - FD(s, F_AICE, k)));
+    } else if (i >= 1 && j >= 1 && FD(s, F_ICETM, k) == 1.0) {      // the T-cell list of evp_prep2 (ice_dyn_shared.F90:528-537)
+        const size_t np = mask_elems(s);
+        const int ncat = p.ncat;
+        const double Cp = p5 * p.gravit * (p.rhow - p.rhoi) * p.rhoi / p.rhow;                              // :68
+        const double Gstari = c1 / Gstar, astari = c1 / astar;
+        double Gsum[MAXCAT + 2], apartic[MAXCAT + 1], hrmin[MAXCAT + 1], hrmax[MAXCAT + 1], hrexp[MAXCAT + 1], krdg[MAXCAT + 1];
+        const double a0 = itd[(size_t)(2 * ncat) * np + km];
+        Gsum[0] = c0;
+        apartic[0] = c0;
+        for (int n = 1; n <= ncat; n++) { apartic[n] = c0; hrmin[n] = c0; hrmax[n] = c0; hrexp[n] = c0; krdg[n] = c1; }
+        Gsum[1] = (a0 > puny) ? a0 : Gsum[0];
+        for (int n = 1; n <= ncat; n++) {
+            const double a = itd[(size_t)(n - 1) * np + km];
+            Gsum[n + 1] = (a > puny) ? Gsum[n] + a : Gsum[n];
+        }
+        const double work = c1 / Gsum[ncat + 1];
+        for (int n = 0; n <= ncat; n++) Gsum[n + 1] = Gsum[n + 1] * work;
+        if (p.krdg_partic == 0) {
+            for (int n = 0; n <= ncat; n++) {
+                const double g1 = Gsum[n + 1], g0 = Gsum[n];
+                if (g1 < Gstar) apartic[n] = Gstari * (g1 - g0) * (c2 - (g0 + g1) * Gstari);
+                else if (g0 < Gstar) apartic[n] = Gstari * (Gstar - g0) * (c2 - (g0 + Gstar) * Gstari);
+            }
+        } else {
+            const double xtmp = c1 / (c1 - dev_exp(-astari));
+            for (int n = -1; n <= ncat; n++) Gsum[n + 1] = dev_exp(-Gsum[n + 1] * astari) * xtmp;
+            for (int n = 0; n <= ncat; n++) apartic[n] = Gsum[n] - Gsum[n + 1];
+        }
+        for (int n = 1; n <= ncat; n++) {
+            const double a = itd[(size_t)(n - 1) * np + km];
+            if (a > puny) {
+                double hi = itd[(size_t)(ncat + n - 1) * np + km] / a;
+                if (p.krdg_redist == 0) {
+                    hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                    hrmax[n] = c2 * sqrt(Hstar * hi);
+                    hrmax[n] = fmax(hrmax[n], hrmin[n] + puny);
+                    const double hrmean = p5 * (hrmin[n] + hrmax[n]);
+                    krdg[n] = hrmean / hi;
+                } else {
+                    hi = fmax(hi, puny);
+                    hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                    hrexp[n] = p.mu_rdg * sqrt(hi);
+                    krdg[n] = (hrmin[n] + hrexp[n]) / hi;
+                }
+            }
+        }
+        double aksum = apartic[0];
+        for (int n = 1; n <= ncat; n++) aksum = aksum + apartic[n] * (c1 - c1 / krdg[n]);
+        double sacc = c0;
+        for (int n = 1; n <= ncat; n++) {
+            const double a = itd[(size_t)(n - 1) * np + km];
+            if (a > puny && apartic[n] > c0) {
+                const double hi = itd[(size_t)(ncat + n - 1) * np + km] / a;
+                double h2rdg;
+                if (p.krdg_redist == 0)
+                    h2rdg = p333 * (hrmax[n] * hrmax[n] * hrmax[n] - hrmin[n] * hrmin[n] * hrmin[n]) / (hrmax[n] - hrmin[n]);
+                else
+                    h2rdg = hrmin[n] * hrmin[n] + c2 * hrmin[n] * hrexp[n] + c2 * hrexp[n] * hrexp[n];
+                const double dh2rdg = -hi * hi + h2rdg / krdg[n];
+                sacc = sacc + apartic[n] * dh2rdg;
+            }
+        }
+        str = p.Cf * Cp * sacc / aksum;
+    }
+    FD(s, F_STRENGTH, k) = str;
 }
 
 // the four T->U averages of evp() in one pass: umass <- tmass, aiu <- aice_init (ice_dyn_evp.F90:218-219) and,

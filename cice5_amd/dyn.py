@@ -21,7 +21,9 @@ from .blocks import Decomp
 
 def set_evp_parameters(dt: float, ndte: int, revised_evp: bool, xmin: float, *,
                        cosw: float = C.cosw, sinw: float = C.sinw,
-                       tilt_from_slope: bool = False, wind_on_ugrid: bool = False) -> evpk.Params:
+                       tilt_from_slope: bool = False, wind_on_ugrid: bool = False,
+                       kstrength: int = 1, krdg_partic: int = 1, krdg_redist: int = 1, ncat: int = 5,
+                       mu_rdg: float = 3.0, Cf: float = 17.0) -> evpk.Params:
     """ice_dyn_shared.F90:185-259.  `xmin` = min(global_minval(dxt,tmask), global_minval(dyt,tmask)) (:221-223)."""
     p = evpk.Params()
     dte = dt / float(ndte)                       # :209
@@ -45,6 +47,9 @@ def set_evp_parameters(dt: float, ndte: int, revised_evp: bool, xmin: float, *,
     p.rhow, p.rhoi, p.rhos, p.gravit = C.rhow, C.rhoi, C.rhos, C.gravit
     p.a_min, p.m_min = C.a_min, C.m_min
     p.tilt_from_slope, p.wind_on_ugrid = int(tilt_from_slope), int(wind_on_ugrid)
+    # ice_strength switches (ice_mechred.F90:54-64; defaults ice_init.F90:273-277), used when the strength is not an input
+    p.kstrength, p.krdg_partic, p.krdg_redist, p.ncat = kstrength, krdg_partic, krdg_redist, ncat
+    p.mu_rdg, p.Cf = mu_rdg, Cf
     return p
 
 
@@ -67,14 +72,19 @@ class EvpDynamics:
     def __init__(self, decomp: Decomp, fields: Dict[str, np.ndarray], *, ndte: int = 120, revised_evp: bool = False,
                  device: int = 0, unique_id: Optional[bytes] = None, cosw: float = C.cosw, sinw: float = C.sinw,
                  tilt_from_slope: bool = False, wind_on_ugrid: bool = False, xmin: Optional[float] = None,
-                 pin_host: bool = False):
+                 pin_host: bool = False, device_strength: Optional[dict] = None):
         """pin_host: page-lock the arrays of `fields` (evpk_pin_host) as a host model does once for its module arrays;
         evp() then moves them in place over PCIe.  The arrays must stay the same objects until close()."""
         self.decomp, self.fields = decomp, fields
         self.ndte, self.revised_evp = ndte, revised_evp
         self._opts = dict(cosw=cosw, sinw=sinw, tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
+        if device_strength is not None:
+            # ice_strength (ice_mechred.F90:2111) on the device instead of fields["strength"] as an input: a dict of
+            # kstrength / krdg_partic / krdg_redist / ncat / mu_rdg / Cf; kstrength = 1 reads fields["aicen", "vicen", "aice0"]
+            self._opts.update(device_strength)
         self._xmin = xmin
         self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id)
+        self.ctx.device_strength = device_strength is not None
         self.params: Optional[evpk.Params] = None
         self._pinned = [a for a in fields.values() if isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
                         and evpk.pin_host(a)] if pin_host else []

@@ -24,7 +24,7 @@ UNIQUE_ID_BYTES = 128
 GEOM_F64 = ["dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
             "tarear", "uarear", "tinyarea", "tarea", "uarea", "fcor"]
 STEP_IN_F64 = ["aice", "vice", "vsno", "aice_init", "strairxT", "strairyT", "strax", "stray",
-               "uocn", "vocn", "ss_tltx", "ss_tlty", "Cdn_ocn", "strength"]
+               "uocn", "vocn", "ss_tltx", "ss_tlty", "Cdn_ocn", "strength", "aicen", "vicen", "aice0"]
 STATE_OUT_F64 = ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx", "strinty",
                  "strocnx", "strocny", "strocnxT", "strocnyT", "strairx", "strairy",
                  "strtltx", "strtlty", "fm", "tmass", "aiu", "umass", "uvel_init", "vvel_init"]
@@ -48,7 +48,9 @@ class Params(ct.Structure):
                 ("cosw", ct.c_double), ("sinw", ct.c_double),
                 ("rhow", ct.c_double), ("rhoi", ct.c_double), ("rhos", ct.c_double), ("gravit", ct.c_double),
                 ("a_min", ct.c_double), ("m_min", ct.c_double),
-                ("tilt_from_slope", ct.c_int32), ("wind_on_ugrid", ct.c_int32)]
+                ("tilt_from_slope", ct.c_int32), ("wind_on_ugrid", ct.c_int32),
+                ("kstrength", ct.c_int32), ("krdg_partic", ct.c_int32), ("krdg_redist", ct.c_int32), ("ncat", ct.c_int32),
+                ("mu_rdg", ct.c_double), ("Cf", ct.c_double)]
 
 
 class StepIn(ct.Structure):
@@ -59,7 +61,7 @@ class State(ct.Structure):
     _fields_ = ([("uvel", c_f64p), ("vvel", c_f64p),
                  ("stressp", c_f64p * 4), ("stressm", c_f64p * 4), ("stress12", c_f64p * 4),
                  ("iceumask", c_i32p)] +
-                [(n, c_f64p) for n in STATE_OUT_F64] + [("icetmask", c_i32p)])
+                [(n, c_f64p) for n in STATE_OUT_F64] + [("icetmask", c_i32p), ("strength", c_f64p)])
 
 
 class Stats(ct.Structure):
@@ -182,6 +184,7 @@ class Context:
         if L.evpk_create(ct.byref(g), ct.byref(self._ctx)):
             raise EvpkError("evpk_create: " + L.evpk_last_error(None).decode())
         self.decomp = decomp
+        self.device_strength = False     # True: evpk_step_in.strength = NULL, ice_strength runs on the device
 
     def _chk(self, rc, what):
         if rc:
@@ -190,15 +193,15 @@ class Context:
     def set_params(self, p: Params):
         self._chk(self._L.evpk_set_params(self._ctx, ct.byref(p)), "evpk_set_params")
 
-    @staticmethod
-    def _step_in(f) -> StepIn:
+    def _step_in(self, f) -> StepIn:
         si = StepIn()
         for n in STEP_IN_F64:
             setattr(si, n, _p64(f.get(n)))
+        if self.device_strength:            # strength == NULL: ice_strength runs on the device
+            si.strength = None
         return si
 
-    @staticmethod
-    def _state(f) -> State:
+    def _state(self, f) -> State:
         st = State()
         st.uvel, st.vvel = _p64(f["uvel"]), _p64(f["vvel"])
         for k in ("stressp", "stressm", "stress12"):
@@ -207,6 +210,7 @@ class Context:
         for n in STATE_OUT_F64:
             setattr(st, n, _p64(f.get(n)))
         st.icetmask = _p32(f.get("icetmask"))
+        st.strength = _p64(f.get("strength")) if self.device_strength else None
         return st
 
     def run(self, f):

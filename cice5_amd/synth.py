@@ -276,3 +276,27 @@ def global_min_dx(case: SynthCase) -> float:
     if not m.any():
         return 1.0
     return float(min(case.field("dxt", I, J)[m].min(), case.field("dyt", I, J)[m].min()))
+
+
+def add_thickness_distribution(f: Dict[str, np.ndarray], ncat: int = 5) -> Dict[str, np.ndarray]:
+    """aicen, vicen (nblocks, ncat, ny_block, nx_block) and aice0 consistent with f['aice'], f['vice'] (the inputs of
+    ice_strength with kstrength = 1, ice_state.F90).  The split over the categories is a function of the cell's own
+    (aice, vice) only, so ghost cells agree with their owners on every decomposition; some categories are left empty
+    (aicen <= puny branches of ridge_itd)."""
+    aice, vice = f["aice"], f["vice"]
+    base = np.array([0.3, 1.0, 2.0, 3.5, 6.0, 9.0, 13.0, 18.0])[:ncat]
+    w = np.zeros((ncat,) + aice.shape)
+    for n in range(ncat):
+        r = np.modf(aice * (997.0 + 131.0 * n) + vice * (113.0 + 17.0 * n))[0]
+        w[n] = np.where(r < 0.2, 0.0, r)
+    tot = w.sum(axis=0)
+    w[0] = np.where(tot == 0.0, 1.0, w[0])
+    tot = np.where(tot == 0.0, 1.0, tot)
+    aicen = aice[None] * (w / tot[None])
+    den = (aicen * base[:, None, None, None]).sum(axis=0)
+    fac = np.where(den > 0.0, vice / np.where(den > 0.0, den, 1.0), 0.0)
+    vicen = aicen * base[:, None, None, None] * fac[None]
+    f["aicen"] = np.ascontiguousarray(np.moveaxis(aicen, 0, 1))        # (nblocks, ncat, ny, nx) = Fortran (nx,ny,ncat,nblocks)
+    f["vicen"] = np.ascontiguousarray(np.moveaxis(vicen, 0, 1))
+    f["aice0"] = np.maximum(1.0 - aice, 0.0)
+    return f

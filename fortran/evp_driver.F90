@@ -18,14 +18,15 @@
       use ice_flux
       use ice_atmo
       use ice_dyn_shared
-      use ice_dyn_evp, only: evp, evpk_npinned
+      use ice_dyn_evp, only: evp, evpk_npinned, evpk_device_strength
+      use ice_mechred, only: kstrength, krdg_partic, krdg_redist
 #ifdef AusCOM
       use cpl_arrays_setup, only: sicemass
 #endif
 
       implicit none
       character (len=512) :: fin, fout
-      integer (int_kind) :: hdr(10), n, i, nb, ncalls, call_no, ew, ns
+      integer (int_kind) :: hdr(10), trl(6), ios, n, i, nb, ncalls, call_no, ew, ns
       real (dbl_kind) :: sc(8), dt
       integer (int_kind), allocatable :: geo(:,:), itmp(:,:,:)
       character (len=16) :: nsname
@@ -76,14 +77,28 @@
       read (10) itmp; tmask = itmp /= 0
       read (10) itmp; umask = itmp /= 0
       read (10) itmp; iceumask = itmp /= 0
+      ! optional trailer: ice_strength on the device (thickness distribution + the ice_mechred switches)
+      trl = 0
+      read (10, iostat=ios) trl
+      if (ios /= 0) trl = 0
+      call zr (aice0)
+      if (trl(1) == 1) then
+         evpk_device_strength = .true.
+         ncat = trl(2); kstrength = trl(3); krdg_partic = trl(4); krdg_redist = trl(5)
+         allocate (aicen(nx_block,ny_block,ncat,nb), vicen(nx_block,ny_block,ncat,nb))
+         read (10) aicen
+         read (10) vicen
+         read (10) aice0
+      else
+         allocate (aicen(nx_block,ny_block,1,nb), vicen(nx_block,ny_block,1,nb))
+         aicen = 0.0_dbl_kind; vicen = 0.0_dbl_kind
+      endif
       close (10)
 
       call zr (divu); call zr (shear); call zr (rdg_conv); call zr (rdg_shear); call zr (prs_sig)
       call zr (strintx); call zr (strinty); call zr (strocnx); call zr (strocny)
       call zr (strocnxT); call zr (strocnyT); call zr (strairx); call zr (strairy)
-      call zr (strtltx); call zr (strtlty); call zr (fm); call zr (uvel_init); call zr (vvel_init); call zr (aice0)
-      allocate (aicen(nx_block,ny_block,1,nb), vicen(nx_block,ny_block,1,nb))
-      aicen = 0.0_dbl_kind; vicen = 0.0_dbl_kind
+      call zr (strtltx); call zr (strtlty); call zr (fm); call zr (uvel_init); call zr (vvel_init)
 
 #ifdef AusCOM
       allocate (sicemass(nx_block,ny_block,nb))     ! drivers/auscom/CICE_InitMod.F90 allocates it in the real model
@@ -103,6 +118,7 @@
       itmp = 0
       where (iceumask) itmp = 1
       write (11) itmp
+      if (evpk_device_strength) write (11) strength
       close (11)
       write (*,'(a,i0)') 'evp_driver: page-locked host arrays = ', evpk_npinned
       write (*,'(a,i0,a,i0,a,es12.5)') 'evp_driver: ', ncalls, ' call(s) of evp(dt) on ', nb, ' block(s); max |uvel| = ', maxval(abs(uvel))

@@ -43,13 +43,16 @@
          real (c_double) :: a_min, m_min
          integer (c_int32_t) :: tilt_from_slope
          integer (c_int32_t) :: wind_on_ugrid
+         integer (c_int32_t) :: kstrength, krdg_partic, krdg_redist, ncat    ! ice_strength on the device (strength = c_null_ptr)
+         real (c_double) :: mu_rdg, Cf
       end type evpk_params
 
       type, bind(C), public :: evpk_step_in
          type (c_ptr) :: aice, vice, vsno, aice_init
          type (c_ptr) :: strairxT, strairyT, strax, stray
          type (c_ptr) :: uocn, vocn, ss_tltx, ss_tlty, Cdn_ocn
-         type (c_ptr) :: strength
+         type (c_ptr) :: strength            ! c_null_ptr: the library evaluates ice_strength itself, from ...
+         type (c_ptr) :: aicen, vicen, aice0 ! ... the thickness distribution (kstrength = 1)
       end type evpk_step_in
 
       type, bind(C), public :: evpk_state
@@ -62,6 +65,7 @@
          type (c_ptr) :: tmass
          type (c_ptr) :: aiu, umass, uvel_init, vvel_init
          type (c_ptr) :: icetmask
+         type (c_ptr) :: strength            ! out: the strength the library computed
       end type evpk_state
 
       type, bind(C), public :: evpk_stats

@@ -37,8 +37,14 @@
       private
       public :: evp
       public :: evpk_npinned      ! (diagnostic) host arrays page-locked for in-place PCIe transfers
-      public :: evpk_resident_state, evpk_state_changed_on_host
+      public :: evpk_resident_state, evpk_state_changed_on_host, evpk_device_strength
       save
+
+      ! .true.: ice_strength (ice_mechred.F90:2111) runs on the device inside evpk_run, from aice, vice, aicen, vicen,
+      ! aice0 and the namelist switches of ice_mechred; the host then skips evp_prep1, the icetmask halo update and
+      ! ice_strength.  The device exp() is a fixed < 1 ulp algorithm, so `strength` may differ from the host intrinsic's
+      ! in the last bit -- hence opt-in.
+      logical (kind=log_kind) :: evpk_device_strength = .false.
 
       integer (kind=int_kind) :: evpk_npinned = 0
 
@@ -142,12 +148,12 @@
          call abort_ice('evp: more than one task needs -DEVPK_USE_MPI')
 #endif
       endif
-      g%dxt = c_loc(dxt);   g%dyt = c_loc(dyt);   g%dxhy = c_loc(dxhy); g%dyhx = c_loc(dyhx)
-      g%cxp = c_loc(cxp);   g%cyp = c_loc(cyp);   g%cxm  = c_loc(cxm);  g%cym  = c_loc(cym)
-      g%tarear = c_loc(tarear); g%uarear = c_loc(uarear); g%tinyarea = c_loc(tinyarea)
-      g%tarea  = c_loc(tarea);  g%uarea  = c_loc(uarea);  g%fcor = c_loc(fcor_blk)
+      g%dxt = loc_r8(dxt);   g%dyt = loc_r8(dyt);   g%dxhy = loc_r8(dxhy); g%dyhx = loc_r8(dyhx)
+      g%cxp = loc_r8(cxp);   g%cyp = loc_r8(cyp);   g%cxm  = loc_r8(cxm);  g%cym  = loc_r8(cym)
+      g%tarear = loc_r8(tarear); g%uarear = loc_r8(uarear); g%tinyarea = loc_r8(tinyarea)
+      g%tarea  = loc_r8(tarea);  g%uarea  = loc_r8(uarea);  g%fcor = loc_r8(fcor_blk)
       g%tmask  = c_loc(tmask_i); g%umask = c_loc(umask_i)
-      g%HTN = c_loc(HTN);  g%HTE = c_loc(HTE)      ! lets the library rebuild the eight metric planes on the fly if they match
+      g%HTN = loc_r8(HTN);  g%HTE = loc_r8(HTE)      ! lets the library rebuild the eight metric planes on the fly if they match
 
       rc = evpk_create (g, ctx)
       if (rc /= 0) call abort_ice('evp: evpk_create: '//trim(evpk_error_string(c_null_ptr)))
@@ -157,11 +163,21 @@
 
 !=======================================================================
 
-      subroutine pin_r8 (a)
-      real (kind=dbl_kind), dimension (:,:,:), intent(in), target, contiguous :: a
+! The reference declares its module arrays without TARGET (ice_state.F90, ice_flux.F90, ice_grid.F90), so C_LOC cannot be
+! applied to them directly.  Passed to an assumed-size TARGET dummy (sequence association: a contiguous whole array is
+! passed by address, no copy) their address can be taken; the arrays live as long as the run.
+
+      type (c_ptr) function loc_r8 (a)
+      real (kind=dbl_kind), dimension (*), intent(in), target :: a
+      loc_r8 = c_loc(a)
+      end function loc_r8
+
+      subroutine pin_r8 (a, n)
+      real (kind=dbl_kind), dimension (*), intent(in), target :: a
+      integer (kind=int_kind), intent(in) :: n      ! elements
       integer (c_int) :: rc
-      if (size(a) > 0) then
-         rc = evpk_pin_host (c_loc(a), int(size(a), c_size_t) * 8_c_size_t)
+      if (n > 0) then
+         rc = evpk_pin_host (c_loc(a), int(n, c_size_t) * 8_c_size_t)
          if (rc == 0) evpk_npinned = evpk_npinned + 1
       endif
       end subroutine pin_r8
@@ -202,7 +218,8 @@
           stressp_1, stressp_2, stressp_3, stressp_4, &
           stressm_1, stressm_2, stressm_3, stressm_4, &
           stress12_1, stress12_2, stress12_3, stress12_4
-      use ice_mechred, only: ice_strength
+      use ice_mechred, only: ice_strength, kstrength, krdg_partic, krdg_redist, mu_rdg, Cf
+      use ice_domain_size, only: ncat
       use ice_state, only: aice, vice, vsno, uvel, vvel, divu, shear, &
           aice_init, aice0, aicen, vicen, strength
       use ice_timers, only: timer_dynamics, timer_bound, &
@@ -259,6 +276,8 @@
 #ifdef ACCESS
       if (.not. calc_strair) p%wind_on_ugrid = 1         ! ice_dyn_evp.F90:226-228
 #endif
+      p%kstrength = kstrength;  p%krdg_partic = krdg_partic;  p%krdg_redist = krdg_redist
+      p%ncat = ncat;  p%mu_rdg = mu_rdg;  p%Cf = Cf
       rc = evpk_set_params (ctx, p)
       if (rc /= 0) call abort_ice('evp: evpk_set_params: '//trim(evpk_error_string(ctx)))
 
@@ -266,6 +285,7 @@
       ! ice strength (host, reference routine and signature): needs the
       ! T-cell list of evp_prep2, hence evp_prep1 + halo of icetmask
       !-----------------------------------------------------------------
+      if (.not. evpk_device_strength) then
       do iblk = 1, nblocks
          this_block = get_block(blocks_ice(iblk),iblk)
          call evp_prep1 (nx_block,           ny_block,           &
@@ -307,60 +327,69 @@
                             strength(:,:,  iblk) )
       enddo
 
+      endif   ! host ice_strength
+
       !-----------------------------------------------------------------
       ! everything else of evp(): one call into the HIP library
       !-----------------------------------------------------------------
       iceumask_i = 0
       where (iceumask) iceumask_i = 1
 
-      sin%aice = c_loc(aice);  sin%vice = c_loc(vice);  sin%vsno = c_loc(vsno)
-      sin%aice_init = c_loc(aice_init)
-      sin%strairxT = c_loc(strairxT);  sin%strairyT = c_loc(strairyT)
-      sin%strax = c_loc(strax);        sin%stray = c_loc(stray)
-      sin%uocn = c_loc(uocn);          sin%vocn = c_loc(vocn)
-      sin%ss_tltx = c_loc(ss_tltx);    sin%ss_tlty = c_loc(ss_tlty)
-      sin%Cdn_ocn = c_loc(Cdn_ocn)
-      sin%strength = c_loc(strength)
+      sin%aice = loc_r8(aice);  sin%vice = loc_r8(vice);  sin%vsno = loc_r8(vsno)
+      sin%aice_init = loc_r8(aice_init)
+      sin%strairxT = loc_r8(strairxT);  sin%strairyT = loc_r8(strairyT)
+      sin%strax = loc_r8(strax);        sin%stray = loc_r8(stray)
+      sin%uocn = loc_r8(uocn);          sin%vocn = loc_r8(vocn)
+      sin%ss_tltx = loc_r8(ss_tltx);    sin%ss_tlty = loc_r8(ss_tlty)
+      sin%Cdn_ocn = loc_r8(Cdn_ocn)
+      sin%strength = loc_r8(strength)
+      sin%aicen = c_null_ptr;  sin%vicen = c_null_ptr;  sin%aice0 = c_null_ptr
+      st%strength = c_null_ptr
+      if (evpk_device_strength) then
+         sin%strength = c_null_ptr
+         sin%aicen = loc_r8(aicen);  sin%vicen = loc_r8(vicen);  sin%aice0 = loc_r8(aice0)
+         st%strength = loc_r8(strength)
+      endif
 
-      st%uvel = c_loc(uvel);  st%vvel = c_loc(vvel)
-      st%stressp(1) = c_loc(stressp_1);   st%stressp(2) = c_loc(stressp_2)
-      st%stressp(3) = c_loc(stressp_3);   st%stressp(4) = c_loc(stressp_4)
-      st%stressm(1) = c_loc(stressm_1);   st%stressm(2) = c_loc(stressm_2)
-      st%stressm(3) = c_loc(stressm_3);   st%stressm(4) = c_loc(stressm_4)
-      st%stress12(1) = c_loc(stress12_1); st%stress12(2) = c_loc(stress12_2)
-      st%stress12(3) = c_loc(stress12_3); st%stress12(4) = c_loc(stress12_4)
+      st%uvel = loc_r8(uvel);  st%vvel = loc_r8(vvel)
+      st%stressp(1) = loc_r8(stressp_1);   st%stressp(2) = loc_r8(stressp_2)
+      st%stressp(3) = loc_r8(stressp_3);   st%stressp(4) = loc_r8(stressp_4)
+      st%stressm(1) = loc_r8(stressm_1);   st%stressm(2) = loc_r8(stressm_2)
+      st%stressm(3) = loc_r8(stressm_3);   st%stressm(4) = loc_r8(stressm_4)
+      st%stress12(1) = loc_r8(stress12_1); st%stress12(2) = loc_r8(stress12_2)
+      st%stress12(3) = loc_r8(stress12_3); st%stress12(4) = loc_r8(stress12_4)
       st%iceumask = c_loc(iceumask_i)
-      st%divu = c_loc(divu);          st%shear = c_loc(shear)
-      st%rdg_conv = c_loc(rdg_conv);  st%rdg_shear = c_loc(rdg_shear)
-      st%prs_sig = c_loc(prs_sig)
-      st%strintx = c_loc(strintx);    st%strinty = c_loc(strinty)
-      st%strocnx = c_loc(strocnx);    st%strocny = c_loc(strocny)
-      st%strocnxT = c_loc(strocnxT);  st%strocnyT = c_loc(strocnyT)
-      st%strairx = c_loc(strairx);    st%strairy = c_loc(strairy)
-      st%strtltx = c_loc(strtltx);    st%strtlty = c_loc(strtlty)
-      st%fm = c_loc(fm)
+      st%divu = loc_r8(divu);          st%shear = loc_r8(shear)
+      st%rdg_conv = loc_r8(rdg_conv);  st%rdg_shear = loc_r8(rdg_shear)
+      st%prs_sig = loc_r8(prs_sig)
+      st%strintx = loc_r8(strintx);    st%strinty = loc_r8(strinty)
+      st%strocnx = loc_r8(strocnx);    st%strocny = loc_r8(strocny)
+      st%strocnxT = loc_r8(strocnxT);  st%strocnyT = loc_r8(strocnyT)
+      st%strairx = loc_r8(strairx);    st%strairy = loc_r8(strairy)
+      st%strtltx = loc_r8(strtltx);    st%strtlty = loc_r8(strtlty)
+      st%fm = loc_r8(fm)
       st%tmass = c_loc(tmass)
       st%aiu = c_loc(aiu);  st%umass = c_loc(umass)
-      st%uvel_init = c_loc(uvel_init);  st%vvel_init = c_loc(vvel_init)
+      st%uvel_init = loc_r8(uvel_init);  st%vvel_init = loc_r8(vvel_init)
       st%icetmask = c_null_ptr
 
       if (.not. pinned) then
          ! The arrays handed over live as long as the run: page-lock them once, so that the library moves them in
          ! place over PCIe instead of through staging copies (a refusal leaves the staged path in use).
-         call pin_r8 (aice);  call pin_r8 (vice);  call pin_r8 (vsno);  call pin_r8 (aice_init)
-         call pin_r8 (strairxT);  call pin_r8 (strairyT);  call pin_r8 (strax);  call pin_r8 (stray)
-         call pin_r8 (uocn);  call pin_r8 (vocn);  call pin_r8 (ss_tltx);  call pin_r8 (ss_tlty)
-         call pin_r8 (Cdn_ocn);  call pin_r8 (strength)
-         call pin_r8 (uvel);  call pin_r8 (vvel)
-         call pin_r8 (stressp_1);  call pin_r8 (stressp_2);  call pin_r8 (stressp_3);  call pin_r8 (stressp_4)
-         call pin_r8 (stressm_1);  call pin_r8 (stressm_2);  call pin_r8 (stressm_3);  call pin_r8 (stressm_4)
-         call pin_r8 (stress12_1); call pin_r8 (stress12_2); call pin_r8 (stress12_3); call pin_r8 (stress12_4)
-         call pin_r8 (divu);  call pin_r8 (shear);  call pin_r8 (rdg_conv);  call pin_r8 (rdg_shear)
-         call pin_r8 (prs_sig);  call pin_r8 (strintx);  call pin_r8 (strinty)
-         call pin_r8 (strocnx);  call pin_r8 (strocny);  call pin_r8 (strocnxT);  call pin_r8 (strocnyT)
-         call pin_r8 (strairx);  call pin_r8 (strairy);  call pin_r8 (strtltx);  call pin_r8 (strtlty)
-         call pin_r8 (fm);  call pin_r8 (tmass);  call pin_r8 (aiu);  call pin_r8 (umass)
-         call pin_r8 (uvel_init);  call pin_r8 (vvel_init)
+         call pin_r8 (aice, size(aice));  call pin_r8 (vice, size(vice));  call pin_r8 (vsno, size(vsno));  call pin_r8 (aice_init, size(aice_init))
+         call pin_r8 (strairxT, size(strairxT));  call pin_r8 (strairyT, size(strairyT));  call pin_r8 (strax, size(strax));  call pin_r8 (stray, size(stray))
+         call pin_r8 (uocn, size(uocn));  call pin_r8 (vocn, size(vocn));  call pin_r8 (ss_tltx, size(ss_tltx));  call pin_r8 (ss_tlty, size(ss_tlty))
+         call pin_r8 (Cdn_ocn, size(Cdn_ocn));  call pin_r8 (strength, size(strength))
+         call pin_r8 (uvel, size(uvel));  call pin_r8 (vvel, size(vvel))
+         call pin_r8 (stressp_1, size(stressp_1));  call pin_r8 (stressp_2, size(stressp_2));  call pin_r8 (stressp_3, size(stressp_3));  call pin_r8 (stressp_4, size(stressp_4))
+         call pin_r8 (stressm_1, size(stressm_1));  call pin_r8 (stressm_2, size(stressm_2));  call pin_r8 (stressm_3, size(stressm_3));  call pin_r8 (stressm_4, size(stressm_4))
+         call pin_r8 (stress12_1, size(stress12_1)); call pin_r8 (stress12_2, size(stress12_2)); call pin_r8 (stress12_3, size(stress12_3)); call pin_r8 (stress12_4, size(stress12_4))
+         call pin_r8 (divu, size(divu));  call pin_r8 (shear, size(shear));  call pin_r8 (rdg_conv, size(rdg_conv));  call pin_r8 (rdg_shear, size(rdg_shear))
+         call pin_r8 (prs_sig, size(prs_sig));  call pin_r8 (strintx, size(strintx));  call pin_r8 (strinty, size(strinty))
+         call pin_r8 (strocnx, size(strocnx));  call pin_r8 (strocny, size(strocny));  call pin_r8 (strocnxT, size(strocnxT));  call pin_r8 (strocnyT, size(strocnyT))
+         call pin_r8 (strairx, size(strairx));  call pin_r8 (strairy, size(strairy));  call pin_r8 (strtltx, size(strtltx));  call pin_r8 (strtlty, size(strtlty))
+         call pin_r8 (fm, size(fm));  call pin_r8 (tmass, size(tmass));  call pin_r8 (aiu, size(aiu));  call pin_r8 (umass, size(umass))
+         call pin_r8 (uvel_init, size(uvel_init));  call pin_r8 (vvel_init, size(vvel_init))
          rc = evpk_pin_host (c_loc(iceumask_i), int(size(iceumask_i), c_size_t) * 4_c_size_t)
          pinned = .true.
       endif

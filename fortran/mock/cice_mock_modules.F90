@@ -147,7 +147,7 @@
       module ice_grid
       use ice_kinds_mod
       implicit none
-      real (kind=dbl_kind), dimension(:,:,:), allocatable, target :: &
+      real (kind=dbl_kind), dimension(:,:,:), allocatable :: &
          dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, uarear, tinyarea, tarea, uarea, HTN, HTE
       logical (kind=log_kind), dimension(:,:,:), allocatable :: tmask, umask
       character (char_len) :: grid_type = 'rectangular'
@@ -156,15 +156,15 @@
       module ice_state
       use ice_kinds_mod
       implicit none
-      real (kind=dbl_kind), dimension(:,:,:), allocatable, target :: &
+      real (kind=dbl_kind), dimension(:,:,:), allocatable :: &
          aice, vice, vsno, aice_init, aice0, uvel, vvel, divu, shear, strength
-      real (kind=dbl_kind), dimension(:,:,:,:), allocatable, target :: aicen, vicen
+      real (kind=dbl_kind), dimension(:,:,:,:), allocatable :: aicen, vicen
       end module ice_state
 
       module ice_flux
       use ice_kinds_mod
       implicit none
-      real (kind=dbl_kind), dimension(:,:,:), allocatable, target :: &
+      real (kind=dbl_kind), dimension(:,:,:), allocatable :: &
          rdg_conv, rdg_shear, prs_sig, strairxT, strairyT, strairx, strairy, uocn, vocn, &
          ss_tltx, ss_tlty, fm, strtltx, strtlty, strocnx, strocny, strintx, strinty, &
          strocnxT, strocnyT, strax, stray, &
@@ -176,13 +176,16 @@
       module ice_atmo
       use ice_kinds_mod
       implicit none
-      real (kind=dbl_kind), dimension(:,:,:), allocatable, target :: Cdn_ocn
+      real (kind=dbl_kind), dimension(:,:,:), allocatable :: Cdn_ocn
       logical (kind=log_kind) :: calc_strair = .true.
       end module ice_atmo
 
       module ice_mechred
       use ice_kinds_mod
       implicit none
+      ! namelist switches (ice_mechred.F90:54-64; defaults ice_init.F90:273-277)
+      integer (kind=int_kind) :: kstrength = 1, krdg_partic = 1, krdg_redist = 1
+      real (kind=dbl_kind) :: mu_rdg = 3.0_dbl_kind, Cf = 17.0_dbl_kind
       contains
       subroutine ice_strength (nx_block, ny_block, ilo, ihi, jlo, jhi, icells, indxi, indxj, &
                                aice, vice, aice0, aicen, vicen, strength)
@@ -215,7 +218,7 @@
       logical (kind=log_kind) :: revised_evp = .false.
       real (kind=dbl_kind) :: cosw = 1.0_dbl_kind, sinw = 0.0_dbl_kind, &
          revp, ecci, dtei, dte2T, denom1, arlx1i, brlx
-      real (kind=dbl_kind), allocatable, target :: fcor_blk(:,:,:), uvel_init(:,:,:), vvel_init(:,:,:)
+      real (kind=dbl_kind), allocatable :: fcor_blk(:,:,:), uvel_init(:,:,:), vvel_init(:,:,:)
       contains
       ! own few-line version of the T-cell mask step (3x3 dilation of the ice mask, cleared on land)
       subroutine evp_prep1 (nx_block, ny_block, ilo, ihi, jlo, jhi, aice, vice, vsno, tmask, &

@@ -82,17 +82,26 @@ typedef struct {
     double a_min, m_min;
     int32_t tilt_from_slope;                   /* 1: strtlt = -gravit*umass*ss_tlt (:601-602 / use_ocnslope), 0: geostrophic (:598-599) */
     int32_t wind_on_ugrid;                     /* 1: strairx/y := strax/stray (ice_dyn_evp.F90:226-228), 0: t2ugrid_vector (:240-241) */
+    /* ice_strength on the device (used only when evpk_step_in.strength == NULL): the namelist switches of
+     * ice_mechred.F90:54-64 (defaults ice_init.F90:273-277: 1, 1, 1, mu_rdg = 3, Cf = 17) and ncat (ice_domain_size) */
+    int32_t kstrength, krdg_partic, krdg_redist, ncat;
+    double mu_rdg, Cf;
 } evpk_params;
 
 /* Per-call inputs: what evp(dt) reads from ice_state / ice_flux / ice_atmo
  * (ice_dyn_evp.F90:70-90).  `strength` is the result of ice_strength (:291-301),
  * physical cells; the library does its halo update (:311).  NULL is allowed for
- * ss_tltx/ss_tlty when tilt_from_slope == 0 and for strax/stray when wind_on_ugrid == 0. */
+ * ss_tltx/ss_tlty when tilt_from_slope == 0 and for strax/stray when wind_on_ugrid == 0.
+ * strength == NULL: the library evaluates ice_strength itself (ice_mechred.F90:2111-2269) where the reference calls it,
+ * from aice, vice and -- for kstrength == 1 -- the thickness distribution aicen, vicen (nx_block, ny_block, ncat,
+ * nblocks) and aice0 (ice_state.F90); the host then needs neither evp_prep1 nor the icetmask halo before the call.
+ * Its exp() is a fixed < 1 ulp algorithm, so the result can differ from a host intrinsic in the last bit. */
 typedef struct {
     const double *aice, *vice, *vsno, *aice_init;
     const double *strairxT, *strairyT, *strax, *stray;
     const double *uocn, *vocn, *ss_tltx, *ss_tlty, *Cdn_ocn;
     const double *strength;
+    const double *aicen, *vicen, *aice0;       /* read only when strength == NULL and kstrength == 1 */
 } evpk_step_in;
 
 /* In/out prognostic state and outputs: the arrays evp(dt) leaves modified.
@@ -110,6 +119,7 @@ typedef struct {
     double *tmass;                             /* AusCOM: sicemass = tmass (ice_dyn_evp.F90:205-207) */
     double *aiu, *umass, *uvel_init, *vvel_init;
     int32_t *icetmask;
+    double *strength;                          /* out, all cells: the strength the library computed (ignored when it was an input) */
 } evpk_state;
 
 typedef struct {

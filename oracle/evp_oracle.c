@@ -410,6 +410,135 @@ void orc_principal_stress(int nx, int ny, const double *stressp_1, const double 
     }
 }
 
+/* ---------------------------------------------------------------------------
+ * exp(x): k = nint(x/ln2), r = x - k ln2 in two pieces, exp(r) = 1 + 2r/(R(r^2) - r) with R = 2 - c/r ... written as in
+ * fdlibm's e_exp.c (Sun Microsystems, public domain), whose error bound is < 1 ulp.
+ * ------------------------------------------------------------------------- */
+double orc_exp(double x) {
+    static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                        invln2 = 1.44269504088896338700e+00,
+                        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                        P5 = 4.13813679705723846039e-08;
+    const double ax = fabs(x);
+    double hi = 0.0, lo = 0.0;
+    int k = 0;
+    if (ax > 0.34657359027997264) {                 /* |x| > 0.5 ln2 */
+        if (ax < 1.0397207708399179) {              /* |x| < 1.5 ln2 */
+            k = x < 0.0 ? -1 : 1;
+            hi = x - (double)k * ln2HI;
+            lo = (double)k * ln2LO;
+        } else {
+            k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+            const double t = (double)k;
+            hi = x - t * ln2HI;                     /* t*ln2HI is exact */
+            lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (ax < 3.725290298461914e-09) {        /* 2^-28 */
+        return c1 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return c1 - ((x * c) / (c - c2) - x);
+    const double y = c1 - ((lo - (x * c) / (c2 - c)) - hi);
+    return ldexp(y, k);
+}
+
+/* ---------------------------------------------------------------------------
+ * ice_strength, source/ice_mechred.F90:2111-2269.  Rothrock (1975): strength from the potential-energy change of
+ * ridging, with the participation function and the ridge thickness distribution of ridge_itd (:936-1285); constants
+ * :66-82.  asum_ridging (:758-812) is called by the reference but its result is not used by the strength.
+ * ------------------------------------------------------------------------- */
+#define ORC_MAXCAT 16
+void orc_ice_strength(int nx, int ny, int ilo, int ihi, int jlo, int jhi, int icells,
+                      const int32_t *indxi, const int32_t *indxj,
+                      const double *aice, const double *vice, const double *aice0,
+                      const double *aicen, const double *vicen, double *strength, const orc_params *p) {
+    const size_t nn = (size_t)nx * ny;
+    const double puny = 1.0e-11, p333 = c1 / 3.0, p15 = 0.15, p05 = 0.05, c25 = 25.0, c20 = 20.0;
+    const double Gstar = p15, astar = p05, maxraft = c1, Hstar = c25, Pstar = 2.75e4, Cstar = c20;      /* :72-82 */
+    const double Cp = p5 * p->gravit * (p->rhow - p->rhoi) * p->rhoi / p->rhow;                         /* :68 */
+    const double Gstari = c1 / Gstar, astari = c1 / astar;                                              /* :1003-1005 */
+    const int ncat = p->ncat;
+    for (size_t k = 0; k < nn; k++) strength[k] = c0;                                                   /* :2183 */
+    if (p->kstrength != 1) {                                                                            /* :2258-2265 */
+        for (int j = jlo; j <= jhi; j++)
+            for (int i = ilo; i <= ihi; i++)
+                strength[IX(i, j)] = Pstar * vice[IX(i, j)] * orc_exp(-Cstar * (c1 - aice[IX(i, j)]));
+        return;
+    }
+    for (int ij = 0; ij < icells; ij++) {
+        const size_t k = IX(indxi[ij], indxj[ij]);
+        double Gsum[ORC_MAXCAT + 2];        /* Gsum[n+1] = Gsum(ij,n), n = -1..ncat */
+        double apartic[ORC_MAXCAT + 1], hrmin[ORC_MAXCAT + 1], hrmax[ORC_MAXCAT + 1], hrexp[ORC_MAXCAT + 1], krdg[ORC_MAXCAT + 1];
+        /* ---- ridge_itd ---- */
+        Gsum[0] = c0;                                                                                   /* :1021-1025 */
+        apartic[0] = c0;
+        for (int n = 1; n <= ncat; n++) { apartic[n] = c0; hrmin[n] = c0; hrmax[n] = c0; hrexp[n] = c0; krdg[n] = c1; }
+        Gsum[1] = (aice0[k] > puny) ? aice0[k] : Gsum[0];                                               /* :1050-1058 */
+        for (int n = 1; n <= ncat; n++) {                                                               /* :1060-1071 */
+            const double a = aicen[(size_t)(n - 1) * nn + k];
+            Gsum[n + 1] = (a > puny) ? Gsum[n] + a : Gsum[n];
+        }
+        const double work = c1 / Gsum[ncat + 1];                                                        /* :1076-1083 */
+        for (int n = 0; n <= ncat; n++) Gsum[n + 1] = Gsum[n + 1] * work;
+        if (p->krdg_partic == 0) {                                                                      /* :1104-1117 */
+            for (int n = 0; n <= ncat; n++) {
+                const double g1 = Gsum[n + 1], g0 = Gsum[n];
+                if (g1 < Gstar) apartic[n] = Gstari * (g1 - g0) * (c2 - (g0 + g1) * Gstari);
+                else if (g0 < Gstar) apartic[n] = Gstari * (Gstar - g0) * (c2 - (g0 + Gstar) * Gstari);
+            }
+        } else {                                                                                        /* :1119-1141 */
+            const double xtmp = c1 / (c1 - orc_exp(-astari));
+            for (int n = -1; n <= ncat; n++) Gsum[n + 1] = orc_exp(-Gsum[n + 1] * astari) * xtmp;
+            for (int n = 0; n <= ncat; n++) apartic[n] = Gsum[n] - Gsum[n + 1];
+        }
+        if (p->krdg_redist == 0) {                                                                      /* :1169-1190 */
+            for (int n = 1; n <= ncat; n++) {
+                const double a = aicen[(size_t)(n - 1) * nn + k];
+                if (a > puny) {
+                    const double hi = vicen[(size_t)(n - 1) * nn + k] / a;
+                    hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                    hrmax[n] = c2 * sqrt(Hstar * hi);
+                    hrmax[n] = fmax(hrmax[n], hrmin[n] + puny);
+                    const double hrmean = p5 * (hrmin[n] + hrmax[n]);
+                    krdg[n] = hrmean / hi;
+                }
+            }
+        } else {                                                                                        /* :1219-1240 */
+            for (int n = 1; n <= ncat; n++) {
+                const double a = aicen[(size_t)(n - 1) * nn + k];
+                if (a > puny) {
+                    double hi = vicen[(size_t)(n - 1) * nn + k] / a;
+                    hi = fmax(hi, puny);
+                    hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                    hrexp[n] = p->mu_rdg * sqrt(hi);
+                    krdg[n] = (hrmin[n] + hrexp[n]) / hi;
+                }
+            }
+        }
+        double aksum = apartic[0];                                                                      /* :1248-1258 */
+        for (int n = 1; n <= ncat; n++) aksum = aksum + apartic[n] * (c1 - c1 / krdg[n]);
+        /* ---- ice_strength, Rothrock ---- */
+        double s = c0;
+        for (int n = 1; n <= ncat; n++) {                                                               /* :2207-2243 */
+            const double a = aicen[(size_t)(n - 1) * nn + k];
+            if (a > puny && apartic[n] > c0) {
+                const double hi = vicen[(size_t)(n - 1) * nn + k] / a;
+                double h2rdg;
+                if (p->krdg_redist == 0)
+                    h2rdg = p333 * (hrmax[n] * hrmax[n] * hrmax[n] - hrmin[n] * hrmin[n] * hrmin[n]) / (hrmax[n] - hrmin[n]);
+                else
+                    h2rdg = hrmin[n] * hrmin[n] + c2 * hrmin[n] * hrexp[n] + c2 * hrexp[n] * hrexp[n];
+                const double dh2rdg = -hi * hi + h2rdg / krdg[n];
+                s = s + apartic[n] * dh2rdg;
+            }
+        }
+        strength[k] = p->Cf * Cp * s / aksum;                                                           /* :2250 */
+    }
+}
+
 /* Hibler (1979) strength, kstrength /= 1  (source/ice_mechred.F90:2258-2265; Pstar,Cstar :80-82) */
 void orc_strength_hibler(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
                          const double *aice, const double *vice, double *strength) {
@@ -605,7 +734,12 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
                       f->strtltx + o, f->strtlty + o, f->strocnx + o, f->strocny + o,
                       f->strintx + o, f->strinty + o, waterx + o, watery + o, forcex + o, forcey + o,
                       sp, sm, s12, f->uvel_init + o, f->vvel_init + o, f->uvel + o, f->vvel + o, p);
-        /* ice_strength (:291-301) is an input here: f->strength already holds it on physical cells */
+        /* ice_strength (:291-301): an input (f->strength already holds it on physical cells) unless strength_mode = 1 */
+        if (p->strength_mode)
+            orc_ice_strength(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], icellt[b], indxti + o, indxtj + o,
+                             f->aice + o, f->vice + o, f->aice0 ? f->aice0 + o : NULL,
+                             f->aicen ? f->aicen + o * (size_t)p->ncat : NULL, f->vicen ? f->vicen + o * (size_t)p->ncat : NULL,
+                             f->strength + o, p);
     }
     orc_halo_r8(g, f->strength, ORC_LOC_CENTER, ORC_KIND_SCALAR, 0.0);    /* :311-312 */
     orc_halo_r8(g, f->uvel, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);      /* :314-315 (fld2 = u,v) */

@@ -49,6 +49,14 @@ typedef struct {
     double a_min, m_min;
     int32_t tilt_from_slope;   /* 1: strtlt = -gravit*umass*ss_tlt (coupled / use_ocnslope), 0: geostrophic */
     int32_t wind_on_ugrid;     /* 1: strairx/y := strax/stray (ACCESS, calc_strair=F), skip t2ugrid_vector */
+    /* ice_strength (source/ice_mechred.F90:2111-2269), SURVEY.md S8 row a10 / f-1 */
+    int32_t strength_mode;     /* 0: f->strength is an input (computed by the caller); 1: evp calls ice_strength as the reference does (:291-301) */
+    int32_t kstrength;         /* 1 Rothrock (1975), else Hibler (1979)            ice_mechred.F90:55-56, ice_init.F90:273 */
+    int32_t krdg_partic;       /* 0 Thorndike et al. (1975), 1 exponential          :57-58 */
+    int32_t krdg_redist;       /* 0 Hibler (1980), 1 exponential                    :59-60 */
+    int32_t ncat;              /* thickness categories (ice_domain_size) */
+    int32_t pad_;
+    double mu_rdg, Cf;         /* :63-64; namelist defaults 3, 17 (ice_init.F90:276-277) */
 } orc_params;
 
 /* module-global state evp(dt) reads and writes */
@@ -61,8 +69,11 @@ typedef struct {
     const double *aice, *vice, *vsno, *aice_init;
     const double *strairxT, *strairyT, *strax, *stray;
     const double *uocn, *vocn, *ss_tltx, *ss_tlty, *Cdn_ocn;
+    /* ice thickness distribution, only read when strength_mode = 1 and kstrength = 1:
+     * aicen, vicen (nx_block, ny_block, ncat, nblocks), aice0 (nx_block, ny_block, nblocks)   ice_state.F90 */
+    const double *aicen, *vicen, *aice0;
     /* in/out */
-    double *strength;            /* in (already computed) */
+    double *strength;            /* in (already computed) when strength_mode = 0, else out */
     double *uvel, *vvel;
     double *stressp[4], *stressm[4], *stress12[4];
     int32_t *iceumask;
@@ -130,6 +141,18 @@ void orc_evp_finish(int nx, int ny, int icellu, const double *Cw,
 
 void orc_principal_stress(int nx, int ny, const double *stressp_1, const double *stressm_1,
                           const double *stress12_1, const double *prs_sig, double *sig1, double *sig2);
+
+/* exp() of this restatement: the reference calls the Fortran intrinsic, whose last bit is implementation-defined; the
+ * oracle and the HIP kernels both evaluate the classical Cody-Waite reduction + degree-5 minimax in r^2 (the fdlibm
+ * scheme, < 1 ulp) in plain un-fused fp64 so that they agree bit for bit.  |x| < 700. */
+double orc_exp(double x);
+
+/* ice_strength (ice_mechred.F90:2111-2269) with asum_ridging (:758-812, unused by the strength) and ridge_itd (:936-1285)
+ * on one block; aicen / vicen are (ncat, ny, nx) planes of that block */
+void orc_ice_strength(int nx, int ny, int ilo, int ihi, int jlo, int jhi, int icells,
+                      const int32_t *indxi, const int32_t *indxj,
+                      const double *aice, const double *vice, const double *aice0,
+                      const double *aicen, const double *vicen, double *strength, const orc_params *p);
 
 void orc_strength_hibler(int nx, int ny, int ilo, int ihi, int jlo, int jhi,
                          const double *aice, const double *vice, double *strength);

@@ -35,7 +35,10 @@ class OrcParams(ct.Structure):
                 ("cosw", ct.c_double), ("sinw", ct.c_double), ("dragio", ct.c_double),
                 ("rhow", ct.c_double), ("rhoi", ct.c_double), ("rhos", ct.c_double), ("gravit", ct.c_double),
                 ("a_min", ct.c_double), ("m_min", ct.c_double),
-                ("tilt_from_slope", ct.c_int32), ("wind_on_ugrid", ct.c_int32)]
+                ("tilt_from_slope", ct.c_int32), ("wind_on_ugrid", ct.c_int32),
+                ("strength_mode", ct.c_int32), ("kstrength", ct.c_int32), ("krdg_partic", ct.c_int32),
+                ("krdg_redist", ct.c_int32), ("ncat", ct.c_int32), ("pad_", ct.c_int32),
+                ("mu_rdg", ct.c_double), ("Cf", ct.c_double)]
 
 
 _F64_IN = ["dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
@@ -51,6 +54,7 @@ _F64_OUT = ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx", "str
 class OrcFields(ct.Structure):
     _fields_ = ([(n, c_f64p) for n in _F64_IN] + [(n, c_i32p) for n in _I32_IN] +
                 [(n, c_f64p) for n in _F64_IN2] +
+                [("aicen", c_f64p), ("vicen", c_f64p), ("aice0", c_f64p)] +
                 [("strength", c_f64p), ("uvel", c_f64p), ("vvel", c_f64p),
                  ("stressp", c_f64p * 4), ("stressm", c_f64p * 4), ("stress12", c_f64p * 4),
                  ("iceumask", c_i32p)] +
@@ -97,6 +101,9 @@ def lib():
         _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
         _lib.orc_principal_stress.argtypes = [ct.c_int, ct.c_int] + [c_f64p] * 6
         _lib.orc_set_halo_callback.argtypes = [HALO_CB, ct.c_void_p]
+        _lib.orc_exp.argtypes = [ct.c_double]
+        _lib.orc_exp.restype = ct.c_double
+        _lib.orc_ice_strength.argtypes = [ct.c_int] * 7 + [c_i32p] * 2 + [c_f64p] * 6 + [ct.POINTER(OrcParams)]
         _lib.orc_stress.argtypes = ([ct.c_int] * 5 + [c_i32p] * 2 + [c_f64p] * 13 +
                                     [ct.POINTER(c_f64p)] * 3 + [c_f64p] * 6 + [ct.POINTER(OrcParams)])
     return _lib
@@ -122,13 +129,20 @@ def make_geom(d):
 
 
 def make_params(dt: float, ndte: int, xmin: float, revised_evp: bool = False, cosw: float = 1.0, sinw: float = 0.0,
-                dragio: float = 0.00536, tilt_from_slope: bool = False, wind_on_ugrid: bool = False) -> OrcParams:
+                dragio: float = 0.00536, tilt_from_slope: bool = False, wind_on_ugrid: bool = False,
+                strength_mode: int = 0, kstrength: int = 1, krdg_partic: int = 1, krdg_redist: int = 1, ncat: int = 5,
+                mu_rdg: float = 3.0, Cf: float = 17.0) -> OrcParams:
+    """strength_mode = 1: evp computes the ice strength itself (ice_mechred.F90:2111) from aice, vice and, for
+    kstrength = 1, the thickness distribution aicen / vicen / aice0 in `f`; the namelist defaults are those of
+    ice_init.F90:273-277."""
     p = OrcParams()
     lib().orc_set_evp_parameters(dt, ndte, int(revised_evp), xmin, ct.byref(p))
     p.cosw, p.sinw, p.dragio = cosw, sinw, dragio
     p.rhow, p.rhoi, p.rhos, p.gravit = 1026.0, 917.0, 330.0, 9.80616
     p.a_min, p.m_min = 0.001, 0.01
     p.tilt_from_slope, p.wind_on_ugrid = int(tilt_from_slope), int(wind_on_ugrid)
+    p.strength_mode, p.kstrength, p.krdg_partic, p.krdg_redist, p.ncat = strength_mode, kstrength, krdg_partic, krdg_redist, ncat
+    p.mu_rdg, p.Cf = mu_rdg, Cf
     return p
 
 
@@ -136,6 +150,8 @@ def make_fields(f: Dict[str, np.ndarray]) -> OrcFields:
     o = OrcFields()
     for n in _F64_IN + _F64_IN2 + _F64_OUT + ["strength", "uvel", "vvel"]:
         setattr(o, n, _p64(f[n]))
+    for n in ("aicen", "vicen", "aice0"):
+        setattr(o, n, _p64(f[n]) if n in f else None)
     for n in _I32_IN + ["iceumask", "icetmask"]:
         setattr(o, n, _p32(f[n]))
     for k in ("stressp", "stressm", "stress12"):
@@ -187,3 +203,16 @@ def stress_block(nx, ny, ksub, ndte, indxti, indxtj, arrs: Dict[str, np.ndarray]
                  *[_p64(arrs[n]) for n in ("shear", "divu", "prs_sig", "rdg_conv", "rdg_shear")],
                  _p64(strv), ct.byref(params))
     return strv
+
+
+def exp(x: float) -> float:
+    """exp() as the restatement evaluates it (orc_exp)."""
+    return float(lib().orc_exp(float(x)))
+
+
+def ice_strength_block(nx, ny, ilo, ihi, jlo, jhi, indxi, indxj, aice, vice, aice0, aicen, vicen, params: OrcParams):
+    """orc_ice_strength on one (ny, nx) block (aicen, vicen: (ncat, ny, nx)); returns the strength plane."""
+    out = np.zeros((ny, nx))
+    lib().orc_ice_strength(nx, ny, ilo, ihi, jlo, jhi, len(indxi), _p32(indxi), _p32(indxj),
+                           _p64(aice), _p64(vice), _p64(aice0), _p64(aicen), _p64(vicen), _p64(out), ct.byref(params))
+    return out

@@ -24,7 +24,7 @@ OUT_F64 = ["uvel", "vvel"] + util.SIGMA + ["divu", "shear", "rdg_conv", "rdg_she
                                             "strtlty", "fm", "uvel_init", "vvel_init"]
 
 
-def write_fixture(path, d, f, p, ncalls):
+def write_fixture(path, d, f, p, ncalls, device_strength=None):
     ga = d.geom_arrays()
     with open(path, "wb") as fh:
         np.array([d.nx_global, d.ny_global, d.nx_block, d.ny_block, d.nblocks, d.ew_boundary, d.ns_boundary,
@@ -37,9 +37,15 @@ def write_fixture(path, d, f, p, ncalls):
             f[n].tofile(fh)
         for n in ("tmask", "umask", "iceumask"):
             f[n].astype(np.int32).tofile(fh)
+        if device_strength is not None:      # trailer: ice_strength on the device
+            sw = device_strength
+            np.array([1, f["aicen"].shape[1], sw.get("kstrength", 1), sw.get("krdg_partic", 1), sw.get("krdg_redist", 1), 0],
+                     dtype=np.int32).tofile(fh)
+            for n in ("aicen", "vicen", "aice0"):
+                f[n].tofile(fh)
 
 
-def read_output(path, d):
+def read_output(path, d, with_strength=False):
     shp = (d.nblocks, d.ny_block, d.nx_block)
     n = int(np.prod(shp))
     out = {}
@@ -47,6 +53,8 @@ def read_output(path, d):
         for name in OUT_F64:
             out[name] = np.fromfile(fh, dtype=np.float64, count=n).reshape(shp)
         out["iceumask"] = np.fromfile(fh, dtype=np.int32, count=n).reshape(shp)
+        if with_strength:
+            out["strength"] = np.fromfile(fh, dtype=np.float64, count=n).reshape(shp)
     return out
 
 
@@ -95,3 +103,28 @@ def test_fortran_host_matches_oracle(tmp_path, ns, bs, ncalls, driver):
     bad = util.compare(d, got, fo, names=list(got.keys()))
     assert not bad, bad[:6]
     assert np.abs(got["uvel"]).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sw", [dict(kstrength=1, krdg_partic=1, krdg_redist=1), dict(kstrength=1, krdg_partic=0, krdg_redist=0)])
+def test_fortran_host_with_ice_strength_on_the_device(tmp_path, sw):
+    """evpk_device_strength = .true.: the module hands aicen / vicen / aice0 and the ice_mechred switches over instead of
+    calling evp_prep1 + ice_HaloUpdate + ice_strength on the host; oracle: evp with strength_mode = 1."""
+    case, d, f = util.make_case(100, 116, 25, 29, land="continents")
+    synth.add_thickness_distribution(f)
+    f["strength"][...] = 0.0
+    xmin = synth.global_min_dx(case)
+    p = dyn.set_evp_parameters(3600.0, 60, False, xmin)
+    write_fixture(tmp_path / "in.bin", d, f, p, 2, device_strength=sw)
+    r = subprocess.run([DRIVER, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = read_output(tmp_path / "out.bin", d, with_strength=True)
+    fo = util.clone(f)
+    po = orc.make_params(3600.0, 60, xmin, strength_mode=1, **sw)
+    for _ in range(2):
+        orc.evp(d, po, fo)
+    names = [n for n in got if n != "strength"]
+    bad = util.compare(d, got, fo, names=names)
+    assert not bad, bad[:6]
+    m = util.cell_mask(d, "all")
+    assert np.array_equal(got["strength"][m], fo["strength"][m]) and fo["strength"].max() > 1e3

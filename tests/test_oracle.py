@@ -244,3 +244,71 @@ def test_principal_stress():
     r = np.sqrt(16.0 + 4.0 * 2.25)
     assert s1[1, 1] == (0.5 * (-3.0 + r)) / 2.0 and s2[1, 1] == (0.5 * (-3.0 - r)) / 2.0
     assert s1[0, 0] == 1.0e30 and s2[0, 0] == 1.0e30      # spval_dbl where prs_sig <= puny
+
+
+def test_exp_of_the_restatement_is_within_one_ulp_of_libm():
+    """orc_exp (Cody-Waite reduction + fdlibm's degree-5 minimax) replaces the Fortran intrinsic in ice_strength so that
+    the HIP kernel can agree with the oracle bit for bit; against libm it may differ in the last bit only."""
+    import math
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-25.0, 5.0, 20000), rng.uniform(-1.1, 1.1, 5000),
+                         [0.0, -0.0, -20.0, -1e-10, 1e-9, 0.34657359027997264, 1.0397207708399179, -0.6931471805599453]])
+    worst = max(abs(orc.exp(float(x)) - math.exp(float(x))) / np.spacing(math.exp(float(x))) for x in xs)
+    assert worst <= 1.0
+    assert orc.exp(0.0) == 1.0
+
+
+def _strength_cell(aice0, aicen, vicen, **kw):
+    ncat = len(aicen)
+    a3 = np.zeros((ncat, 3, 3)); v3 = np.zeros((ncat, 3, 3))
+    a3[:, 1, 1] = aicen; v3[:, 1, 1] = vicen
+    a0 = np.zeros((3, 3)); a0[1, 1] = aice0
+    aice = np.zeros((3, 3)); aice[1, 1] = sum(aicen)
+    vice = np.zeros((3, 3)); vice[1, 1] = sum(vicen)
+    p = orc.make_params(3600.0, 120, 1.0, strength_mode=1, ncat=ncat, **kw)
+    s = orc.ice_strength_block(3, 3, 2, 2, 2, 2, np.array([2], dtype=np.int32), np.array([2], dtype=np.int32),
+                               aice, vice, a0, a3, v3, p)
+    return s[1, 1], p
+
+
+def test_rothrock_strength_closed_forms():
+    """ice_strength, kstrength = 1 (ice_mechred.F90:2111-2269, ridge_itd :936-1285) against hand-derived cases."""
+    # (a) Thorndike participation: with more than Gstar = 15 % open water only open water closes -> no strength
+    s, _ = _strength_cell(0.3, [0.2, 0.5, 0.0, 0.0, 0.0], [0.1, 1.0, 0.0, 0.0, 0.0], krdg_partic=0, krdg_redist=0)
+    assert s == 0.0
+    # (b) one category covering the cell, Thorndike + Hibler (1980) redistribution: all ridging comes from it (apartic = 1)
+    h = 1.7
+    s, p = _strength_cell(0.0, [1.0], [h], krdg_partic=0, krdg_redist=0)
+    hrmin = min(2 * h, h + 1.0)
+    hrmax = max(2 * np.sqrt(25.0 * h), hrmin + 1e-11)
+    krdg = 0.5 * (hrmin + hrmax) / h
+    Cp = 0.5 * p.gravit * (p.rhow - p.rhoi) * p.rhoi / p.rhow
+    expect = p.Cf * Cp * (-h * h + (hrmax ** 3 - hrmin ** 3) / (3.0 * (hrmax - hrmin)) / krdg) / (1.0 - 1.0 / krdg)
+    assert np.isclose(s, expect, rtol=1e-13) and s > 1e4
+    # (c) the same ice with the exponential redistribution: <h^2> of an exponential tail above hrmin
+    s, p = _strength_cell(0.0, [1.0], [h], krdg_partic=0, krdg_redist=1)
+    hrexp = p.mu_rdg * np.sqrt(h)
+    krdg = (hrmin + hrexp) / h
+    expect = p.Cf * Cp * (-h * h + (hrmin ** 2 + 2 * hrmin * hrexp + 2 * hrexp ** 2) / krdg) / (1.0 - 1.0 / krdg)
+    assert np.isclose(s, expect, rtol=1e-13)
+    # (d) exponential participation: the weights sum to one whatever the distribution (telescoping sum)
+    s1, _ = _strength_cell(0.1, [0.3, 0.3, 0.3], [0.2, 0.6, 1.5], krdg_partic=1, krdg_redist=1)
+    assert np.isfinite(s1) and s1 > 0.0
+    # Hibler (1979), kstrength = 0
+    sH, _ = _strength_cell(0.2, [0.8], [1.2], kstrength=0)
+    assert np.isclose(sH, 2.75e4 * 1.2 * np.exp(-20.0 * 0.2), rtol=1e-15)
+
+
+def test_strength_inside_evp_is_decomposition_invariant():
+    from cice5_amd import synth
+    outs = []
+    for bs in ((48, 40), (12, 10)):
+        case, d, f = util.make_case(48, 40, *bs, land="continents")
+        synth.add_thickness_distribution(f)
+        f["strength"][...] = -1.0                       # must be overwritten
+        p = orc.make_params(3600.0, 10, synth.global_min_dx(case), strength_mode=1)
+        orc.evp(d, p, f)
+        outs.append({n: blocks.gather_global(d, f[n]) for n in ("strength", "uvel", "stressp_1")})
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+    assert outs[0]["strength"].max() > 1e4 and outs[0]["strength"].min() == 0.0

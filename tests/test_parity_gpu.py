@@ -140,6 +140,40 @@ def test_strip_rows_do_not_matter():
         assert not util.compare(d, g, out[0])
 
 
+@pytest.mark.parametrize("sw", [dict(kstrength=1, krdg_partic=1, krdg_redist=1), dict(kstrength=1, krdg_partic=0, krdg_redist=0),
+                                dict(kstrength=1, krdg_partic=0, krdg_redist=1), dict(kstrength=1, krdg_partic=1, krdg_redist=0),
+                                dict(kstrength=0)])
+def test_ice_strength_on_the_device(sw):
+    """evpk_step_in.strength == NULL: ice_strength (ice_mechred.F90:2111-2269, Rothrock with both participation and both
+    redistribution functions, or Hibler) runs on the device where the reference calls it; bit-identical to the oracle doing
+    the same (both use the same fixed exp algorithm), strength included, on all cells (it is halo-updated, :311)."""
+    for (nx, ny, bsx, bsy, ns) in ((100, 116, 25, 29, "open"), (96, 64, 96, 64, "tripole")):
+        case, d, f = util.make_case(nx, ny, bsx, bsy, ns=ns, land="continents")
+        synth.add_thickness_distribution(f)
+        f["strength"][...] = -7.0                      # not an input any more
+        xmin = synth.global_min_dx(case)
+        fo, fg = util.clone(f), util.clone(f)
+        p = orc.make_params(3600.0, 24, xmin, strength_mode=1, **sw)
+        solver = dyn.EvpDynamics(d, fg, ndte=24, xmin=xmin, device_strength=dict(sw))
+        solver.init_evp(3600.0)
+        for call in range(2):
+            if call:
+                for ff in (fo, fg):
+                    ff["aice"] *= 0.9
+                    ff["vice"] *= 0.9
+                    ff["aicen"] *= 0.9
+                    ff["vicen"] *= 0.9
+                    ff["aice0"][...] = np.maximum(1.0 - ff["aice"], 0.0)
+            orc.evp(d, p, fo)
+            solver.evp(3600.0)
+            bad = util.compare(d, fg, fo)
+            m = util.cell_mask(d, "all")
+            assert np.array_equal(fg["strength"][m], fo["strength"][m]), (sw, ns, call)
+            assert not bad, (sw, ns, call, bad[:6])
+        assert fo["strength"].max() > 1e3 and np.abs(fo["uvel"]).max() > 1e-3
+        solver.close()
+
+
 @pytest.mark.parametrize("ns", ["open", "tripole"])
 def test_page_locked_host_arrays(ns):
     """evpk_pin_host: the gather / scatter kernels read and write the caller's arrays in place over PCIe; a download
