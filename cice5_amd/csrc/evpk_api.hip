@@ -768,15 +768,16 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     {   // two subcycles per launch: single rank, no tripole fold between the subcycles (EVPK_DOUBLE=0 disables)
         const char *e = getenv("EVPK_DOUBLE");
-        c->use_double = !(e && atoi(e) == 0) && s.nxl >= 4;
+        // (the choice must be the same on every rank: it decides which exchanges the ranks post)
+        int minw = s.nxl;
+        for (int r = 0; r < g->nranks; r++) minw = std::min(minw, c->slab_i0[r + 1] - c->slab_i0[r]);
+        c->use_double = !(e && atoi(e) == 0) && minw >= 4;
         if (g->ns_boundary == EVPK_BND_TRIPOLE) {
             // the fold mixes mirrored columns between the two fused subcycles: only the rows next to the fold are affected,
             // they are redone by band launches (x-slabs: without the edge/interior overlap, the fold all-gathers in between)
             c->band_mode = c->use_double = c->use_double && s.nyl >= 8;
         }
         // ghost-zone depth: zM launches per exchange, zones of 2*zM columns; every slab must be able to supply them
-        int minw = s.nxl;
-        for (int r = 0; r < g->nranks; r++) minw = std::min(minw, c->slab_i0[r + 1] - c->slab_i0[r]);
         const char *zm = getenv("EVPK_ZONE_M");
         int m = zm ? atoi(zm) : ZW_MAX / 2;
         m = std::max(1, std::min(m, std::min(ZW_MAX / 2, minw / 2)));
