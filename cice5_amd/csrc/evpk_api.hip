@@ -388,8 +388,9 @@ static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes) {
 // fsrc_fold >= 0: ice_HaloUpdate_stress variant (only the tripole north ghost row of the
 // destination planes is written, from the top physical row of the source planes).
 // skip_ew: the caller refreshes the E-W ghost columns itself right after (exchange_cols carries them, all rows)
+// fprev: see k_fold_pack (velocity updates inside the subcycle loop: the state buffer the kernel read)
 static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t one_launch_stream = nullptr,
-                bool skip_ew = false) {
+                bool skip_ew = false, int fprev = -1) {
     Slab &s = c->s;
     const int tx = 128;
     const int gcol = (s.nxl + 2 + tx - 1) / tx, grow = (s.nyl + 2 + tx - 1) / tx;
@@ -400,7 +401,7 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         // single rank: the whole update of an NE-corner field in one launch
         const int n = std::max(std::max(s.nxg / 2 + 1, s.nxl + 2), s.nyl);
         hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, one_launch_stream ? one_launch_stream : c->stream,
-                           s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0);
+                           s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0, fprev);
         HIPCHK(c, hipGetLastError());
         return 0;
     }
@@ -409,12 +410,12 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         if (!stress_mode) hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 0);
         const int fp = stress_mode ? fsrc_fold : f;
         if (c->nranks == 1 && !c->force_exchange) {
-            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, s, fp, nf, c->foldbuf, s.i0 - 1);
+            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, s, fp, nf, c->foldbuf, s.i0 - 1, fprev);
         } else {
             // pack own segment [nf][2][wmax], all-gather, re-pack into [nf][2][nxg]
             HIPCHK(c, hipMemsetAsync(c->foldloc, 0, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax, c->stream));
             Slab t = s; t.nxg = c->wmax;   // local segment addressed with gofs = 0
-            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, fp, nf, c->foldloc, 0);
+            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, fp, nf, c->foldloc, 0, fprev);
             const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
             if (c->nranks > 1) {
                 if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
@@ -1159,7 +1160,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                     HIPCHK(c, hipEventRecord(c->evB0, c->stream));          // the previous pair is complete
                     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evB0, 0));
                     launch_band(b1, c->stream2);
-                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, c->stream2)) return 1;
+                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, c->stream2, false, a.sr + S_U)) return 1;
                     HIPCHK(c, hipEventRecord(c->evB1, c->stream2));
                 }
             }
@@ -1205,12 +1206,12 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
             if (c->band_mode) {
                 if (!band_ahead) {
                     launch_band(b1, c->stream);
-                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0)) return 1;
+                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, nullptr, false, a.sr + S_U)) return 1;
                 } else
                     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
                 launch_band(b2, c->stream);
                 // (x-slabs: the ghost-zone exchange below delivers the E-W ghost columns of the new state, all rows)
-                if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, nullptr, c->zone_mode)) return 1;
+                if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, nullptr, c->zone_mode, F_STATE2 + S_U)) return 1;
             }
             c->ksub += 2;
             n += 2;
@@ -1245,7 +1246,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         evE_valid = false;
         c->cur ^= 1;
         if (need_halo) {                                                          // ice_dyn_evp.F90:392-400
-            if (halo(c, (c->cur ? F_STATE1 : F_STATE0) + S_U, 2, true, true, 0.0)) return 1;
+            if (halo(c, (c->cur ? F_STATE1 : F_STATE0) + S_U, 2, true, true, 0.0, -1, nullptr, false, a.sr + S_U)) return 1;
         }
         if (c->zone_mode) { c->zone_left = 0; c->inner_ok = true; }     // one ghost column is current, the deeper zone is not
     }

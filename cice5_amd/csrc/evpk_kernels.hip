@@ -481,12 +481,17 @@ __global__ void k_halo_ns_fill(Slab s, int f, int nf, double fill, int north_too
 }
 
 // fold buffer layout: fb[(q*2 + r)*nxg + (g-1)], r = 0: row ny-1, r = 1: row ny; g global column
-__global__ void k_fold_pack(Slab s, int f, int nf, double *fb, int gofs /* global col of local col 1, minus 1 */) {
+// fprev >= 0 (velocity in the subcycle loop): the planes f were written from the planes fprev by a kernel that leaves
+// inactive U cells alone.  The reference keeps ONE array, in which the fold rewrites the whole top row after every
+// subcycle -- also an inactive cell whose mirror image is active -- so the value such a cell carries into this update
+// is the one the previous update left in fprev.
+__global__ void k_fold_pack(Slab s, int f, int nf, double *fb, int gofs /* global col of local col 1, minus 1 */, int fprev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (i > s.nxl) return;
+    const bool stale = fprev >= 0 && !(s.cmask[mcell(s, i, s.nyl)] & CM_U);
     for (int q = 0; q < nf; q++) {
         fb[((size_t)q * 2 + 0) * s.nxg + (gofs + i - 1)] = FD(s, f + q, cell(s, i, s.nyl - 1));
-        fb[((size_t)q * 2 + 1) * s.nxg + (gofs + i - 1)] = FD(s, f + q, cell(s, i, s.nyl));
+        fb[((size_t)q * 2 + 1) * s.nxg + (gofs + i - 1)] = FD(s, (stale ? fprev : f) + q, cell(s, i, s.nyl));
     }
 }
 
@@ -532,7 +537,7 @@ __global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int nec
 // pair and no staging buffer is needed; every other value read lies in a cell this kernel does not write.
 //   blockIdx.y == 0: fold (thread k: columns k and nx-k; k = 0 stands for column nx), rows nyl and nyl+1
 //   blockIdx.y == 1: rows 0 .. nyl-1: south fill and the two ghost columns
-__global__ void k_halo_tripole_ne1(Slab s, int f, int nf, int cyclic, double fill, double sgn) {
+__global__ void k_halo_tripole_ne1(Slab s, int f, int nf, int cyclic, double fill, double sgn, int fprev /* see k_fold_pack */) {
     const int nx = s.nxg, h = nx / 2, nyl = s.nyl;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.y == 1) {
@@ -554,14 +559,18 @@ __global__ void k_halo_tripole_ne1(Slab s, int f, int nf, int cyclic, double fil
         if (g == nx) { FD(s, f + q, cell(s, 0, nyl)) = cyclic ? top : fill; FD(s, f + q, cell(s, 0, nyl + 1)) = cyclic ? ghost : fill; }
         if (g == 1) { FD(s, f + q, cell(s, nx + 1, nyl)) = cyclic ? top : fill; FD(s, f + q, cell(s, nx + 1, nyl + 1)) = cyclic ? ghost : fill; }
     };
+    auto top = [&](int q, int g) {       // old top-row value of column g: an inactive cell carries the previous update's
+        const bool stale = fprev >= 0 && !(s.cmask[mcell(s, g, nyl)] & CM_U);
+        return FD(s, (stale ? fprev : f) + q, cell(s, g, nyl));
+    };
     for (int q = 0; q < nf; q++) {
         if (t == 0 || t == h) {
             const int g = t == 0 ? nx : h;                  // src == g: the value itself
-            const double T = FD(s, f + q, cell(s, g, nyl)), R = FD(s, f + q, cell(s, g, nyl - 1));
+            const double T = top(q, g), R = FD(s, f + q, cell(s, g, nyl - 1));
             put(q, g, sgn * T, sgn * R);
         } else {
             const int ga = t, gb = nx - t;                   // ga in 1..h-1, gb in h+1..nx-1
-            const double Ta = FD(s, f + q, cell(s, ga, nyl)), Tb = FD(s, f + q, cell(s, gb, nyl));
+            const double Ta = top(q, ga), Tb = top(q, gb);
             const double Ra = FD(s, f + q, cell(s, ga, nyl - 1)), Rb = FD(s, f + q, cell(s, gb, nyl - 1));
             // column ga: src = gb >= h+1:  v = sgn*(0.5*(B2[nx-src] + sgn*B2[src]));  column gb: src = ga:  v = 0.5*(B2[src] + sgn*B2[nx-src])
             const double va = sgn * (0.5 * (Ta + sgn * Tb));

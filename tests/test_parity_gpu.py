@@ -291,6 +291,97 @@ def test_device_resident_steps_inputs_only_upload(mode, monkeypatch):
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["plain", "exchange", "tripole", "device-strength"])
+def test_soak_twelve_steps_with_wandering_ice(mode, monkeypatch):
+    """Twelve consecutive evp() calls with the state resident on the device while the ice cover wanders: patches melt
+    away completely, reappear elsewhere, thin out below the a_min / m_min thresholds and thicken again.  Every prep takes
+    a different mix of skipped / re-zeroed / newly active tiles, strip lists and (exchange mode) ghost-zone row lists;
+    after every call the download must equal the oracle run with the same inputs, bit for bit."""
+    if mode == "exchange":
+        monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+    ns = "tripole" if mode == "tripole" else "open"
+    case, d, f = util.make_case(260, 140, 65, 35, ns=ns, land="continents")
+    dev_strength = dict(kstrength=1, krdg_partic=1, krdg_redist=1) if mode == "device-strength" else None
+    xmin = synth.global_min_dx(case)
+    base = util.clone(f)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, 16, xmin, **(dict(strength_mode=1, **dev_strength) if dev_strength else {}))
+    s = dyn.EvpDynamics(d, fg, ndte=16, xmin=xmin, device_strength=dev_strength)
+    s.init_evp(3600.0)
+    ctx = s.ctx
+    I, J = blocks.block_index_windows(d)
+    # ghost cells must hold what a halo update would put there (ice_dyn_evp.F90:157-169): wrap E-W, and on the tripole grid
+    # the north ghost row is the mirror image of the top row, T cell (i, ny+1) = (nx-i+1, ny)  (serial/ice_boundary.F90:801-888)
+    nxg, nyg = d.nx_global, d.ny_global
+    I = (I - 1) % nxg + 1
+    if ns == "tripole":
+        top = J > nyg
+        I = [np.broadcast_to(I[n][None, :], (d.ny_block, d.nx_block)).copy() for n in range(d.nblocks)]
+        for n in range(d.nblocks):
+            I[n][top[n], :] = nxg - I[n][top[n], :] + 1
+        J = np.minimum(J, nyg)
+    else:
+        I = [np.broadcast_to(I[n][None, :], (d.ny_block, d.nx_block)) for n in range(d.nblocks)]
+    rng = np.random.default_rng(2026)
+    for call in range(12):
+        # a smooth, moving mask in global coordinates (identical in ghost cells): ice survives where it is positive
+        kx, ky, ph = rng.uniform(0.02, 0.09), rng.uniform(0.03, 0.12), rng.uniform(0, 6.28)
+        thin = rng.uniform(0.0, 1.0)
+        for ff in (fo, fg):
+            for n in range(d.nblocks):
+                w = np.sin(kx * I[n] + ph) * np.cos(ky * J[n][:, None] - 0.5 * ph) + 0.35 * np.sin(0.7 * call)
+                keep = np.where(w > 0.0, 1.0, 0.0) * np.where(w > 0.6, 1.0, thin * 0.01 + 0.001)   # some cells just above / below a_min
+                for name in ("aice", "vice", "vsno", "aice_init"):
+                    ff[name][n] = base[name][n] * keep
+                ff["strength"][n] = base["strength"][n] * keep
+                ff["strairxT"][n] = base["strairxT"][n] * np.cos(0.5 * call) - base["strairyT"][n] * np.sin(0.5 * call)
+                ff["strairyT"][n] = base["strairyT"][n] * np.cos(0.5 * call) + base["strairxT"][n] * np.sin(0.5 * call)
+            if dev_strength:
+                synth.add_thickness_distribution(ff)
+        nt, nu, _ = orc.evp(d, p, fo)
+        if call == 0:
+            ctx.upload(fg)
+        else:
+            ctx.upload_inputs(fg)
+        ctx.prep(); ctx.subcycle(16); ctx.finish()
+        st = ctx.stats()
+        assert (st.icellt, st.icellu) == (nt, nu), call
+        out = util.clone(fg)
+        ctx.download(out)
+        bad = util.compare(d, out, fo)
+        assert not bad, f"call {call}: {bad[:6]}"
+    s.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"EVPK_DOUBLE": "0"}, {"EVPK_FORCE_EXCHANGE": "1"}])
+def test_tripole_fold_rewrites_inactive_top_row_cells(env, monkeypatch):
+    """The tripole halo update rewrites the WHOLE top row of u, v after every subcycle (serial/ice_boundary.F90:801-888),
+    also a U cell without ice whose mirror image across the fold has ice; the reference keeps one velocity array, so
+    that cell carries the value into the next update.  Here the ice mask is deliberately NOT mirror-symmetric across the
+    fold (ghost cells inconsistent with their images), which makes such cells common: the double-buffered kernels must
+    still reproduce the single-array behaviour bit for bit, for 1, 2, 3 and 16 subcycles."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case, d, f = util.make_case(260, 140, 65, 35, ns="tripole", land="continents")
+    xmin = synth.global_min_dx(case)
+    I, J = blocks.block_index_windows(d)
+    for n in range(d.nblocks):
+        w = np.sin(0.05 * I[n][None, :] + 1.0) * np.cos(0.07 * J[n][:, None] - 0.5)
+        keep = np.where(w > 0.0, 1.0, 0.0) * np.where(w > 0.6, 1.0, 0.004)
+        for name in ("aice", "vice", "vsno", "aice_init", "strength"):
+            f[name][n] = f[name][n] * keep
+    for ndte in (1, 2, 3, 16):
+        fo, fg = util.clone(f), util.clone(f)
+        p = orc.make_params(3600.0, ndte, xmin)
+        s = dyn.EvpDynamics(d, fg, ndte=ndte, xmin=xmin)
+        s.init_evp(3600.0)
+        orc.evp(d, p, fo)
+        s.evp(3600.0)
+        s.close()
+        bad = util.compare(d, fg, fo)
+        assert not bad, (ndte, bad[:4])
+
+
 @pytest.mark.parametrize("mode", ["given", "absent", "inconsistent", "disabled"])
 def test_compact_metrics_from_htn_hte(mode, monkeypatch):
     """HTN/HTE are optional: when they reproduce the eight metric planes bit for bit the kernel reads them instead
