@@ -574,6 +574,12 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         if (d.ilo < 2 || d.ihi > g->nx_block - 1 || d.ihi < d.ilo || d.jlo < 2 || d.jhi > g->ny_block - 1 || d.jhi < d.jlo)
             FAIL(c, "block %d: bad ilo/ihi/jlo/jhi", b);
         if (d.iglob_lo < 1 || d.jglob_lo < 1) FAIL(c, "block %d: bad global origin", b);
+        // The fold rewrites the top physical row; the reference fills the ghost row of the block BELOW from its value before
+        // that (regular copies first, tripole buffer second, ice_boundary.F90), so with a one-row top block the results
+        // of the reference depend on the decomposition.  Not reproduced here.
+        if (g->ns_boundary == EVPK_BND_TRIPOLE && d.jglob_lo + (d.jhi - d.jlo) == g->ny_global && d.jhi == d.jlo && g->ny_global > 1 &&
+            d.jglob_lo > 1)
+            FAIL(c, "tripole: the top row of blocks must hold at least two physical rows (block %d has one)", b);
         c->bd[b] = d;
         i0 = std::min(i0, d.iglob_lo); i1 = std::max(i1, d.iglob_lo + d.ihi - d.ilo);
         j0 = std::min(j0, d.jglob_lo); j1 = std::max(j1, d.jglob_lo + d.jhi - d.jlo);

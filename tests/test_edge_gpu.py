@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from cice5_amd import blocks, constants as C, dyn, synth
+from cice5_amd import blocks, constants as C, dyn, evpk, synth
 from oracle import orc
 from tests import util
 
@@ -104,3 +104,14 @@ def test_closed_boundaries():
     d = blocks.create_distrb_cart(70, 40, 35, 20, ew_boundary_type="closed", ns_boundary_type="closed")
     f = synth.make_block_fields(case, d)
     _check(case, d, f, ndte=15, ncalls=2)
+
+
+def test_tripole_top_block_of_one_row_is_rejected():
+    """With a one-row top block the reference's halo leaves the ghost copy of the (fold-symmetrised) top row stale in the
+    block below, so its own results depend on the decomposition (the oracle reproduces that: 1 block != 20x11 blocks on a
+    122x23 grid).  The library refuses the layout instead of silently answering for a different decomposition."""
+    case, d, f = util.make_case(122, 23, 20, 11, ns="tripole", land="rows", ice="full")
+    with pytest.raises(evpk.EvpkError, match="at least two physical rows"):
+        dyn.EvpDynamics(d, f, ndte=2)
+    case, d, f = util.make_case(122, 23, 20, 12, ns="tripole", land="rows", ice="full")
+    dyn.EvpDynamics(d, f, ndte=2).close()

@@ -1,0 +1,86 @@
+"""Seeded random configurations of the single-rank path against the oracle, bit for bit: grid and block shapes (blocks that
+do not divide the grid, i.e. padded edge blocks), boundary types, ndte parity, classic / revised EVP, ocean turning angle,
+ice cover (polar / full / wandering patches / isolated cells), library modes.  Cheap cases, many of them: the point is
+the corners nobody thought of writing a test for."""
+import os
+
+import numpy as np
+import pytest
+
+from cice5_amd import blocks, constants as C, dyn, synth
+from oracle import orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH": "0"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_ZONE_M": "2"},
+         {"EVPK_COMPACT_METRICS": "0"}, {"EVPK_STRIP_ROWS": "3"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_OVERLAP": "0"}]
+
+
+def _config(seed):
+    rng = np.random.default_rng(1000 + seed)
+    nx = int(rng.choice([8, 24, 61, 62, 64, 96, 122, 123, 130, 200]))
+    ny = int(rng.choice([10, 12, 23, 40, 57, 64]))
+    ns = str(rng.choice(["open", "open", "tripole", "closed"]))
+    ew = str(rng.choice(["cyclic", "cyclic", "open", "closed"]))
+    if ns == "tripole":
+        ew = "cyclic"
+        nx += nx & 1                                   # the fold needs an even nx_global
+    bsx = int(rng.choice([nx, max(3, nx // 2), max(3, nx // 3 + 1), 7, 20]))
+    bsy = int(rng.choice([ny, max(3, ny // 2), max(3, ny // 3 + 1), 5]))
+    bsx, bsy = min(bsx, nx), min(bsy, ny)
+    if ns == "tripole" and ny % bsy == 1 and bsy < ny:
+        bsy += 1           # a one-row top block is rejected (the reference's own result then depends on the decomposition)
+    return dict(nx=nx, ny=ny, bsx=bsx, bsy=bsy, ns=ns, ew=ew, ndte=int(rng.choice([1, 2, 5, 8, 13, 20])),
+                revised=bool(rng.random() < 0.3), turn=bool(rng.random() < 0.3), ice=str(rng.choice(["polar", "full", "patches", "dots"])),
+                land=str(rng.choice(["rows", "continents"])), mode=MODES[int(rng.integers(len(MODES)))], ncalls=int(rng.choice([1, 2, 3])), rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_N", "40"))))
+def test_random_configuration(seed, monkeypatch):
+    k = _config(seed)
+    for name, v in k["mode"].items():
+        monkeypatch.setenv(name, v)
+    case = synth.SynthCase(nx=k["nx"], ny=k["ny"], ns_boundary=C.BND_NAMES[k["ns"]], ew_boundary=C.BND_NAMES[k["ew"]],
+                           land=k["land"], ice="full" if k["ice"] != "polar" else "polar")
+    d = blocks.create_distrb_cart(k["nx"], k["ny"], k["bsx"], k["bsy"], ew_boundary_type=k["ew"], ns_boundary_type=k["ns"])
+    f = synth.make_block_fields(case, d)
+    base = util.clone(f)
+    xmin = synth.global_min_dx(case)
+    cosw, sinw = (np.cos(0.4), np.sin(0.4)) if k["turn"] else (1.0, 0.0)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, k["ndte"], xmin, revised_evp=k["revised"], cosw=cosw, sinw=sinw)
+    s = dyn.EvpDynamics(d, fg, ndte=k["ndte"], revised_evp=k["revised"], xmin=xmin, cosw=cosw, sinw=sinw)
+    s.init_evp(3600.0)
+    I, J = blocks.block_index_windows(d)
+    nxg, nyg = d.nx_global, d.ny_global
+    rng = k["rng"]
+    for call in range(k["ncalls"]):
+        if k["ice"] in ("patches", "dots"):
+            kx, ky, ph = rng.uniform(0.05, 0.5), rng.uniform(0.05, 0.5), rng.uniform(0, 6.28)
+            for ff in (fo, fg):
+                for n in range(d.nblocks):
+                    Ig = np.broadcast_to(I[n][None, :], (d.ny_block, d.nx_block)).copy()
+                    Jg = np.broadcast_to(J[n][:, None], (d.ny_block, d.nx_block)).copy()
+                    if k["ew"] == "cyclic":
+                        Ig = (Ig - 1) % nxg + 1
+                    if k["ns"] == "tripole":
+                        top = Jg > nyg
+                        Ig[top] = nxg - Ig[top] + 1
+                        Jg = np.minimum(Jg, nyg)
+                    w = np.sin(kx * Ig + ph) * np.cos(ky * Jg - ph)
+                    keep = (w > (0.97 if k["ice"] == "dots" else 0.2)).astype(np.float64)
+                    for name in ("aice", "vice", "vsno", "aice_init", "strength"):
+                        ff[name][n] = base[name][n] * keep
+        elif call:
+            for ff in (fo, fg):
+                ff["aice"] *= 0.9
+                ff["vice"] *= 0.9
+        nt, nu, _ = orc.evp(d, p, fo)
+        s.evp(3600.0)
+        st = s.ctx.stats()
+        desc = {a: b for a, b in k.items() if a != "rng"}
+        assert (st.icellt, st.icellu) == (nt, nu), (desc, call)
+        bad = util.compare(d, fg, fo)
+        assert not bad, (desc, call, bad[:4])
+    s.close()

@@ -16,6 +16,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _wander(d, base, ff, call, ns):
+    """Inputs of call `call`: the ice cover of `base` under a moving smooth mask of the global cell index (so every
+    decomposition and every ghost cell sees the same field; ghost cells wrap E-W and mirror across a tripole fold)."""
+    from cice5_amd import blocks
+    I, J = blocks.block_index_windows(d)
+    nxg, nyg = d.nx_global, d.ny_global
+    rng = np.random.default_rng(77 + call)
+    kx, ky, ph, thin = rng.uniform(0.02, 0.09), rng.uniform(0.03, 0.12), rng.uniform(0, 6.28), rng.uniform(0.0, 1.0)
+    for n in range(d.nblocks):
+        Ig = np.broadcast_to(((I[n] - 1) % nxg + 1)[None, :], (d.ny_block, d.nx_block)).copy()
+        Jg = np.broadcast_to(J[n][:, None], (d.ny_block, d.nx_block)).copy()
+        if ns == "tripole":
+            top = Jg > nyg
+            Ig[top] = nxg - Ig[top] + 1
+            Jg = np.minimum(Jg, nyg)
+        w = np.sin(kx * Ig + ph) * np.cos(ky * Jg - 0.5 * ph) + 0.35 * np.sin(0.7 * call)
+        keep = np.where(w > 0.0, 1.0, 0.0) * np.where(w > 0.6, 1.0, thin * 0.01 + 0.001)
+        for name in ("aice", "vice", "vsno", "aice_init", "strength"):
+            ff[name][n] = base[name][n] * keep
+        ff["strairxT"][n] = base["strairxT"][n] * np.cos(0.5 * call) - base["strairyT"][n] * np.sin(0.5 * call)
+        ff["strairyT"][n] = base["strairyT"][n] * np.cos(0.5 * call) + base["strairxT"][n] * np.sin(0.5 * call)
+
+
 def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
     try:
         import time
@@ -39,8 +62,13 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
         f1 = synth.make_block_fields(case, d1)
         p = orc.make_params(3600.0, ndte, xmin)
         bad = []
-        for call in range(2):
-            if call:
+        ncalls = int(env.get("TEST_WANDER_CALLS", "0"))
+        base, base1 = util.clone(f), util.clone(f1)
+        for call in range(ncalls or 2):
+            if ncalls:
+                _wander(d, base, f, call, ns)
+                _wander(d1, base1, f1, call, ns)
+            elif call:
                 for ff in (f, f1):
                     ff["aice"] *= 0.97
                     ff["vice"] *= 0.97
@@ -113,6 +141,14 @@ def test_narrow_slabs_limit_the_zone_depth():
     """Slabs of 6 columns can only feed zones of 6 (m = 3); slabs of 4 columns zones of 4."""
     assert all(r[6] == 6 for r in _run(4, "open", 24, 40, 6, 20, ndte=22))
     assert all(r[6] == 4 for r in _run(4, "open", 16, 40, 4, 20, ndte=22))
+
+
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_soak_wandering_ice_across_slabs(ns):
+    """Eight consecutive evp() calls on three x-slabs while the ice cover wanders across the slab boundaries (and, on the
+    tripole grid, across the fold): the ghost-zone row lists, strip lists and tile flags change every call."""
+    res = _run(3, ns, 240, 72, 20, 36, ndte=14, env={"TEST_WANDER_CALLS": "8"})
+    assert all(r[3] > 0 for r in res)
 
 
 def test_cfg4_1440x1080_on_four_ranks():
