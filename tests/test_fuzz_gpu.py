@@ -33,7 +33,10 @@ def _config(seed):
         bsy += 1           # a one-row top block is rejected (the reference's own result then depends on the decomposition)
     return dict(nx=nx, ny=ny, bsx=bsx, bsy=bsy, ns=ns, ew=ew, ndte=int(rng.choice([1, 2, 5, 8, 13, 20])),
                 revised=bool(rng.random() < 0.3), turn=bool(rng.random() < 0.3), ice=str(rng.choice(["polar", "full", "patches", "dots"])),
-                land=str(rng.choice(["rows", "continents"])), mode=MODES[int(rng.integers(len(MODES)))], ncalls=int(rng.choice([1, 2, 3])), rng=rng)
+                land=str(rng.choice(["rows", "continents"])), mode=MODES[int(rng.integers(len(MODES)))], ncalls=int(rng.choice([1, 2, 3])),
+                resident=bool(rng.random() < 0.5), pin=bool(rng.random() < 0.2),
+                strength=(None if rng.random() < 0.6 else dict(kstrength=int(rng.integers(0, 2)), krdg_partic=int(rng.integers(0, 2)),
+                                                                 krdg_redist=int(rng.integers(0, 2)))), rng=rng)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_N", "40"))))
@@ -49,8 +52,10 @@ def test_random_configuration(seed, monkeypatch):
     xmin = synth.global_min_dx(case)
     cosw, sinw = (np.cos(0.4), np.sin(0.4)) if k["turn"] else (1.0, 0.0)
     fo, fg = util.clone(f), util.clone(f)
-    p = orc.make_params(3600.0, k["ndte"], xmin, revised_evp=k["revised"], cosw=cosw, sinw=sinw)
-    s = dyn.EvpDynamics(d, fg, ndte=k["ndte"], revised_evp=k["revised"], xmin=xmin, cosw=cosw, sinw=sinw)
+    skw = dict(strength_mode=1, **k["strength"]) if k["strength"] else {}
+    p = orc.make_params(3600.0, k["ndte"], xmin, revised_evp=k["revised"], cosw=cosw, sinw=sinw, **skw)
+    s = dyn.EvpDynamics(d, fg, ndte=k["ndte"], revised_evp=k["revised"], xmin=xmin, cosw=cosw, sinw=sinw,
+                        device_strength=k["strength"], pin_host=k["pin"])
     s.init_evp(3600.0)
     I, J = blocks.block_index_windows(d)
     nxg, nyg = d.nx_global, d.ny_global
@@ -76,8 +81,15 @@ def test_random_configuration(seed, monkeypatch):
             for ff in (fo, fg):
                 ff["aice"] *= 0.9
                 ff["vice"] *= 0.9
+        if k["strength"]:
+            for ff in (fo, fg):
+                synth.add_thickness_distribution(ff)
         nt, nu, _ = orc.evp(d, p, fo)
-        s.evp(3600.0)
+        if k["resident"] and call:             # the state stays on the device: inputs only, then the staged calls
+            s.ctx.upload_inputs(fg)
+            s.ctx.prep(); s.ctx.subcycle(k["ndte"]); s.ctx.finish(); s.ctx.download(fg)
+        else:
+            s.evp(3600.0)
         st = s.ctx.stats()
         desc = {a: b for a, b in k.items() if a != "rng"}
         assert (st.icellt, st.icellu) == (nt, nu), (desc, call)

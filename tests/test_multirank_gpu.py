@@ -171,3 +171,29 @@ def test_x_slabs_one_subcycle_kernel_and_serial_exchange():
     _run(3, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"})
     _run(2, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_OVERLAP": "0"})
     _run(2, "tripole", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"})
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_MR_N", "8"))))
+def test_random_multirank_configuration(seed):
+    """Seeded random x-slab runs through the relay: 2-4 ranks, slab widths from 4 columns up, several blocks per slab,
+    open / tripole, ghost-zone depth, overlap on / off, one- or two-subcycle kernel, odd / even ndte, wandering ice."""
+    rng = np.random.default_rng(500 + seed)
+    world = int(rng.choice([2, 3, 4]))
+    bsx = int(rng.choice([4, 6, 10, 20, 31]))
+    nx = world * int(rng.choice([1, 2, 3])) * bsx
+    ns = str(rng.choice(["open", "tripole"]))
+    if ns == "tripole" and nx % 2:
+        bsx += 1
+        nx = world * (nx // (bsx - 1) // world) * bsx
+    ny = int(rng.choice([24, 40, 64]))
+    bsy = int(rng.choice([ny, ny // 2]))
+    env = {"EVPK_ZONE_M": str(int(rng.integers(1, 5)))}
+    if rng.random() < 0.3:
+        env["EVPK_OVERLAP"] = "0"
+    if rng.random() < 0.2:
+        env["EVPK_DOUBLE"] = "0"
+    if rng.random() < 0.5:
+        env["TEST_WANDER_CALLS"] = "3"
+    ndte = int(rng.choice([5, 8, 13]))
+    print("config:", world, ns, nx, ny, bsx, bsy, ndte, env)
+    _run(world, ns, nx, ny, bsx, bsy, ndte=ndte, env=env)
