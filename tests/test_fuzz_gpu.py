@@ -19,8 +19,8 @@ MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH
 
 def _config(seed):
     rng = np.random.default_rng(1000 + seed)
-    nx = int(rng.choice([8, 24, 61, 62, 64, 96, 122, 123, 130, 200]))
-    ny = int(rng.choice([10, 12, 23, 40, 57, 64]))
+    nx = int(rng.choice([8, 24, 61, 62, 64, 96, 122, 123, 130, 200, 371, 733]))
+    ny = int(rng.choice([10, 12, 23, 40, 57, 64, 131, 257]))
     ns = str(rng.choice(["open", "open", "tripole", "closed"]))
     ew = str(rng.choice(["cyclic", "cyclic", "open", "closed"]))
     if ns == "tripole":
@@ -35,6 +35,7 @@ def _config(seed):
                 revised=bool(rng.random() < 0.3), turn=bool(rng.random() < 0.3), ice=str(rng.choice(["polar", "full", "patches", "dots"])),
                 land=str(rng.choice(["rows", "continents"])), mode=MODES[int(rng.integers(len(MODES)))], ncalls=int(rng.choice([1, 2, 3])),
                 resident=bool(rng.random() < 0.5), pin=bool(rng.random() < 0.2),
+                tilt=bool(rng.random() < 0.2), ugrid_wind=bool(rng.random() < 0.2), dt=float(rng.choice([3600.0, 900.0, 7200.0])),
                 strength=(None if rng.random() < 0.6 else dict(kstrength=int(rng.integers(0, 2)), krdg_partic=int(rng.integers(0, 2)),
                                                                  krdg_redist=int(rng.integers(0, 2)))), rng=rng)
 
@@ -53,10 +54,12 @@ def test_random_configuration(seed, monkeypatch):
     cosw, sinw = (np.cos(0.4), np.sin(0.4)) if k["turn"] else (1.0, 0.0)
     fo, fg = util.clone(f), util.clone(f)
     skw = dict(strength_mode=1, **k["strength"]) if k["strength"] else {}
-    p = orc.make_params(3600.0, k["ndte"], xmin, revised_evp=k["revised"], cosw=cosw, sinw=sinw, **skw)
+    dt = k["dt"]
+    p = orc.make_params(dt, k["ndte"], xmin, revised_evp=k["revised"], cosw=cosw, sinw=sinw, tilt_from_slope=k["tilt"],
+                        wind_on_ugrid=k["ugrid_wind"], **skw)
     s = dyn.EvpDynamics(d, fg, ndte=k["ndte"], revised_evp=k["revised"], xmin=xmin, cosw=cosw, sinw=sinw,
-                        device_strength=k["strength"], pin_host=k["pin"])
-    s.init_evp(3600.0)
+                        tilt_from_slope=k["tilt"], wind_on_ugrid=k["ugrid_wind"], device_strength=k["strength"], pin_host=k["pin"])
+    s.init_evp(dt)
     I, J = blocks.block_index_windows(d)
     nxg, nyg = d.nx_global, d.ny_global
     rng = k["rng"]
@@ -89,7 +92,7 @@ def test_random_configuration(seed, monkeypatch):
             s.ctx.upload_inputs(fg)
             s.ctx.prep(); s.ctx.subcycle(k["ndte"]); s.ctx.finish(); s.ctx.download(fg)
         else:
-            s.evp(3600.0)
+            s.evp(dt)
         st = s.ctx.stats()
         desc = {a: b for a, b in k.items() if a != "rng"}
         assert (st.icellt, st.icellu) == (nt, nu), (desc, call)
