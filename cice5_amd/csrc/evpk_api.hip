@@ -187,7 +187,7 @@ struct evpk_ctx {
     float loop_ms = 0.f, kernel_ms = 0.f, kernel2_ms = 0.f;
     int kernel_launches = 0;
     std::vector<char> kev_is_double;
-    int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around every 8th subcycle kernel launch (default), 2 all
+    int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around every 7th subcycle kernel launch (default), 2 all
     std::vector<int> kev_slot;     // launch index -> event pair index, -1 not timed
     int nkev = 0;
     bool force_exchange = false;   // EVPK_FORCE_EXCHANGE=1: single rank takes the multi-rank pack/exchange/unpack path (tests)
@@ -1097,8 +1097,9 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     }
     c->kev_slot.assign((size_t)nsub + 1, -1);
     c->nkev = 0;
-    // event pairs cost ~8 us per launch: by default only every 8th launch is timed (the launches are alike)
-    auto timed = [&](int launch) { return c->time_kernels == 2 || (c->time_kernels == 1 && (launch & 7) == 3); };
+    // event pairs cost ~8 us per launch: by default only every 7th launch is timed (the launches are alike; 7 is coprime
+    // to the ghost-zone period, so split and whole launches are both sampled on x-slabs)
+    auto timed = [&](int launch) { return c->time_kernels == 2 || (c->time_kernels == 1 && launch % 7 == 3); };
     auto ev_begin = [&](hipStream_t st) -> int {
         if (!timed(c->kernel_launches)) return 0;
         c->kev_slot[c->kernel_launches] = c->nkev;

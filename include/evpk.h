@@ -131,7 +131,7 @@ typedef struct {
     int32_t subcycles_done;  /* since the last evpk_prep */
     float loop_ms;           /* HIP-event time of the last evpk_subcycle call on the compute stream */
     float kernel_ms;         /* time of the one-subcycle kernel launches (k_subcycle) of that call: mean of the HIP-event-timed
-                                launches (every 8th by default, EVPK_TIME_KERNELS=2: all, 0: none) x number of launches */
+                                launches (every 7th by default, EVPK_TIME_KERNELS=2: all, 0: none) x number of launches */
     int32_t kernel_launches; /* ... and their number */
     float kernel2_ms;        /* the same for the two-subcycle kernel (k_subcycle2) */
     int32_t kernel2_launches;
