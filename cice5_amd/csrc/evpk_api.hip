@@ -390,7 +390,7 @@ static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes) {
 // skip_ew: the caller refreshes the E-W ghost columns itself right after (exchange_cols carries them, all rows)
 // fprev: see k_fold_pack (velocity updates inside the subcycle loop: the state buffer the kernel read)
 static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t one_launch_stream = nullptr,
-                bool skip_ew = false, int fprev = -1) {
+                bool skip_ew = false, int fprev = -1, int ew_from = 0) {
     Slab &s = c->s;
     const int tx = 128;
     const int gcol = (s.nxl + 2 + tx - 1) / tx, grow = (s.nyl + 2 + tx - 1) / tx;
@@ -401,7 +401,7 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         // single rank: the whole update of an NE-corner field in one launch
         const int n = std::max(std::max(s.nxg / 2 + 1, s.nxl + 2), s.nyl);
         hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, one_launch_stream ? one_launch_stream : c->stream,
-                           s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0, fprev);
+                           s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0, fprev, ew_from);
         HIPCHK(c, hipGetLastError());
         return 0;
     }
@@ -462,6 +462,36 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->recvW,
                            (const double *)c->recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
     }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// ---- the twelve ice_HaloUpdate_stress calls after the loop (tripole): one pack, one all-gather, one apply ----------
+static int halo_stress12(evpk_ctx *c, int f0) {
+    Slab &s = c->s;
+    const int tx = 128, nf = 12;
+    const int gcol = (s.nxl + 2 + tx - 1) / tx;
+    if (nf > c->max_nf) FAIL(c, "halo_stress12: buffer too small");
+    if (c->nranks == 1 && !c->force_exchange) {
+        hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, s, f0, nf, c->foldbuf, s.i0 - 1, -1);
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->foldloc, 0, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax, c->stream));
+        Slab t = s; t.nxg = c->wmax;
+        hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, f0, nf, c->foldloc, 0, -1);
+        const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
+        if (c->nranks > 1) {
+            if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
+        } else
+            HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
+        for (int r = 0; r < c->nranks; r++) {
+            const int w = c->slab_i0[r + 1] - c->slab_i0[r];
+            for (int q = 0; q < nf; q++)
+                HIPCHK(c, hipMemcpyAsync(c->foldbuf + ((size_t)q * 2 + 1) * s.nxg + (c->slab_i0[r] - 1),
+                                         c->foldall + r * seg + ((size_t)q * 2 + 1) * c->wmax,
+                                         sizeof(double) * w, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    hipLaunchKernelGGL(k_fold_apply_stress12, dim3(gcol), dim3(tx), 0, c->stream, s, f0, (const double *)c->foldbuf);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1137,25 +1167,29 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0; a.G = 0;
+        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30;
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
         const bool pair_inside = c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
-        // ... or, outside the tripole band mode, when the second of them is the last one (k_subcycle2<.., LAST2>)
-        const bool pair_ends_evp = c->use_double && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte) && !c->band_mode;
+        // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: only on a single rank, where
+        // the second band launch is then the LAST variant of k_subcycle)
+        const bool pair_ends_evp = c->use_double && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte) && (!c->band_mode || !c->zone_mode);
         if (pair_inside || pair_ends_evp) {
             a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             // tripole: rows next to the fold are redone one subcycle at a time with the fold in between
             //   band 1: T rows nyl-2..nyl+1, U rows nyl-2..nyl   state `sr` -> scratch;  fold(scratch)
             //   band 2: T rows nyl-1..nyl+1, U rows nyl-1..nyl   scratch -> state `sw`;  fold(sw)
-            // Band 1 reads the state this launch reads, so on a single rank it runs beside the main launch on stream2.
+            // On a single rank the main launch leaves rows >= nyl-1 to the bands (jmax) and writes its own E-W ghost images,
+            // so the whole band sequence -- band 1, fold, band 2, fold -- runs beside it on stream2.
             SubArgs b1 = a, b2 = a;
             const bool band_ahead = c->band_mode && !c->zone_mode;
-            auto launch_band = [&](const SubArgs &bb, hipStream_t st) {
+            auto launch_band = [&](const SubArgs &bb, hipStream_t st, bool last = false) {
                 const dim3 g((((c->ncx + 3) / 4 + 7) / 8) * 8), b(256);
-                if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, st, bb);
+                if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, st, bb);
+                else if (last) hipLaunchKernelGGL((k_subcycle<true, false>), g, b, 0, st, bb);
+                else if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, st, bb);
                 else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, st, bb);
             };
             if (c->band_mode) {
@@ -1168,7 +1202,10 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evB0, 0));
                     launch_band(b1, c->stream2);
                     if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, c->stream2, false, a.sr + S_U)) return 1;
+                    launch_band(b2, c->stream2, pair_ends_evp);
+                    if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, c->stream2, false, F_STATE2 + S_U, s.nyl - 1)) return 1;
                     HIPCHK(c, hipEventRecord(c->evB1, c->stream2));
+                    a.jmax = s.nyl - 2;
                 }
             }
             if (c->zone_mode && c->zone_left < 1) {         // (a one-subcycle launch or a partial call came before)
@@ -1214,11 +1251,11 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 if (!band_ahead) {
                     launch_band(b1, c->stream);
                     if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, nullptr, false, a.sr + S_U)) return 1;
+                    launch_band(b2, c->stream);
+                    // (x-slabs: the ghost-zone exchange below delivers the E-W ghost columns of the new state, all rows)
+                    if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, nullptr, c->zone_mode, F_STATE2 + S_U)) return 1;
                 } else
                     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
-                launch_band(b2, c->stream);
-                // (x-slabs: the ghost-zone exchange below delivers the E-W ghost columns of the new state, all rows)
-                if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, nullptr, c->zone_mode, F_STATE2 + S_U)) return 1;
             }
             c->ksub += 2;
             n += 2;
@@ -1288,16 +1325,7 @@ extern "C" int evpk_finish(evpk_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     const dim3 g2 = grid2d(s, B2D);
     const int SB = c->cur ? F_STATE1 : F_STATE0;
-    if (c->ns == EVPK_BND_TRIPOLE) {                                              // ice_dyn_evp.F90:454-479
-        const int base[3] = {S_SP, S_SM, S_S12};
-        for (int t = 0; t < 3; t++) {
-            const int b = SB + base[t];
-            if (halo(c, b + 0, 1, false, false, 0.0, b + 2)) return 1;
-            if (halo(c, b + 2, 1, false, false, 0.0, b + 0)) return 1;
-            if (halo(c, b + 1, 1, false, false, 0.0, b + 3)) return 1;
-            if (halo(c, b + 3, 1, false, false, 0.0, b + 1)) return 1;
-        }
-    }
+    if (c->ns == EVPK_BND_TRIPOLE && halo_stress12(c, SB + S_SP)) return 1;        // ice_dyn_evp.F90:454-479
     hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
     // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)
     if (halo(c, F_WORK3, 2, true, true, 0.0)) return 1;

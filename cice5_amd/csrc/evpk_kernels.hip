@@ -531,19 +531,38 @@ __global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int nec
     }
 }
 
+// The twelve ice_HaloUpdate_stress calls of evp (ice_dyn_evp.F90:454-479) in one launch: the north ghost row of sigma_k
+// takes the top physical row of its partner (1 <-> 3, 2 <-> 4 within stressp, stressm, stress12) at the mirrored column,
+// center rule, no sign.  The sources are physical rows that none of the twelve updates writes, so their order is immaterial.
+// fb: k_fold_pack of the twelve planes.
+__global__ void k_fold_apply_stress12(Slab s, int fdst0, const double *fb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // local col 0..nxl+1
+    if (i > s.nxl + 1) return;
+    const int nx = s.nxg;
+    int g = s.i0 + i - 1;
+    if (g < 1) g += nx;
+    if (g > nx) g -= nx;
+    for (int q = 0; q < 12; q++) {
+        const int src = (q & ~3) | ((q & 3) ^ 2);
+        const double *B2 = fb + ((size_t)src * 2 + 1) * nx - 1;  // 1-based top row of the partner plane
+        FD(s, fdst0 + q, cell(s, i, s.nyl + 1)) = B2[nx - g + 1];
+    }
+}
+
 // Whole halo update of an NE-corner vector field on a single-rank tripole grid in ONE launch (the subcycle loop calls
 // it twice per launch pair): south ghost row, the u-fold of k_fold_apply straight from the planes, and the E-W ghost
 // columns.  The symmetrised top row of column g depends on the old values at g and nx-g only, so one thread owns that
 // pair and no staging buffer is needed; every other value read lies in a cell this kernel does not write.
 //   blockIdx.y == 0: fold (thread k: columns k and nx-k; k = 0 stands for column nx), rows nyl and nyl+1
 //   blockIdx.y == 1: rows 0 .. nyl-1: south fill and the two ghost columns
-__global__ void k_halo_tripole_ne1(Slab s, int f, int nf, int cyclic, double fill, double sgn, int fprev /* see k_fold_pack */) {
+// ew_from: the E-W ghost columns are refreshed for rows ew_from .. nyl-1 only (the rows below are another launch's business)
+__global__ void k_halo_tripole_ne1(Slab s, int f, int nf, int cyclic, double fill, double sgn, int fprev /* see k_fold_pack */, int ew_from) {
     const int nx = s.nxg, h = nx / 2, nyl = s.nyl;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.y == 1) {
         if (t <= s.nxl + 1)
             for (int q = 0; q < nf; q++) FD(s, f + q, cell(s, t, 0)) = fill;
-        if (t >= 1 && t <= nyl - 1)
+        if (t >= 1 && t >= ew_from && t <= nyl - 1)
             for (int q = 0; q < nf; q++) {
                 FD(s, f + q, cell(s, 0, t)) = cyclic ? FD(s, f + q, cell(s, s.nxl, t)) : fill;
                 FD(s, f + q, cell(s, s.nxl + 1, t)) = cyclic ? FD(s, f + q, cell(s, 1, t)) : fill;
@@ -738,6 +757,7 @@ struct SubArgs {
     int nstrips, ncx, R, wrap;
     int sr, sw;        // field ids of the state buffer read / written (F_STATE0, F_STATE1 or F_STATE2)
     int jb0;           // > 0: band launch -- every strip starts at row jb0 (tripole top band), strips[] holds cx only
+    int jmax;          // k_subcycle2: rows above are not stored (tripole, single rank: the band launches own rows >= nyl-1)
     int G;             // k_subcycle2 in ghost-zone mode: columns 1-G .. nxl+G are advanced (zones of G+2 columns per side)
 };
 
@@ -1180,7 +1200,7 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
                 double tarear = 0.0;
                 if (LAST2) tarear = *reinterpret_cast<const double *>(rq + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
                 stress_cell<LAST2>(mtp, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
-                if (own && q2 >= jb && q2 < jb + R) {
+                if (own && q2 >= jb && q2 < jb + R && q2 <= a.jmax) {
                     store_sig(rq, pp, SW, lo, g2);
                     if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);     // east ghost T column = image of column 1
                     if (LAST2) {    // the second subcycle is the last one of this evp: ridging diagnostics (ice_dyn_evp.F90:665-677)
@@ -1195,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
 
         // ---------------- stage 2: U2(r-2) ----------------
         const int q3 = r - 2;
-        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl;
+        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl && q3 <= a.jmax;
         if (__any(u2act)) {
             if (u2act) {
                 double un, vn, sxi, syi;
@@ -1469,7 +1489,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
                 if (LAST2) tarear = *reinterpret_cast<const double *>(rq + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
                 const TMet mt2 = CM ? tmet_from_lengths(hn_p, hn_pp, he_p, hw_p, tiny_p, str_p) : mtp;
                 stress_cell<LAST2>(mt2, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
-                if (own && q2 >= jb && q2 < jb + R) {
+                if (own && q2 >= jb && q2 < jb + R && q2 <= a.jmax) {
                     store_sig(rq, pp, SW, lo, g2);
                     if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);
                     if (LAST2) {
@@ -1484,7 +1504,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
 
         // ---------------- stage 2: U2(r-2) ----------------
         const int q3 = r - 2;
-        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl;
+        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl && q3 <= a.jmax;
         if (__any(u2act)) {
             if (u2act) {
                 double un, vn, sxi, syi;
