@@ -228,6 +228,13 @@ def main():
             out["config"]["evp_incl_pcie_ms"] = evp_incl_pcie(d, f, a, xmin, local_rank)
         except Exception as e:
             out["config"]["evp_incl_pcie_ms"] = {"error": str(e)[:200]}
+    # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would otherwise surface AFTER
+    # the JSON line at exit: flush it first so that the JSON line is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
         print(json.dumps(out), flush=True)
     if solver is not None:

@@ -417,7 +417,7 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
             Slab t = s; t.nxg = c->wmax;   // local segment addressed with gofs = 0
             hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, fp, nf, c->foldloc, 0, fprev);
             const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
-            if (c->nranks > 1) {
+            if (c->nranks > 1 || c->comm) {
                 if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
             } else
                 HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
@@ -451,7 +451,7 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         c->sendW = c->sendbuf; c->sendE = c->sendbuf + cnt;
         c->recvE = c->recvbuf; c->recvW = c->recvbuf + cnt;
         hipLaunchKernelGGL(k_ew_pack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->sendW, c->sendE);
-        if (c->nranks == 1) {          // forced exchange with myself (cyclic): my W edge is my own east ghost
+        if (c->nranks == 1 && !c->comm) {   // forced exchange with myself (cyclic): my W edge is my own east ghost
             if (c->west >= 0) {
                 HIPCHK(c, hipMemcpyAsync(c->recvE, c->sendW, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
                 HIPCHK(c, hipMemcpyAsync(c->recvW, c->sendE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
@@ -479,7 +479,7 @@ static int halo_stress12(evpk_ctx *c, int f0) {
         Slab t = s; t.nxg = c->wmax;
         hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, f0, nf, c->foldloc, 0, -1);
         const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
-        if (c->nranks > 1) {
+        if (c->nranks > 1 || c->comm) {
             if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
         } else
             HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
@@ -535,7 +535,7 @@ static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact) {
     const int tx = 256;
     const int nps = std::max(zr.sW.n, zr.sE.n) * W, npr = std::max(zr.rE.n, zr.rW.n) * W;
     if (nps > 0) hipLaunchKernelGGL(k_cols_pack, dim3((nps + tx - 1) / tx), dim3(tx), 0, c->stream, s, pl, W, zr, sendW, sendE);
-    if (c->nranks == 1) {              // forced exchange with myself (cyclic ring of one)
+    if (c->nranks == 1 && !c->comm) {   // forced exchange with myself (cyclic ring of one)
         if (c->west >= 0) {
             if (nSW != nRE || nSE != nRW) FAIL(c, "exchange_cols: self-exchange row sets differ");
             if (nSW) HIPCHK(c, hipMemcpyAsync(recvE, sendW, sizeof(double2) * nSW, hipMemcpyDeviceToDevice, c->stream));
@@ -708,6 +708,14 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     {
         const char *fe = getenv("EVPK_FORCE_EXCHANGE");
         c->force_exchange = fe && atoi(fe) != 0;
+        if (fe && atoi(fe) == 2 && g->nranks == 1) {
+            // ... and EVPK_FORCE_EXCHANGE=2 routes that self-exchange through a ONE-rank RCCL communicator: ncclSend / ncclRecv
+            // to itself inside a group and ncclAllGather, with the production buffers, counts and stream (tests: the RCCL
+            // call path on a one-GPU box)
+            ncclUniqueId u;
+            NCCLCHK(c, ncclGetUniqueId(&u));
+            NCCLCHK(c, ncclCommInitRank(&c->comm, 1, u, 0));
+        }
     }
     const size_t eslot = (size_t)c->max_nf * (s.nyl + 2);
     HIPCHK(c, hipMalloc(&c->sendbuf, sizeof(double) * 2 * eslot));

@@ -182,6 +182,18 @@ def test_page_locked_host_arrays(ns):
     _both(130, 60, 130, 60, ns=ns, ice="full", ndte=12, pin_host=True)
 
 
+@pytest.mark.parametrize("ns,m", [("open", 4), ("open", 1), ("tripole", 1)])
+def test_self_exchange_through_rccl(ns, m, monkeypatch):
+    """EVPK_FORCE_EXCHANGE=2: the single rank's self-exchange goes through a ONE-rank RCCL communicator created by the
+    library -- ncclSend / ncclRecv to itself in a group (ghost zones, one-column halos, compacted row lists) and
+    ncclAllGather (tripole fold) on the production buffers, counts and stream.  RCCL refuses two ranks on one GPU, so this
+    is how far the RCCL call path can be exercised on a one-GPU box."""
+    monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "2")
+    monkeypatch.setenv("EVPK_ZONE_M", str(m))
+    _both(200, 96, 50, 48, ns=ns, land="continents", ndte=31, ncalls=2)
+    _both(130, 60, 130, 60, ns=ns, ice="full", ndte=18, revised_evp=True)
+
+
 @pytest.mark.parametrize("m", [1, 2, 4])
 def test_forced_exchange_zone_depth(m, monkeypatch):
     """Self-exchange on a cyclic ring of one rank with ghost zones of 2*m columns (EVPK_ZONE_M)."""
