@@ -14,7 +14,8 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH": "0"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_ZONE_M": "2"},
-         {"EVPK_COMPACT_METRICS": "0"}, {"EVPK_STRIP_ROWS": "3"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_OVERLAP": "0"}]
+         {"EVPK_COMPACT_METRICS": "0"}, {"EVPK_STRIP_ROWS": "3"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_OVERLAP": "0"},
+         {"EVPK_FORCE_EXCHANGE": "2"}, {"EVPK_FORCE_EXCHANGE": "2", "EVPK_ZONE_M": "1"}]
 
 
 def _config(seed):
