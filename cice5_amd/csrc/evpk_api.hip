@@ -3,9 +3,10 @@
 // Mirrors the control flow of subroutine evp (source/ice_dyn_evp.F90:68-510) on one HIP
 // stream: gather block arrays into the slab, evp_prep1 / to_ugrid / evp_prep2, halo
 // updates, ndte x (fused stress+stepu kernel, velocity halo), tripole stress fold,
-// evp_finish, u2tgrid, scatter back.  Multi-GPU: x-slabs on a ring, packed edge columns
-// exchanged with ncclSend/ncclRecv (RCCL over xGMI); the tripole fold all-gathers the two
-// top rows.  No CPU fallback exists: every entry point needs a gfx950 device.
+// evp_finish, u2tgrid, scatter back.  Multi-GPU: x-slabs on a ring, ghost zones of up to 8
+// columns exchanged once per 4 launches with ncclSend/ncclRecv (RCCL over xGMI) beside the
+// interior strips on a second stream; the tripole fold all-gathers the two top rows.
+// No CPU fallback exists: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 

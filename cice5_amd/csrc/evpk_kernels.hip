@@ -4,12 +4,13 @@
 // reference spells out, so results are bit-comparable with a non-FMA CPU build.
 // fp64 sqrt and divide lower to correctly rounded sequences on gfx950.
 //
-// Hot kernel: k_subcycle -- one launch = one EVP subcycle = stress (ice_dyn_evp.F90:520-849)
-// fused with stepu (ice_dyn_shared.F90:623-748).  The str(:,:,1:8) work array of the
-// reference never reaches HBM: it lives in registers and moves between lanes with DPP/
-// bpermute shuffles.  u, v and the twelve sigma planes are double buffered (read buffer
-// `cur`, write buffer `cur^1`) so that redundant T cells on strip edges see old values.
-// All hot fields are read and written as double2 pairs (16 B per lane, see evpk_internal.h).
+// Hot kernels: k_subcycle2p / k_subcycle2 -- one launch = TWO EVP subcycles, and k_subcycle -- one launch = one EVP
+// subcycle = stress (ice_dyn_evp.F90:520-849) fused with stepu (ice_dyn_shared.F90:623-748).  The str(:,:,1:8)
+// work array of the reference never reaches HBM: it lives in registers and moves between lanes with DPP wave
+// shifts.  u, v and the twelve sigma planes are double buffered (read buffer `cur`, write buffer `cur^1`) so that
+// redundant T cells on strip edges see old values.  All hot fields are read and written as double2 pairs (16 B per
+// lane, see evpk_internal.h).  Order of the file: block <-> slab transfer, per-evp kernels (prep, strength, T<->U
+// averages), halo / fold / ghost-zone kernels, strip bookkeeping, the subcycle kernels, finish.
 #include "evpk_internal.h"
 
 namespace evpk {
@@ -632,10 +633,9 @@ __global__ void k_ew_unpack(Slab s, int f, int nf, const double *recvW, const do
 }
 
 // ------------------------------------------------------------------------------------
-// Two-column ghost zones for the two-subcycle kernel on x-slabs: columns {1,2} go to the west
-// neighbour (its columns nxl+1, nxl+2), columns {nxl-1, nxl} to the east neighbour (its -1, 0),
-// over all rows, for a list of pair planes (+ optionally the byte mask as a pseudo plane).
-// Buffer layout: buf[((p*2 + k)*rows + j)] of double2, k = 0,1 the two columns in ascending order.
+// Ghost zones of the two-subcycle kernel on x-slabs, W = 2..8 columns per side: columns 1..W go to the west neighbour
+// (its columns nxl+1..nxl+W), columns nxl-W+1..nxl to the east neighbour (its 1-W..0), for a list of pair planes
+// (+ optionally the byte mask as a pseudo plane), all rows or a compacted row list per side.
 // ------------------------------------------------------------------------------------
 struct PairList { int n; int with_cmask; int p[24]; };
 
