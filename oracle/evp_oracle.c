@@ -9,6 +9,9 @@
  */
 #include "evp_oracle.h"
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -578,7 +581,9 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
     const int nxg = g->nx_global, nyg = g->ny_global;
     const size_t nn = (size_t)nx * ny;
     double *G = (double *)malloc(sizeof(double) * (size_t)nxg * nyg);
-    for (size_t k = 0; k < (size_t)nxg * nyg; k++) G[k] = fill;
+#pragma omp parallel for schedule(static)
+    for (long long k = 0; k < (long long)nxg * nyg; k++) G[k] = fill;
+#pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < g->nblocks; b++) {
         const double *ab = asrc + (size_t)b * nn;
         for (int j = g->jlo[b]; j <= g->jhi[b]; j++)
@@ -613,6 +618,7 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
         }
         free(row2);
     }
+#pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < g->nblocks; b++) {
         double *ab = a + (size_t)b * nn;
         const int ilo = g->ilo[b], ihi = g->ihi[b], jlo = g->jlo[b], jhi = g->jhi[b];
@@ -757,11 +763,22 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
     if (counts) { counts[0] = nt; counts[1] = nu; }
 
     const int nsub = nsub_override > 0 ? nsub_override : p->ndte;
+    /* one str(nx,ny,8) work array per thread for the whole loop (the reference's is an automatic array of stress) */
+    int nthr = 1;
+#ifdef _OPENMP
+    nthr = omp_get_max_threads();
+#endif
+    double **strbuf = (double **)malloc(sizeof(double *) * (size_t)nthr);
+    for (int t = 0; t < nthr; t++) strbuf[t] = (double *)malloc(8 * nn * sizeof(double));
     double t0 = wall();
     for (int ksub = 1; ksub <= nsub; ksub++) {                            /* :336-410 */
 #pragma omp parallel
         {
-            double *strtmp = (double *)malloc(8 * nn * sizeof(double));
+            int me = 0;
+#ifdef _OPENMP
+            me = omp_get_thread_num();
+#endif
+            double *strtmp = strbuf[me];
             double *tsp[4], *tsm[4], *ts12[4];
 #pragma omp for schedule(dynamic, 1)
             for (int b = 0; b < nb; b++) {
@@ -778,12 +795,13 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
                           f->strintx + o, f->strinty + o, f->uvel_init + o, f->vvel_init + o,
                           f->uvel + o, f->vvel + o, p);
             }
-            free(strtmp);
         }
         orc_halo_r8(g, f->uvel, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);  /* :392-400 */
         orc_halo_r8(g, f->vvel, ORC_LOC_NECORNER, ORC_KIND_VECTOR, 0.0);
     }
     if (loop_seconds) *loop_seconds = wall() - t0;
+    for (int t = 0; t < nthr; t++) free(strbuf[t]);
+    free(strbuf);
 
     if (g->ns_boundary == ORC_BND_TRIPOLE) {                              /* :416-481 */
         double **S[3] = { f->stressp, f->stressm, f->stress12 };
