@@ -417,6 +417,15 @@ void orc_principal_stress(int nx, int ny, const double *stressp_1, const double 
  * exp(x): k = nint(x/ln2), r = x - k ln2 in two pieces, exp(r) = 1 + 2r/(R(r^2) - r) with R = 2 - c/r ... written as in
  * fdlibm's e_exp.c (Sun Microsystems, public domain), whose error bound is < 1 ulp.
  * ------------------------------------------------------------------------- */
+/* OpenMP team size of the loops below (the runtime may have been initialised by the host process with another default) */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 double orc_exp(double x) {
     static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                         invln2 = 1.44269504088896338700e+00,

@@ -146,6 +146,7 @@ void orc_principal_stress(int nx, int ny, const double *stressp_1, const double 
  * oracle and the HIP kernels both evaluate the classical Cody-Waite reduction + degree-5 minimax in r^2 (the fdlibm
  * scheme, < 1 ulp) in plain un-fused fp64 so that they agree bit for bit.  |x| < 700. */
 double orc_exp(double x);
+void orc_set_num_threads(int n);
 
 /* ice_strength (ice_mechred.F90:2111-2269) with asum_ridging (:758-812, unused by the strength) and ridge_itd (:936-1285)
  * on one block; aicen / vicen are (ncat, ny, nx) planes of that block */

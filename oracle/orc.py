@@ -91,8 +91,12 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _limit_threads()
+        nthr = _limit_threads()
         _lib = ct.CDLL(_LIB_PATH)
+        # the environment variable is only read when the OpenMP runtime starts, which a host process (torch) may have done
+        # long ago with its own default: set the team size explicitly
+        _lib.orc_set_num_threads.argtypes = [ct.c_int]
+        _lib.orc_set_num_threads(nthr)
         _lib.orc_set_evp_parameters.argtypes = [ct.c_double, ct.c_int32, ct.c_int32, ct.c_double, ct.POINTER(OrcParams)]
         _lib.orc_evp.argtypes = [ct.POINTER(OrcGeom), ct.POINTER(OrcParams), ct.POINTER(OrcFields), ct.c_int,
                                  ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double)]
