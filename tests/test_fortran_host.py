@@ -128,3 +128,36 @@ def test_fortran_host_with_ice_strength_on_the_device(tmp_path, sw):
     assert not bad, bad[:6]
     m = util.cell_mask(d, "all")
     assert np.array_equal(got["strength"][m], fo["strength"][m]) and fo["strength"].max() > 1e3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_F_N", "6"))))
+def test_fortran_host_random_configuration(tmp_path, seed):
+    """Seeded random shapes through the Fortran module: padded edge blocks, boundary types, 1-3 calls (the second call on
+    takes the inputs-only upload with the state resident on the device), host or device ice_strength."""
+    rng = np.random.default_rng(900 + seed)
+    nx, ny = int(rng.choice([24, 61, 96, 130])), int(rng.choice([12, 23, 40, 57]))
+    ns = str(rng.choice(["open", "tripole", "closed"]))
+    nx += (nx & 1) if ns == "tripole" else 0
+    bsx = min(nx, int(rng.choice([7, 20, max(3, nx // 3 + 1), nx])))
+    bsy = min(ny, int(rng.choice([5, 11, max(3, ny // 2), ny])))
+    if ns == "tripole" and ny % bsy == 1 and bsy < ny:
+        bsy += 1
+    ndte, ncalls = int(rng.choice([1, 2, 7, 12])), int(rng.choice([1, 2, 3]))
+    sw = None if rng.random() < 0.5 else dict(kstrength=int(rng.integers(0, 2)), krdg_partic=int(rng.integers(0, 2)),
+                                              krdg_redist=int(rng.integers(0, 2)))
+    case, d, f = util.make_case(nx, ny, bsx, bsy, ns=ns, land="continents", ice=str(rng.choice(["polar", "full"])))
+    if sw:
+        synth.add_thickness_distribution(f)
+    xmin = synth.global_min_dx(case)
+    p = dyn.set_evp_parameters(3600.0, ndte, False, xmin)
+    write_fixture(tmp_path / "in.bin", d, f, p, ncalls, device_strength=sw)
+    r = subprocess.run([DRIVER, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = read_output(tmp_path / "out.bin", d, with_strength=sw is not None)
+    fo = util.clone(f)
+    po = orc.make_params(3600.0, ndte, xmin, **(dict(strength_mode=1, **sw) if sw else {}))
+    for _ in range(ncalls):
+        orc.evp(d, po, fo)
+    bad = util.compare(d, got, fo, names=[n for n in got if n != "strength"])
+    assert not bad, ((nx, ny, bsx, bsy, ns, ndte, ncalls, sw), bad[:4])
