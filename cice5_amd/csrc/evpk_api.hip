@@ -259,10 +259,12 @@ extern "C" int evpk_unpin_host(void *ptr) {
     return 0;
 }
 
-// device-visible alias of a registered host array, or nullptr
+// device-visible alias of a registered host array -- or the pointer itself if the caller's array already lives in device
+// memory (a host model that keeps its fields on the GPU: OpenMP target / OpenACC `use_device` data) -- else nullptr
 static void *mapped_alias(const void *host) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type == hipMemoryTypeDevice) return const_cast<void *>(host);
     if (at.type != hipMemoryTypeHost) return nullptr;
     void *dp = nullptr;
     if (hipHostGetDevicePointer(&dp, const_cast<void *>(host), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }

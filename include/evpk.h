@@ -178,6 +178,9 @@ int evpk_destroy(evpk_ctx *c);
  * evpk_download / evpk_run then read and write such arrays in place over PCIe instead of staging them, and a download
  * touches only the cells it delivers.  Arrays that were not registered keep working (staged copies).  Unpin before the
  * memory is freed.  Returns 0 on success. */
+/* Arrays that already live in DEVICE memory (a host model whose fields are resident on the GPU: OpenMP target /
+ * OpenACC use_device pointers, hipMalloc) may be passed wherever a host array is expected: the library detects them
+ * (hipPointerGetAttributes) and gathers / scatters them in place, no PCIe transfer at all. */
 int evpk_pin_host(void *ptr, size_t bytes);
 int evpk_unpin_host(void *ptr);
 const char *evpk_last_error(const evpk_ctx *c);  /* c may be NULL: error of the last failed evpk_create */

@@ -518,3 +518,41 @@ def test_full_size_3600x2700_properties():
     s2.evp(450.0)
     s2.close()
     assert not util.compare(d, h1, h2)
+
+
+def test_caller_arrays_in_device_memory():
+    """A host model whose fields already live on the GPU passes device pointers in place of host arrays (same block
+    layout): the library reads and writes them in place.  Here the arrays are torch tensors on the device."""
+    import ctypes as ct
+    torch = pytest.importorskip("torch")
+    case, d, f = util.make_case(100, 116, 25, 29, ns="tripole", land="continents")
+    xmin = synth.global_min_dx(case)
+    fo = util.clone(f)
+    p = orc.make_params(3600.0, 20, xmin)
+    s = dyn.EvpDynamics(d, f, ndte=20, xmin=xmin)       # geometry from host arrays; the per-step arrays from the device
+    s.init_evp(3600.0)
+    dev = {n: torch.from_numpy(np.ascontiguousarray(a)).cuda() for n, a in f.items() if isinstance(a, np.ndarray)}
+    ptr = lambda n, T: ct.cast(dev[n].data_ptr(), T) if n in dev else None
+    for call in range(2):
+        if call:
+            for n in ("aice", "vice"):
+                fo[n] *= 0.95
+                dev[n] *= 0.95
+        si, st = evpk.StepIn(), evpk.State()
+        for n in evpk.STEP_IN_F64:
+            setattr(si, n, ptr(n, evpk.c_f64p))
+        st.uvel, st.vvel = ptr("uvel", evpk.c_f64p), ptr("vvel", evpk.c_f64p)
+        for k in ("stressp", "stressm", "stress12"):
+            setattr(st, k, (evpk.c_f64p * 4)(*[ptr(f"{k}_{c}", evpk.c_f64p) for c in (1, 2, 3, 4)]))
+        st.iceumask = ptr("iceumask", evpk.c_i32p)
+        for n in evpk.STATE_OUT_F64:
+            setattr(st, n, ptr(n, evpk.c_f64p))
+        st.icetmask, st.strength = None, None
+        torch.cuda.synchronize()
+        assert s.ctx._L.evpk_run(s.ctx._ctx, ct.byref(si), ct.byref(st)) == 0
+        orc.evp(d, p, fo)
+        got = {n: t.cpu().numpy() for n, t in dev.items()}
+        got["icetmask"] = fo["icetmask"]
+        bad = util.compare(d, got, fo)
+        assert not bad, (call, bad[:4])
+    s.close()
