@@ -143,7 +143,10 @@ typedef struct {
 } evpk_stats;
 
 /* rank 0 creates the RCCL id; the host model broadcasts the bytes (MPI_Bcast in CICE,
- * torch.distributed in bench.py) and every rank passes them to evpk_create. */
+ * torch.distributed in bench.py) and every rank passes them to evpk_create.
+ * Second transport, for ranks that cannot form an RCCL communicator (several ranks on one GPU: tests; or a node whose
+ * RCCL bootstrap fails: bench.py's fallback): a unique id that starts with "EVPKSHM:<name>" selects a host-staged relay
+ * through the POSIX shared-memory segment /<name> with the same point-to-point / all-gather semantics (correct, slow). */
 int evpk_get_unique_id(void *id /* EVPK_UNIQUE_ID_BYTES */);
 
 int evpk_create(const evpk_geom *g, evpk_ctx **out);
