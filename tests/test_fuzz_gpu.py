@@ -20,8 +20,12 @@ MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH
 
 def _config(seed):
     rng = np.random.default_rng(1000 + seed)
-    nx = int(rng.choice([8, 24, 61, 62, 64, 96, 122, 123, 130, 200, 371, 733]))
-    ny = int(rng.choice([10, 12, 23, 40, 57, 64, 131, 257]))
+    if os.environ.get("EVPK_FUZZ_BIG"):          # many strip columns / rows: the strip-height tuner, several rounds of workgroups
+        nx = int(rng.choice([733, 1000, 1464, 2048]))
+        ny = int(rng.choice([257, 400, 701]))
+    else:
+        nx = int(rng.choice([8, 24, 61, 62, 64, 96, 122, 123, 130, 200, 371, 733]))
+        ny = int(rng.choice([10, 12, 23, 40, 57, 64, 131, 257]))
     ns = str(rng.choice(["open", "open", "tripole", "closed"]))
     ew = str(rng.choice(["cyclic", "cyclic", "open", "closed"]))
     if ns == "tripole":
