@@ -342,48 +342,51 @@ static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int 
 // ring exchange with the west / east neighbour; counts in doubles: nSW to the west, nSE to the east, nRE from the
 // east, nRW from the west.  With two ranks on a cyclic ring the neighbours coincide and one message [sW | sE] goes each
 // way, received as [rE | rW] (sE must follow sW and rW follow rE in memory).
-static int xp_ring(evpk_ctx *c, const double *sW, size_t nSW, const double *sE, size_t nSE, double *rE, size_t nRE, double *rW, size_t nRW) {
+static int xp_ring(evpk_ctx *c, const double *sW, size_t nSW, const double *sE, size_t nSE, double *rE, size_t nRE, double *rW, size_t nRW,
+                   hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     const bool merged = (c->west == c->east && c->west >= 0);
     if (merged && (sE != sW + nSW || rW != rE + nRE)) FAIL(c, "xp_ring: merged message needs contiguous buffers");
     if (c->relay) {
         int rc = 0;
         if (merged) {
-            rc |= c->relay->send(c->west, sW, (nSW + nSE) * 8, c->stream);
-            rc |= c->relay->recv(c->west, rE, (nRE + nRW) * 8, c->stream);
+            rc |= c->relay->send(c->west, sW, (nSW + nSE) * 8, st);
+            rc |= c->relay->recv(c->west, rE, (nRE + nRW) * 8, st);
         } else {
-            if (c->west >= 0) rc |= c->relay->send(c->west, sW, nSW * 8, c->stream);
-            if (c->east >= 0) rc |= c->relay->send(c->east, sE, nSE * 8, c->stream);
-            if (c->east >= 0) rc |= c->relay->recv(c->east, rE, nRE * 8, c->stream);
-            if (c->west >= 0) rc |= c->relay->recv(c->west, rW, nRW * 8, c->stream);
+            if (c->west >= 0) rc |= c->relay->send(c->west, sW, nSW * 8, st);
+            if (c->east >= 0) rc |= c->relay->send(c->east, sE, nSE * 8, st);
+            if (c->east >= 0) rc |= c->relay->recv(c->east, rE, nRE * 8, st);
+            if (c->west >= 0) rc |= c->relay->recv(c->west, rW, nRW * 8, st);
         }
         if (rc) FAIL(c, "shared-memory relay: exchange failed (%s)", rc & 2 ? "timeout" : "copy / size");
         return 0;
     }
     NCCLCHK(c, ncclGroupStart());
     if (merged) {
-        if (nSW + nSE) NCCLCHK(c, ncclSend(sW, nSW + nSE, ncclDouble, c->west, c->comm, c->stream));
-        if (nRE + nRW) NCCLCHK(c, ncclRecv(rE, nRE + nRW, ncclDouble, c->west, c->comm, c->stream));
+        if (nSW + nSE) NCCLCHK(c, ncclSend(sW, nSW + nSE, ncclDouble, c->west, c->comm, st));
+        if (nRE + nRW) NCCLCHK(c, ncclRecv(rE, nRE + nRW, ncclDouble, c->west, c->comm, st));
     } else {
-        if (c->west >= 0 && nSW) NCCLCHK(c, ncclSend(sW, nSW, ncclDouble, c->west, c->comm, c->stream));
-        if (c->east >= 0 && nSE) NCCLCHK(c, ncclSend(sE, nSE, ncclDouble, c->east, c->comm, c->stream));
-        if (c->east >= 0 && nRE) NCCLCHK(c, ncclRecv(rE, nRE, ncclDouble, c->east, c->comm, c->stream));
-        if (c->west >= 0 && nRW) NCCLCHK(c, ncclRecv(rW, nRW, ncclDouble, c->west, c->comm, c->stream));
+        if (c->west >= 0 && nSW) NCCLCHK(c, ncclSend(sW, nSW, ncclDouble, c->west, c->comm, st));
+        if (c->east >= 0 && nSE) NCCLCHK(c, ncclSend(sE, nSE, ncclDouble, c->east, c->comm, st));
+        if (c->east >= 0 && nRE) NCCLCHK(c, ncclRecv(rE, nRE, ncclDouble, c->east, c->comm, st));
+        if (c->west >= 0 && nRW) NCCLCHK(c, ncclRecv(rW, nRW, ncclDouble, c->west, c->comm, st));
     }
     NCCLCHK(c, ncclGroupEnd());
     return 0;
 }
 
 // all-gather of `bytes` per rank (multiple of 4) into dst[rank*bytes ...]
-static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes) {
+static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     if (c->relay) {
         int rc = 0;
-        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->send(r, src, bytes, c->stream);
-        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->recv(r, (char *)dst + (size_t)r * bytes, bytes, c->stream);
+        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->send(r, src, bytes, st);
+        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->recv(r, (char *)dst + (size_t)r * bytes, bytes, st);
         if (rc) FAIL(c, "shared-memory relay: all-gather failed");
-        HIPCHK(c, hipMemcpyAsync((char *)dst + (size_t)c->rank * bytes, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync((char *)dst + (size_t)c->rank * bytes, src, bytes, hipMemcpyDeviceToDevice, st));
         return 0;
     }
-    NCCLCHK(c, ncclAllGather(src, dst, bytes / 4, ncclInt32, c->comm, c->stream));
+    NCCLCHK(c, ncclAllGather(src, dst, bytes / 4, ncclInt32, c->comm, st));
     return 0;
 }
 
@@ -392,9 +395,10 @@ static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes) {
 // destination planes is written, from the top physical row of the source planes).
 // skip_ew: the caller refreshes the E-W ghost columns itself right after (exchange_cols carries them, all rows)
 // fprev: see k_fold_pack (velocity updates inside the subcycle loop: the state buffer the kernel read)
-static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t one_launch_stream = nullptr,
+static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t st_in = nullptr,
                 bool skip_ew = false, int fprev = -1, int ew_from = 0) {
     Slab &s = c->s;
+    hipStream_t st = st_in ? st_in : c->stream;       // every launch, copy and transport call of this update
     const int tx = 128;
     const int gcol = (s.nxl + 2 + tx - 1) / tx, grow = (s.nyl + 2 + tx - 1) / tx;
     const bool stress_mode = fsrc_fold >= 0;
@@ -403,42 +407,42 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     if (c->ns == EVPK_BND_TRIPOLE && c->nranks == 1 && !c->force_exchange && necorner && !stress_mode && s.nyl >= 3) {
         // single rank: the whole update of an NE-corner field in one launch
         const int n = std::max(std::max(s.nxg / 2 + 1, s.nxl + 2), s.nyl);
-        hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, one_launch_stream ? one_launch_stream : c->stream,
+        hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, st,
                            s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill, vector ? -1.0 : 1.0, fprev, ew_from);
         HIPCHK(c, hipGetLastError());
         return 0;
     }
     // N-S
     if (c->ns == EVPK_BND_TRIPOLE) {
-        if (!stress_mode) hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 0);
+        if (!stress_mode) hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, st, s, f, nf, fill, 0);
         const int fp = stress_mode ? fsrc_fold : f;
         if (c->nranks == 1 && !c->force_exchange) {
-            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, s, fp, nf, c->foldbuf, s.i0 - 1, fprev);
+            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, st, s, fp, nf, c->foldbuf, s.i0 - 1, fprev);
         } else {
             // pack own segment [nf][2][wmax], all-gather, re-pack into [nf][2][nxg]
-            HIPCHK(c, hipMemsetAsync(c->foldloc, 0, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->foldloc, 0, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax, st));
             Slab t = s; t.nxg = c->wmax;   // local segment addressed with gofs = 0
-            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, fp, nf, c->foldloc, 0, fprev);
+            hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, st, t, fp, nf, c->foldloc, 0, fprev);
             const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
             if (c->nranks > 1 || c->comm) {
-                if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
+                if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double), st)) return 1;
             } else
-                HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, st));
             for (int r = 0; r < c->nranks; r++) {
                 const int w = c->slab_i0[r + 1] - c->slab_i0[r];
                 for (int q = 0; q < nf; q++)
                     for (int rr = 0; rr < 2; rr++)
                         HIPCHK(c, hipMemcpyAsync(c->foldbuf + ((size_t)q * 2 + rr) * s.nxg + (c->slab_i0[r] - 1),
                                                  c->foldall + r * seg + ((size_t)q * 2 + rr) * c->wmax,
-                                                 sizeof(double) * w, hipMemcpyDeviceToDevice, c->stream));
+                                                 sizeof(double) * w, hipMemcpyDeviceToDevice, st));
             }
         }
-        hipLaunchKernelGGL(k_fold_apply, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->foldbuf,
+        hipLaunchKernelGGL(k_fold_apply, dim3(gcol), dim3(tx), 0, st, s, f, nf, (const double *)c->foldbuf,
                            (necorner && !stress_mode) ? 1 : 0, (vector && !stress_mode) ? -1.0 : 1.0);
         HIPCHK(c, hipGetLastError());
         if (stress_mode) return 0;
     } else {
-        hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, c->stream, s, f, nf, fill, 1);
+        hipLaunchKernelGGL(k_halo_ns_fill, dim3(gcol), dim3(tx), 0, st, s, f, nf, fill, 1);
     }
     // E-W over all rows (ghost rows included, which carries the corners)
     if (skip_ew) {
@@ -446,23 +450,23 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         return 0;
     }
     if (c->nranks == 1 && !c->force_exchange) {
-        hipLaunchKernelGGL(k_halo_ew_local, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill);
+        hipLaunchKernelGGL(k_halo_ew_local, dim3(grow), dim3(tx), 0, st, s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill);
     } else {
         // edge columns over all rows: sendbuf = [my W edge | my E edge], recvbuf = [east ghost | west ghost].
         // The W edge goes to the west neighbour (it is their east ghost), the E edge to the east one.
         const size_t cnt = (size_t)nf * (s.nyl + 2);
         c->sendW = c->sendbuf; c->sendE = c->sendbuf + cnt;
         c->recvE = c->recvbuf; c->recvW = c->recvbuf + cnt;
-        hipLaunchKernelGGL(k_ew_pack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, c->sendW, c->sendE);
+        hipLaunchKernelGGL(k_ew_pack, dim3(grow), dim3(tx), 0, st, s, f, nf, c->sendW, c->sendE);
         if (c->nranks == 1 && !c->comm) {   // forced exchange with myself (cyclic): my W edge is my own east ghost
             if (c->west >= 0) {
-                HIPCHK(c, hipMemcpyAsync(c->recvE, c->sendW, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(c, hipMemcpyAsync(c->recvW, c->sendE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->recvE, c->sendW, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(c->recvW, c->sendE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
             }
         } else {
-            if (xp_ring(c, c->sendW, cnt, c->sendE, cnt, c->recvE, cnt, c->recvW, cnt)) return 1;
+            if (xp_ring(c, c->sendW, cnt, c->sendE, cnt, c->recvE, cnt, c->recvW, cnt, st)) return 1;
         }
-        hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, c->stream, s, f, nf, (const double *)c->recvW,
+        hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, st, s, f, nf, (const double *)c->recvW,
                            (const double *)c->recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
     }
     HIPCHK(c, hipGetLastError());
@@ -637,8 +641,9 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         int least = 0, greatest = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
-        // (single rank: stream2 carries the first tripole band launch beside the main launch -- few, short, urgent)
-        HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, g->nranks > 1 ? least : greatest));
+        // (tripole: stream2 carries the band launches and folds beside the main launch -- few, short, urgent)
+        HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking,
+                                              (g->nranks > 1 && g->ns_boundary != EVPK_BND_TRIPOLE) ? least : greatest));
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->evB0, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->evB1, hipEventDisableTiming));
@@ -1183,19 +1188,23 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
         const bool pair_inside = c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
-        // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: only on a single rank, where
-        // the second band launch is then the LAST variant of k_subcycle)
-        const bool pair_ends_evp = c->use_double && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte) && (!c->band_mode || !c->zone_mode);
+        // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
+        // the LAST variant of k_subcycle)
+        const bool pair_ends_evp = c->use_double && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte);
         if (pair_inside || pair_ends_evp) {
             a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             // tripole: rows next to the fold are redone one subcycle at a time with the fold in between
             //   band 1: T rows nyl-2..nyl+1, U rows nyl-2..nyl   state `sr` -> scratch;  fold(scratch)
             //   band 2: T rows nyl-1..nyl+1, U rows nyl-1..nyl   scratch -> state `sw`;  fold(sw)
-            // On a single rank the main launch leaves rows >= nyl-1 to the bands (jmax) and writes its own E-W ghost images,
-            // so the whole band sequence -- band 1, fold, band 2, fold -- runs beside it on stream2.
+            // The main launch leaves rows >= nyl-1 to the bands (jmax), and nothing the band sequence -- band 1, fold, band 2,
+            // fold -- reads or writes is touched by it (single rank: the main launch writes its own E-W ghost images;
+            // x-slabs: those come with the ghost-zone exchange after both), so the sequence runs beside it on stream2.
+            if (c->zone_mode && c->zone_left < 1) {         // (a one-subcycle launch or a partial call came before)
+                if (join()) FAIL(c, "hipStreamWaitEvent failed");
+                if (zone_exchange(a.sr)) return 1;
+            }
             SubArgs b1 = a, b2 = a;
-            const bool band_ahead = c->band_mode && !c->zone_mode;
             auto launch_band = [&](const SubArgs &bb, hipStream_t st, bool last = false) {
                 const dim3 g((((c->ncx + 3) / 4 + 7) / 8) * 8), b(256);
                 if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, st, bb);
@@ -1208,20 +1217,15 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
                 b2 = b1;
                 b2.R = 3; b2.jb0 = s.nyl - 1; b2.sr = F_STATE2; b2.sw = a.sw;
-                if (band_ahead) {
-                    HIPCHK(c, hipEventRecord(c->evB0, c->stream));          // the previous pair is complete
-                    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evB0, 0));
-                    launch_band(b1, c->stream2);
-                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, c->stream2, false, a.sr + S_U)) return 1;
-                    launch_band(b2, c->stream2, pair_ends_evp);
-                    if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, c->stream2, false, F_STATE2 + S_U, s.nyl - 1)) return 1;
-                    HIPCHK(c, hipEventRecord(c->evB1, c->stream2));
-                    a.jmax = s.nyl - 2;
-                }
-            }
-            if (c->zone_mode && c->zone_left < 1) {         // (a one-subcycle launch or a partial call came before)
-                if (join()) FAIL(c, "hipStreamWaitEvent failed");
-                if (zone_exchange(a.sr)) return 1;
+                HIPCHK(c, hipEventRecord(c->evB0, c->stream));          // the previous pair (and its exchange) is complete
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evB0, 0));
+                launch_band(b1, c->stream2);
+                if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, c->stream2, false, a.sr + S_U)) return 1;
+                launch_band(b2, c->stream2, pair_ends_evp);
+                // (x-slabs: the ghost-zone exchange after the pair delivers the E-W ghost columns of the new state, all rows)
+                if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, c->stream2, c->zone_mode, F_STATE2 + S_U, s.nyl - 1)) return 1;
+                HIPCHK(c, hipEventRecord(c->evB1, c->stream2));
+                a.jmax = s.nyl - 2;
             }
             // x-slabs: the launch that uses up the zones runs its edge strips first on `stream`, followed by the exchange
             // of the edge columns there, while the interior strips run on `stream2`
@@ -1258,16 +1262,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
                 HIPCHK(c, hipEventRecord(c->evE, c->stream));
                 evE_valid = true;
             }
-            if (c->band_mode) {
-                if (!band_ahead) {
-                    launch_band(b1, c->stream);
-                    if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, nullptr, false, a.sr + S_U)) return 1;
-                    launch_band(b2, c->stream);
-                    // (x-slabs: the ghost-zone exchange below delivers the E-W ghost columns of the new state, all rows)
-                    if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, nullptr, c->zone_mode, F_STATE2 + S_U)) return 1;
-                } else
-                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
-            }
+            if (c->band_mode) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
             c->ksub += 2;
             n += 2;
             c->cur ^= 1;
