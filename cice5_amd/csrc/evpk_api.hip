@@ -428,14 +428,8 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
                 if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double), st)) return 1;
             } else
                 HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, st));
-            for (int r = 0; r < c->nranks; r++) {
-                const int w = c->slab_i0[r + 1] - c->slab_i0[r];
-                for (int q = 0; q < nf; q++)
-                    for (int rr = 0; rr < 2; rr++)
-                        HIPCHK(c, hipMemcpyAsync(c->foldbuf + ((size_t)q * 2 + rr) * s.nxg + (c->slab_i0[r] - 1),
-                                                 c->foldall + r * seg + ((size_t)q * 2 + rr) * c->wmax,
-                                                 sizeof(double) * w, hipMemcpyDeviceToDevice, st));
-            }
+            hipLaunchKernelGGL(k_fold_repack, dim3((s.nxg + tx - 1) / tx), dim3(tx), 0, st, nf, c->max_nf, c->nranks, c->wmax, s.nxg,
+                               (const int *)c->d_slab_i0, (const double *)c->foldall, c->foldbuf);
         }
         hipLaunchKernelGGL(k_fold_apply, dim3(gcol), dim3(tx), 0, st, s, f, nf, (const double *)c->foldbuf,
                            (necorner && !stress_mode) ? 1 : 0, (vector && !stress_mode) ? -1.0 : 1.0);
@@ -490,13 +484,8 @@ static int halo_stress12(evpk_ctx *c, int f0) {
             if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
         } else
             HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
-        for (int r = 0; r < c->nranks; r++) {
-            const int w = c->slab_i0[r + 1] - c->slab_i0[r];
-            for (int q = 0; q < nf; q++)
-                HIPCHK(c, hipMemcpyAsync(c->foldbuf + ((size_t)q * 2 + 1) * s.nxg + (c->slab_i0[r] - 1),
-                                         c->foldall + r * seg + ((size_t)q * 2 + 1) * c->wmax,
-                                         sizeof(double) * w, hipMemcpyDeviceToDevice, c->stream));
-        }
+        hipLaunchKernelGGL(k_fold_repack, dim3((s.nxg + tx - 1) / tx), dim3(tx), 0, c->stream, nf, c->max_nf, c->nranks, c->wmax, s.nxg,
+                           (const int *)c->d_slab_i0, (const double *)c->foldall, c->foldbuf);
     }
     hipLaunchKernelGGL(k_fold_apply_stress12, dim3(gcol), dim3(tx), 0, c->stream, s, f0, (const double *)c->foldbuf);
     HIPCHK(c, hipGetLastError());
@@ -779,6 +768,8 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         if (g->ns_boundary == EVPK_BND_TRIPOLE) {
             HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
             HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax * g->nranks));
+            HIPCHK(c, hipMalloc(&c->d_slab_i0, sizeof(int) * (g->nranks + 1)));
+            HIPCHK(c, hipMemcpy(c->d_slab_i0, c->slab_i0.data(), sizeof(int) * (g->nranks + 1), hipMemcpyHostToDevice));
         }
     } else {
         c->slab_i0 = {1, g->nx_global + 1};
@@ -786,6 +777,8 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         if (c->force_exchange && g->ns_boundary == EVPK_BND_TRIPOLE) {
             HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
             HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+            HIPCHK(c, hipMalloc(&c->d_slab_i0, sizeof(int) * 2));
+            HIPCHK(c, hipMemcpy(c->d_slab_i0, c->slab_i0.data(), sizeof(int) * 2, hipMemcpyHostToDevice));
         }
     }
 

@@ -496,6 +496,17 @@ __global__ void k_fold_pack(Slab s, int f, int nf, double *fb, int gofs /* globa
     }
 }
 
+// x-slabs: the all-gathered segments [rank][nfmax*2][wmax] -> the global fold buffer [nf*2][nxg] (one launch instead of
+// nranks x nf x 2 small copies).  i0[r] = first global column of rank r, i0[nranks] = nxg + 1.
+__global__ void k_fold_repack(int nf, int nfmax, int nranks, int wmax, int nxg, const int *i0, const double *all, double *fb) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (g > nxg) return;
+    int r = 0;
+    while (r + 1 < nranks && g >= i0[r + 1]) r++;
+    const size_t seg = (size_t)nfmax * 2 * wmax;
+    for (int q = 0; q < nf * 2; q++) fb[(size_t)q * nxg + (g - 1)] = all[(size_t)r * seg + (size_t)q * wmax + (g - i0[r])];
+}
+
 // u-fold copy-out (serial/ice_boundary.F90:801-888, copy lists :3752-3776)
 //   center  : ghost(i,ny+1) = sgn*B2(nx-g+1)
 //   NEcorner: top(i,ny) = sgn*sym(B2)(nx-g), ghost(i,ny+1) = sgn*B1(nx-g), index 0 -> nx
