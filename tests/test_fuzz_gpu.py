@@ -19,7 +19,7 @@ MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH
 
 
 def _config(seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + int(os.environ.get("EVPK_FUZZ_BASE", "0")))
     if os.environ.get("EVPK_FUZZ_BIG"):          # many strip columns / rows: the strip-height tuner, several rounds of workgroups
         nx = int(rng.choice([733, 1000, 1464, 2048]))
         ny = int(rng.choice([257, 400, 701]))
