@@ -54,6 +54,7 @@ def parse():
 
 
 def main():
+    t_start = time.perf_counter()
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -140,6 +141,7 @@ def main():
 
     if a.calib:
         ctx.calibrate(a.calib)
+    t_setup = time.perf_counter() - t_start
     for _ in range(a.warmup):
         step()
     fence()
@@ -210,9 +212,12 @@ def main():
                      "other_kernel": {"name": "k_subcycle", "launches": int(k1_n), "avg_launch_ms": k1_ms / max(k1_n, 1)}},
     }
 
+    t_cpu = time.perf_counter()
     if rank == 0 and world == 1 and a.cpu_subcycles > 0:
         solver.init_evp(a.dt)          # the host arrays are still the uploaded inputs; state back at rest
         out["cpu_baseline"] = cpu_baseline(d, f, a, xmin)
+    t_cpu = time.perf_counter() - t_cpu
+    t_extra = time.perf_counter()
     # (profiling runs pass --cpu-subcycles 0 and skip both extras, so that their traces hold the timed workload only)
     if world == 1 and a.ns == "open" and a.cpu_subcycles > 0 and not a.no_tripole_variant:
         # informational: the same grid closed by the tripole fold at the north (BASELINE config 5's boundary; two extra
@@ -228,6 +233,10 @@ def main():
             out["config"]["evp_incl_pcie_ms"] = evp_incl_pcie(d, f, a, xmin, local_rank)
         except Exception as e:
             out["config"]["evp_incl_pcie_ms"] = {"error": str(e)[:200]}
+    # where the wall time of this process went (the timed region is `steps` x ms_per_step; the rest is imports, synthetic
+    # inputs, context creation, warm-up, the CPU baseline and the informational extras)
+    out["wall_s"] = {"setup_imports_inputs_create_upload": t_setup, "timed_steps": dt_wall, "cpu_baseline": t_cpu,
+                     "extras_tripole_and_pcie": time.perf_counter() - t_extra, "total": time.perf_counter() - t_start}
     # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would otherwise surface AFTER
     # the JSON line at exit: flush it first so that the JSON line is the last line of stdout
     try:
