@@ -148,6 +148,7 @@ struct evpk_ctx {
     hipEvent_t evI = nullptr, evX = nullptr;
     int *d_strips2e = nullptr, *d_strips2i = nullptr;
     int *d_band = nullptr;           // strips 0..ncx-1 of a one-band launch (tripole top band)
+    bool strips1_valid = false;      // d_strips / nstrips (one-subcycle kernel) match the masks of the last prep
     bool band_mode = false;          // tripole + k_subcycle2: the top rows are redone with two one-subcycle band launches
     int nstrips2e = 0, nstrips2i = 0;
     bool overlap = true;
@@ -683,7 +684,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     c->nry = (s.nyl + 1 + c->R - 1) / c->R;
     HIPCHK(c, hipMalloc(&c->d_flags, (size_t)c->ncx * c->nry));
     HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * (size_t)c->ncx * c->nry));
-    HIPCHK(c, hipMalloc(&c->d_counts, sizeof(unsigned long long) * 2));
+    HIPCHK(c, hipMalloc(&c->d_counts, sizeof(unsigned long long) * 4));
     c->ncx2 = (s.nxl + STRIP2_W - 1) / STRIP2_W;
     {
         const size_t n2 = (size_t)((s.nxl + 2 * (ZW_MAX - 2) + STRIP2_W - 1) / STRIP2_W) * (s.nyl + 2);   // any strip height >= 1, any zone width
@@ -990,6 +991,28 @@ static int tune_R2(evpk_ctx *c) {
     return 0;
 }
 
+// Strip list of the one-subcycle kernel (and, when the two-subcycle kernel is off, the active-cell counts): flags on the
+// device, compaction on the host.  Called by evpk_prep when only that kernel exists, else on first use after a prep.
+static int strips1(evpk_ctx *c) {
+    if (c->strips1_valid) return 0;
+    Slab &s = c->s;
+    const int ns_tot = c->ncx * c->nry;
+    unsigned long long *d_cnt = c->use_double ? c->d_counts + 2 : c->d_counts;      // (the counts of prep stay untouched)
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * 2, c->stream));
+    hipLaunchKernelGGL(k_strip_flags, dim3((ns_tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx, c->nry, c->R, c->d_flags, d_cnt);
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned char> flags(ns_tot);
+    HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags, ns_tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> list;
+    list.reserve(ns_tot);
+    for (int k = 0; k < ns_tot; k++) if (flags[k]) list.push_back(k);
+    c->nstrips = (int)list.size();
+    if (c->nstrips) HIPCHK(c, hipMemcpy(c->d_strips, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+    c->strips1_valid = true;
+    return 0;
+}
+
 extern "C" int evpk_prep(evpk_ctx *c) {
     if (!c) return 1;
     if (!c->uploaded) FAIL(c, "evpk_upload has not been called");
@@ -1057,29 +1080,22 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         c->zone_left = c->zM;
         c->inner_ok = true;
     }
-    // active strips
-    const int ns_tot = c->ncx * c->nry;
+    // active strips.  The list of the one-subcycle kernel is only built when that kernel is going to run (odd ndte, EVPK_DOUBLE=0,
+    // a partial evpk_subcycle call): strips1() below; the cell counts then come from the two-subcycle kernel's flag pass.
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * 2, c->stream));
-    hipLaunchKernelGGL(k_strip_flags, dim3((ns_tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx, c->nry, c->R, c->d_flags, c->d_counts);
-    HIPCHK(c, hipGetLastError());
+    c->strips1_valid = false;
+    if (!c->use_double && strips1(c)) return 1;
     if (c->use_double && tune_R2(c)) return 1;
     const int ns_tot2 = c->ncx2 * c->nry2;
     std::vector<unsigned char> flags2(c->use_double ? ns_tot2 : 0);
+    unsigned long long cnt[2] = {0, 0};
     if (c->use_double) {
         hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry2, c->R2,
-                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, G, c->d_flags2, (unsigned int *)nullptr);
+                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, G, c->d_flags2, (unsigned int *)nullptr, c->d_counts);
         HIPCHK(c, hipMemcpyAsync(flags2.data(), c->d_flags2, ns_tot2, hipMemcpyDeviceToHost, c->stream));
     }
-    std::vector<unsigned char> flags(ns_tot);
-    unsigned long long cnt[2];
-    HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags, ns_tot, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<int> list;
-    list.reserve(ns_tot);
-    for (int k = 0; k < ns_tot; k++) if (flags[k]) list.push_back(k);
-    c->nstrips = (int)list.size();
-    if (c->nstrips) HIPCHK(c, hipMemcpyAsync(c->d_strips, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, c->stream));
     std::vector<int> list2;
     if (c->use_double) {
         for (int k = 0; k < ns_tot2; k++) if (flags2[k]) list2.push_back(k);
@@ -1272,6 +1288,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         }
         if (join()) FAIL(c, "hipStreamWaitEvent failed");
         if (c->zone_mode && !c->inner_ok && zone_exchange(a.sr)) return 1;
+        if (strips1(c)) return 1;
         c->ksub++;
         n++;
         a.strips = c->d_strips; a.nstrips = c->nstrips; a.ncx = c->ncx; a.wrap = wrap ? 1 : 0;

@@ -1560,7 +1560,9 @@ template __global__ void k_subcycle2<true, true>(SubArgs);
 
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
-__global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, unsigned char *flags, unsigned int *count) {
+// cells: if given, also counts the active T / U cells on the physical cells each strip owns (icellt, icellu of the rank)
+__global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, unsigned char *flags, unsigned int *count,
+                               unsigned long long *cells = nullptr) {
     const int sid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (sid >= ncx * nry) return;
@@ -1571,13 +1573,23 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
     if (cyc) { ci = (c - 1) % s.nxl; if (ci < 0) ci += s.nxl; ci += 1; ok = true; }
     else ok = (c >= -G && c <= s.nxl + 2 + G);
     const int jb = ry * R + 1;
-    int any = 0;
+    int any = 0, nt = 0, nu = 0;
+    const bool owned = (lane >= 1 && lane <= STRIP2_W && c >= 1 && c <= s.nxl);
     if (ok)
         for (int r = jb - 1; r <= jb + R + 1; r++) {
             if (r < 1 || r > s.nyl + 1) continue;
-            if (s.cmask[mcell(s, ci, r)]) any = 1;
+            const unsigned char m = s.cmask[mcell(s, ci, r)];
+            if (m) any = 1;
+            if (owned && r >= jb && r < jb + R && r <= s.nyl) { nt += (m & CM_T) ? 1 : 0; nu += (m & CM_U) ? 1 : 0; }
         }
     const unsigned long long b = __ballot(any);
+    if (cells) {
+        for (int o = 32; o > 0; o >>= 1) { nt += __shfl_down(nt, o); nu += __shfl_down(nu, o); }
+        if (lane == 0) {
+            if (nt) atomicAdd(&cells[0], (unsigned long long)nt);
+            if (nu) atomicAdd(&cells[1], (unsigned long long)nu);
+        }
+    }
     if (lane == 0) {
         if (flags) flags[sid] = b ? 1 : 0;
         if (count && b) atomicAdd(count, 1u);
