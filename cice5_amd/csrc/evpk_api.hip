@@ -1105,10 +1105,11 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         // lane 0 of strip cx sits at column x0 = cx*61 - G, the strip reads x0-1 .. x0+63 and stores x0+1 .. x0+61.
         // The edge strips run first, the interior overlaps the exchange.
         std::vector<int> le, li;
-        for (int k : list2) {
-            const int x0 = (k % c->ncx2) * STRIP2_W - G;
-            if (x0 >= c->zW && x0 <= s.nxl - c->zW - STRIP2_W) li.push_back(k); else le.push_back(k);
-        }
+        if (c->zone_mode && c->overlap && !c->band_mode)       // (only the split launches of x-slabs use the two lists)
+            for (int k : list2) {
+                const int x0 = (k % c->ncx2) * STRIP2_W - G;
+                if (x0 >= c->zW && x0 <= s.nxl - c->zW - STRIP2_W) li.push_back(k); else le.push_back(k);
+            }
         c->nstrips2e = (int)le.size(); c->nstrips2i = (int)li.size();
         if (c->nstrips2e) HIPCHK(c, hipMemcpyAsync(c->d_strips2e, le.data(), sizeof(int) * le.size(), hipMemcpyHostToDevice, c->stream));
         if (c->nstrips2i) HIPCHK(c, hipMemcpyAsync(c->d_strips2i, li.data(), sizeof(int) * li.size(), hipMemcpyHostToDevice, c->stream));
