@@ -199,7 +199,7 @@ def main():
                    "strips_per_launch_rank0": int(st.nstrips2 or st.nstrips),
                    "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows), "transport": transport,
                    "ghost_zone_cols": int(st.zone_cols), "zone_exchanges_per_evp": int(st.zone_exchanges),
-                   "zone_bytes_sent_rank0": int(st.zone_bytes), "step": "prep + ndte x (stress+stepu, halo) + finish"},
+                   "zone_bytes_sent_rank0": int(st.zone_bytes), "overlap_split_rank0": int(st.overlap_split), "step": "prep + ndte x (stress+stepu, halo) + finish"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,

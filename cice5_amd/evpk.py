@@ -70,7 +70,8 @@ class Stats(ct.Structure):
                 ("loop_ms", ct.c_float), ("kernel_ms", ct.c_float), ("kernel_launches", ct.c_int32),
                 ("kernel2_ms", ct.c_float), ("kernel2_launches", ct.c_int32),
                 ("strip_rows", ct.c_int32), ("strip_rows2", ct.c_int32), ("nstrips2", ct.c_int32),
-                ("zone_cols", ct.c_int32), ("zone_exchanges", ct.c_int32), ("zone_bytes", ct.c_int64)]
+                ("zone_cols", ct.c_int32), ("zone_exchanges", ct.c_int32), ("zone_bytes", ct.c_int64),
+                ("overlap_split", ct.c_int32), ("reserved_", ct.c_int32)]
 
 
 EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",

@@ -140,6 +140,9 @@ typedef struct {
     int32_t zone_cols;                 /* x-slabs: ghost-zone width per side (2 x launches per exchange); 0 = no ghost zones */
     int32_t zone_exchanges;            /* ghost-zone exchanges with the slab neighbours in the last evpk_subcycle call */
     int64_t zone_bytes;                /* bytes this rank sent in them */
+    int32_t overlap_split;             /* x-slabs: 1 the exchange launches are split into edge + interior strips on two streams, 0 whole
+                                          launches, -1 still trying both (first three evps; EVPK_OVERLAP fixes it) */
+    int32_t reserved_;
 } evpk_stats;
 
 /* rank 0 creates the RCCL id; the host model broadcasts the bytes (MPI_Bcast in CICE,
