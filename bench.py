@@ -2,10 +2,11 @@
 """bench.py -- EVP subcycle throughput on N MI355X of one node.
 
 Metric (BASELINE.json): EVP subcycle cell-updates/s + % HBM roofline, 3600x2700, ndte=120.
-A step = one device-resident evp(dt): evp_prep1/2 + ndte x (fused stress+stepu kernel,
-velocity halo) + evp_finish, inputs already in HBM.  N > 1 shards the SAME grid into x-slabs
-(one ice_blocks block of 450x2700 per eighth of the grid), i.e. strong scaling, with the
-per-subcycle halo exchange over RCCL.
+Workload: BASELINE config 5's grid and boundary -- 3600x2700, ns_boundary_type = 'tripole' (the only 3600x2700 entry of
+BASELINE.json's configs is the tripolar one) -- at the metric's ndte = 120.  A step = one device-resident evp(dt):
+evp_prep1/2 + ndte x (fused stress+stepu kernel, velocity halo / tripole fold) + stress folds + evp_finish, inputs
+already in HBM.  N > 1 shards the SAME grid into x-slabs (one ice_blocks block column of 450x2700 per eighth of the
+grid), i.e. strong scaling, with the halo exchange between the ranks' libevpk contexts.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -13,6 +14,7 @@ per-subcycle halo exchange over RCCL.
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,9 +26,9 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-ALG_BYTES_STRESS = 360      # 24 reads + 21 writes, fp64
+ALG_BYTES_STRESS = 360      # 24 reads + 21 writes, fp64 -- the reference's UNFUSED per-subcycle traffic
 ALG_BYTES_STEPU = 232       # 23 reads + 6 writes
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s is what a streaming copy reaches)
 
 
 def parse():
@@ -39,18 +41,39 @@ def parse():
     ap.add_argument("--dt", type=float, default=450.0)
     ap.add_argument("--ice", default="polar", choices=["polar", "full"])
     ap.add_argument("--land", default="continents", choices=["continents", "rows"])
-    ap.add_argument("--ns", default="open", choices=["open", "tripole"])
+    ap.add_argument("--ns", default="tripole", choices=["open", "tripole"])
     ap.add_argument("--xblocks", type=int, default=8, help="blocks across x (one slab each at 8 GPUs)")
     ap.add_argument("--yblocks", type=int, default=10, help="blocks across y")
     ap.add_argument("--cpu-subcycles", type=int, default=120, help="subcycles of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"],
-                    help="shm: host-staged shared-memory relay (functional check of the multi-rank path on one GPU, not a measurement)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm", "ipc"],
+                    help="rccl: ncclSend/ncclRecv over xGMI (the measurement); ipc: peer-mapped buffers; shm: host-staged "
+                         "shared-memory relay (functional check of the multi-rank path on one GPU, never a measurement)")
     ap.add_argument("--calib", type=int, default=0, help="untimed calibration copies for rocprofv3 --pmc runs")
-    ap.add_argument("--no-tripole-variant", action="store_true",
-                    help="skip the informational run of the same grid with ns_boundary_type='tripole' (N = 1, default flags only)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the informational extras (same grid with ns_boundary_type='open', PCIe-inclusive evp; N = 1 only)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per k_subcycle launch from a separate rocprofv3 --pmc pass (profiles/)")
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
     return ap.parse_args()
+
+
+def source_sha():
+    """identifies the kernel build a PMC pass was made with: the three sources libevpk.so is compiled from"""
+    h = hashlib.sha256()
+    for n in ("evpk_kernels.hip", "evpk_api.hip", "evpk_internal.h"):
+        h.update(open(os.path.join(ROOT, "cice5_amd", "csrc", n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def fused_bytes(icellt, icellu, st, revp, two_subcycles):
+    """Bytes one launch of the fused kernel MUST move (fp64, each distinct array element once, perfect stencil reuse):
+    per active T cell: 12 sigma read + 12 written, the (tinyarea, strength) pair, the metrics the variant reads -- the
+    (HTN, HTE) pair with compact metrics, else the four pairs cxp/cyp, cxm/cym, dxt/dyt, dxhy/dyhx -- the (u, v) pair and
+    the mask byte; per active U cell: the four stepu input pairs (vrelc/uarear, uocn/vocn, forcex/forcey, umassdti/fm),
+    (u, v) written, + the uvel_init pair under revised EVP.  The two-subcycle kernel moves this ONCE per two subcycles."""
+    metrics = 16 if (st.compact_metrics and two_subcycles) else 64
+    per_t = 12 * 8 * 2 + 16 + metrics + 16 + 1
+    per_u = 4 * 16 + 16 + (16 if revp else 0)
+    return per_t * icellt + per_u * icellu
 
 
 def main():
@@ -64,7 +87,7 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this pool
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL / IPC handles across processes need dmabuf IPC on this pool
     import torch
     import torch.distributed as dist
     from cice5_amd import blocks, constants as C, dyn, evpk, synth
@@ -74,18 +97,31 @@ def main():
     if os.environ.get("EVPK_FORCE_DEVICE") is not None:      # debugging only: several ranks on one GPU
         local_rank = int(os.environ["EVPK_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
-    uid = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # torch.distributed is only the control plane here (rendezvous, barrier, scalar reductions, the 128-byte
-        # RCCL id): gloo on CPU tensors.  The data plane is libevpk's own RCCL communicator (ncclSend/ncclRecv over xGMI).
+        # unique id): gloo on CPU tensors.  The data plane is libevpk's own transport (ncclSend/ncclRecv over xGMI).
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        if a.transport == "shm":
-            box = [(b"EVPKSHM:evpk_bench_%d" % os.getpid()).ljust(128, b"\0") if rank == 0 else None]
-        else:
-            box = [evpk.get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+
+    def all_ok(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t[0]) == 1
+
+    def fail(stage, err):
+        """A failed start is a failed measurement: no fallback to a slower transport under the same metric name."""
+        if world > 1:
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            err = "; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e)
+        if rank == 0:
+            print(json.dumps({"metric": "EVP subcycle cell-updates/sec", "value": None, "unit": "cell-updates/s", "n_gpus": world,
+                              "failed": stage, "error": err[:600], "transport_requested": a.transport}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     nx, ny = (int(v) for v in a.grid.split("x"))
     if nx % a.xblocks or a.xblocks % world or ny % a.yblocks:
@@ -93,9 +129,7 @@ def main():
     bsx, bsy = nx // a.xblocks, ny // a.yblocks
     case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[a.ns], land=a.land, ice=a.ice, dt=a.dt, ndte=a.ndte)
     d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=a.ns)
-    t_gen = time.time()
     f = synth.make_block_fields(case, d)
-    t_gen = time.time() - t_gen
     # global_minval(dxt/dyt) of set_evp_parameters: local minimum, then MIN over ranks
     xmin = dyn.local_min_dx(f, d)
     if world > 1:
@@ -103,35 +137,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         xmin = float(t[0])
 
-    transport = a.transport if world > 1 else "none"
+    # two-phase start: every rank checks its device and creates its context WITHOUT touching the others; only when all
+    # of them succeeded do the ranks enter the collective part (communicator / peer mapping)
+    err = evpk.device_check(local_rank)
+    if not all_ok(err is None):
+        fail("device check", err)
+    solver, err = None, None
     try:
-        solver, err = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=local_rank, unique_id=uid), ""
+        solver = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=local_rank, defer_connect=(world > 1))
     except evpk.EvpkError as e:
-        solver, err = None, str(e)
+        err = str(e)
+    if not all_ok(solver is not None):
+        fail("evpk_create", err)
     if world > 1:
-        # every rank must end up on the same transport: if RCCL could not be brought up anywhere, all ranks fall back to
-        # the host-staged shared-memory relay (correct, slow) instead of losing the run
-        okv = torch.tensor([1 if solver is not None else 0], dtype=torch.int32)
-        dist.all_reduce(okv, op=dist.ReduceOp.MIN)
-        if int(okv[0]) == 0:
-            if a.transport == "shm":
-                raise SystemExit(f"rank {rank}: evpk_create failed: {err}")
-            if solver is not None:
-                solver.close()
-            box = [(b"EVPKSHM:evpk_bench_fb_%d" % os.getpid()).ljust(128, b"\0") if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            solver = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=local_rank, unique_id=box[0])
-            transport = "shm relay (fallback: RCCL communicator could not be created" + (": " + err[:200] if err else "") + ")"
-    elif solver is None:
-        raise SystemExit("evpk_create failed: " + err)
+        tag = b"evpk_bench_%d" % os.getpid()
+        box = [{"rccl": lambda: evpk.get_unique_id(), "shm": lambda: (b"EVPKSHM:" + tag).ljust(128, b"\0"),
+                "ipc": lambda: (b"EVPKIPC:" + tag).ljust(128, b"\0")}[a.transport]() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        try:
+            solver.connect(box[0])
+        except evpk.EvpkError as e:
+            err = str(e)
+        if not all_ok(err is None):
+            fail("evpk_connect (" + a.transport + ")", err)
     solver.init_evp(a.dt)
     ctx = solver.ctx
     ctx.upload(f)                       # inputs resident in HBM from here on
-
-    def step():
-        ctx.prep()
-        ctx.subcycle(a.ndte)
-        ctx.finish()
 
     def fence():
         ctx.sync()
@@ -142,22 +173,10 @@ def main():
     if a.calib:
         ctx.calibrate(a.calib)
     t_setup = time.perf_counter() - t_start
-    for _ in range(a.warmup):
-        step()
-    fence()
-    loop_ms, k1_ms, k1_n, k2_ms, k2_n = 0.0, 0.0, 0, 0.0, 0
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        st = ctx.stats()                # HIP events on the library's compute stream: the ndte loop and every kernel launch
-        loop_ms += st.loop_ms
-        k1_ms += st.kernel_ms; k1_n += st.kernel_launches
-        k2_ms += st.kernel2_ms; k2_n += st.kernel2_launches
-    fence()
-    dt_wall = time.perf_counter() - t0
-    st = ctx.stats()
+    r = timed_steps(ctx, a.ndte, a.steps, a.warmup, fence)
+    st = r["stats"]
 
-    vals = torch.tensor([dt_wall, loop_ms, k1_ms, k2_ms, float(st.icellt), float(st.icellu)], dtype=torch.float64)
+    vals = torch.tensor([r["wall_s"], r["loop_ms"], r["k1_ms"], r["k2_ms"], float(st.icellt), float(st.icellu)], dtype=torch.float64)
     if world > 1:
         tmax = vals[:4].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -166,29 +185,30 @@ def main():
         dt_wall, loop_ms, k1_ms, k2_ms = (float(v) for v in tmax)
         icellt, icellu = float(tsum[0]), float(tsum[1])
     else:
+        dt_wall, loop_ms, k1_ms, k2_ms = r["wall_s"], r["loop_ms"], r["k1_ms"], r["k2_ms"]
         icellt, icellu = float(st.icellt), float(st.icellu)
 
     n_active = 0.5 * (icellt + icellu)                  # one cell-update = one T stress + one U stepu update
-    updates = n_active * a.ndte * a.steps
-    value = updates / dt_wall
-    alg_bytes_sub = (ALG_BYTES_STRESS * icellt + ALG_BYTES_STEPU * icellu) / world   # per GPU per subcycle
-    # dominant kernel: the two-subcycle kernel when it ran (one launch = two subcycles of algorithmic work)
-    if k2_n > 0:
-        k2 = "evpk::k_subcycle2" if os.environ.get("EVPK_PREFETCH") == "0" else "evpk::k_subcycle2p"    # name in the rocprofv3 trace
-        kname, nsub_per_launch, kern_ms, launches = k2 + " (stress+stepu fused, two subcycles per launch)", 2, k2_ms / k2_n, k2_n
-    else:
-        kname, nsub_per_launch, kern_ms, launches = "evpk::k_subcycle (stress+stepu fused)", 1, k1_ms / max(k1_n, 1), k1_n
-    alg_bytes_launch = nsub_per_launch * alg_bytes_sub
-    achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-
-    traffic = a.traffic_bytes
+    value = n_active * a.ndte * a.steps / dt_wall
     workload = (f"{nx}x{ny} ndte={a.ndte} ice={a.ice} land={a.land} ns={a.ns} "
                 f"({a.xblocks * a.yblocks} ice_blocks blocks of {bsx}x{bsy}, x-slabs over {world} GPU)")
-    tfile = os.path.join(ROOT, "profiles", f"traffic_n{world}.json")
-    if traffic is None and os.path.exists(tfile):       # measured in a separate rocprofv3 --pmc pass of this same command
-        t = json.load(open(tfile))
-        if t.get("workload") == workload:
-            traffic = t["hbm_bytes_per_launch"]
+    roof = roofline(r, icellt / world, icellu / world, revp=False)
+    sha = source_sha()
+    traffic, tnote = a.traffic_bytes, "given on the command line" if a.traffic_bytes else None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if traffic is None and os.path.exists(tfile):       # measured in separate rocprofv3 --pmc passes of this same command
+        ent = [e for e in json.load(open(tfile)).get("entries", []) if e.get("workload") == workload]
+        cur = [e for e in ent if e.get("source_sha") == sha]
+        if cur:
+            traffic, tnote = cur[-1]["hbm_bytes_per_launch"], cur[-1].get("profile")
+        elif ent:
+            tnote = f"profiles/traffic.json holds this workload for another kernel build ({ent[-1].get('source_sha')}): not reported"
+    kern_s = roof["avg_launch_ms"] * 1e-3
+    roof.update({"traffic": traffic, "traffic_source": tnote, "source_sha": sha,
+                 "traffic_GBps": (traffic / kern_s / 1e9) if (traffic and kern_s > 0) else None,
+                 "traffic_frac_of_peak": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if (traffic and kern_s > 0) else None,
+                 "traffic_over_alg": (traffic / roof["alg_bytes_per_launch"]) if traffic else None,
+                 "loop_ms_per_step": loop_ms / a.steps})
     out = {
         "metric": "EVP subcycle cell-updates/sec", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_wall / a.steps,
@@ -197,19 +217,12 @@ def main():
                    "active_T_cells": int(icellt), "active_U_cells": int(icellu), "grid_cells": nx * ny,
                    "grid_cell_updates_per_s": nx * ny * a.ndte * a.steps / dt_wall,
                    "strips_per_launch_rank0": int(st.nstrips2 or st.nstrips),
-                   "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows), "transport": transport,
+                   "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows),
+                   "transport": evpk.XP_NAMES.get(int(st.transport), "?") if world > 1 else "none",
                    "ghost_zone_cols": int(st.zone_cols), "zone_exchanges_per_evp": int(st.zone_exchanges),
-                   "zone_bytes_sent_rank0": int(st.zone_bytes), "overlap_split_rank0": int(st.overlap_split), "step": "prep + ndte x (stress+stepu, halo) + finish"},
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic,
-                     # real HBM rate of that kernel: PMC bytes per launch (profiles/) over the launch time measured here
-                     "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
-                     "traffic_frac_of_peak": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
-                     "alg_bytes_per_launch": alg_bytes_launch,
-                     "avg_launch_ms": kern_ms, "launches_timed": int(launches), "subcycles_per_launch": nsub_per_launch,
-                     "loop_ms_per_step": loop_ms / a.steps,
-                     "other_kernel": {"name": "k_subcycle", "launches": int(k1_n), "avg_launch_ms": k1_ms / max(k1_n, 1)}},
+                   "zone_bytes_sent_rank0": int(st.zone_bytes), "overlap_split_rank0": int(st.overlap_split),
+                   "step": "prep + ndte x (stress+stepu, halo / fold) + stress folds + finish"},
+        "roofline": roof,
     }
 
     t_cpu = time.perf_counter()
@@ -218,16 +231,16 @@ def main():
         out["cpu_baseline"] = cpu_baseline(d, f, a, xmin)
     t_cpu = time.perf_counter() - t_cpu
     t_extra = time.perf_counter()
-    # (profiling runs pass --cpu-subcycles 0 and skip both extras, so that their traces hold the timed workload only)
-    if world == 1 and a.ns == "open" and a.cpu_subcycles > 0 and not a.no_tripole_variant:
-        # informational: the same grid closed by the tripole fold at the north (BASELINE config 5's boundary; two extra
-        # band launches + two fold updates per launch pair).  Not part of `value`.
+    # (profiling runs pass --cpu-subcycles 0 and skip the extras, so that their traces hold the timed workload only)
+    if world == 1 and a.cpu_subcycles > 0 and not a.no_variants:
+        # informational, never part of `value`: the same grid closed at the north (ns_boundary_type = 'open': no fold, so
+        # no band launches), timed the same way -- HIP events on the library's stream, same roofline accounting
         solver.close()
         solver = None
         try:
-            out["config"]["tripole_variant"] = tripole_variant(a, nx, ny, bsx, bsy, local_rank)
-        except Exception as e:           # never lose the bench line over the extra
-            out["config"]["tripole_variant"] = {"error": str(e)[:200]}
+            out["config"]["open_variant" if a.ns == "tripole" else "tripole_variant"] = other_boundary(a, nx, ny, bsx, bsy, local_rank)
+        except Exception as e:           # never lose the bench line over an extra
+            out["config"]["open_variant"] = {"error": str(e)[:200]}
         # informational: one whole evp(dt) through evpk_run INCLUDING the PCIe transfers of all arrays (never `value`)
         try:
             out["config"]["evp_incl_pcie_ms"] = evp_incl_pcie(d, f, a, xmin, local_rank)
@@ -236,7 +249,7 @@ def main():
     # where the wall time of this process went (the timed region is `steps` x ms_per_step; the rest is imports, synthetic
     # inputs, context creation, warm-up, the CPU baseline and the informational extras)
     out["wall_s"] = {"setup_imports_inputs_create_upload": t_setup, "timed_steps": dt_wall, "cpu_baseline": t_cpu,
-                     "extras_tripole_and_pcie": time.perf_counter() - t_extra, "total": time.perf_counter() - t_start}
+                     "extras": time.perf_counter() - t_extra, "total": time.perf_counter() - t_start}
     # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would otherwise surface AFTER
     # the JSON line at exit: flush it first so that the JSON line is the last line of stdout
     try:
@@ -250,6 +263,57 @@ def main():
         solver.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def timed_steps(ctx, ndte, steps, warmup, fence):
+    """`warmup` untimed and `steps` timed device-resident evp(dt).  Wall clock around the timed steps (fence = sync +
+    barrier on both sides); per step the library's own HIP events on ITS streams: the whole ndte loop and the sampled
+    kernel launches (torch.cuda.Event would only see torch's current stream)."""
+    def step():
+        ctx.prep()
+        ctx.subcycle(ndte)
+        ctx.finish()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    loop_ms, k1_ms, k1_n, k1_t, k2_ms, k2_n, k2_t = 0.0, 0.0, 0, 0, 0.0, 0, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        st = ctx.stats()
+        loop_ms += st.loop_ms
+        k1_ms += st.kernel_ms; k1_n += st.kernel_launches; k1_t += st.kernel_timed
+        k2_ms += st.kernel2_ms; k2_n += st.kernel2_launches; k2_t += st.kernel2_timed
+    fence()
+    wall = time.perf_counter() - t0
+    return {"wall_s": wall, "loop_ms": loop_ms, "k1_ms": k1_ms, "k1_n": k1_n, "k1_timed": k1_t, "k2_ms": k2_ms, "k2_n": k2_n,
+            "k2_timed": k2_t, "stats": ctx.stats(), "steps": steps}
+
+
+def roofline(r, icellt, icellu, revp):
+    """The dominant kernel against the HBM roofline.  `achieved` = the bytes one launch of the fused kernel must move
+    (fused_bytes) / its average duration, from HIP events around the sampled launches; `frac` = achieved / 8 TB/s.  The
+    SURVEY S8d figure (592 B per cell-update: the reference's unfused traffic, which this kernel never moves) is kept
+    as `effective_vs_reference_accounting`."""
+    st = r["stats"]
+    if r["k2_n"] > 0:
+        base = "evpk::k_subcycle2t" if st.tile_kernel else ("evpk::k_subcycle2" if os.environ.get("EVPK_PREFETCH") == "0" else "evpk::k_subcycle2p")
+        kname, nsub, kern_ms, launches, timed = base + " (stress+stepu fused, two subcycles per launch)", 2, r["k2_ms"] / r["k2_n"], r["k2_n"], r["k2_timed"]
+    else:
+        kname, nsub, kern_ms, launches, timed = "evpk::k_subcycle (stress+stepu fused)", 1, r["k1_ms"] / max(r["k1_n"], 1), r["k1_n"], r["k1_timed"]
+    alg = fused_bytes(icellt, icellu, st, revp, nsub == 2)
+    ref = nsub * (ALG_BYTES_STRESS * icellt + ALG_BYTES_STEPU * icellu)
+    ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "alg_bytes_per_launch": alg, "alg_bytes_per_cell_update": alg / max(0.5 * (icellt + icellu) * nsub, 1.0),
+            "avg_launch_ms": kern_ms, "launches": int(launches), "launches_timed": int(timed), "subcycles_per_launch": nsub,
+            "compact_metrics": int(st.compact_metrics),
+            "effective_vs_reference_accounting": {"bytes_per_cell_update": ALG_BYTES_STRESS + ALG_BYTES_STEPU,
+                                                  "GBps": ref / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
+                                                  "frac_of_peak": ref / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0},
+            "other_kernel": {"name": "k_subcycle (tripole band launches / odd remainder)", "launches": int(r["k1_n"]),
+                             "launches_timed": int(r["k1_timed"]), "avg_launch_ms": r["k1_ms"] / max(r["k1_n"], 1)}}
 
 
 def evp_incl_pcie(d, f, a, xmin, device):
@@ -266,25 +330,29 @@ def evp_incl_pcie(d, f, a, xmin, device):
     return res
 
 
-def tripole_variant(a, nx, ny, bsx, bsy, device):
+def other_boundary(a, nx, ny, bsx, bsy, device):
     from cice5_amd import blocks, constants as C, dyn, synth
-    case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES["tripole"], land=a.land, ice=a.ice, dt=a.dt, ndte=a.ndte)
-    d = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type="tripole")
+    import torch
+    ns = "open" if a.ns == "tripole" else "tripole"
+    case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[ns], land=a.land, ice=a.ice, dt=a.dt, ndte=a.ndte)
+    d = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns)
     f = synth.make_block_fields(case, d)
     s = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=dyn.local_min_dx(f, d), device=device)
     s.init_evp(a.dt)
     s.ctx.upload(f)
-    ts = []
-    for k in range(2 + 3):
-        t = time.perf_counter()
-        s.ctx.prep(); s.ctx.subcycle(a.ndte); s.ctx.finish(); s.ctx.sync()
-        if k >= 2:
-            ts.append(time.perf_counter() - t)
-    st = s.ctx.stats()
+
+    def fence():
+        s.ctx.sync()
+        torch.cuda.synchronize()
+
+    r = timed_steps(s.ctx, a.ndte, 3, 2, fence)
+    st = r["stats"]
+    roof = roofline(r, float(st.icellt), float(st.icellu), revp=False)
     s.close()
-    sec = sum(ts) / len(ts)
-    return {"ns": "tripole", "ms_per_step": 1e3 * sec, "value": 0.5 * (st.icellt + st.icellu) * a.ndte / sec,
-            "active_T_cells": int(st.icellt), "steps": len(ts)}
+    return {"ns": ns, "ms_per_step": 1e3 * r["wall_s"] / r["steps"], "steps": r["steps"],
+            "value": 0.5 * (st.icellt + st.icellu) * a.ndte * r["steps"] / r["wall_s"],
+            "active_T_cells": int(st.icellt), "loop_ms_per_step": r["loop_ms"] / r["steps"],
+            "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_timed", "alg_bytes_per_launch")}}
 
 
 def cpu_baseline(d, f, a, xmin):
@@ -294,11 +362,14 @@ def cpu_baseline(d, f, a, xmin):
     p = orc.make_params(a.dt, a.ndte, xmin)
     threads = orc._limit_threads()
     nt, nu, secs = orc.evp(d, p, f, nsub=a.cpu_subcycles)
-    return {"value": 0.5 * (nt + nu) * a.cpu_subcycles / secs, "unit": "cell-updates/s", "cores": min(threads, d.nblocks),
-            "kind": "port",
+    cores = min(threads, d.nblocks)
+    v = 0.5 * (nt + nu) * a.cpu_subcycles / secs
+    return {"value": v, "unit": "cell-updates/s", "cores": cores, "kind": "port", "per_core": v / cores,
+            "reference_per_core_survey": 1.1e7,
             "sample": f"first {a.cpu_subcycles} of {a.ndte} subcycles of the same {d.nx_global}x{d.ny_global} state "
                       f"({d.nblocks} blocks of {d.block_size_x}x{d.block_size_y}, OpenMP over blocks: "
-                      f"stress + stepu + halo copies), {secs:.2f} s of CPU wall time"}
+                      f"stress + stepu + halo copies), {secs:.2f} s of CPU wall time; reference_per_core_survey = the "
+                      f"reference's own whole evp on gx3, one Xeon core (SURVEY.md S8c)"}
 
 
 if __name__ == "__main__":

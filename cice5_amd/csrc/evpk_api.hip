@@ -115,6 +115,7 @@ struct evpk_ctx {
     Slab s{};
     DevParams p{};
     bool have_params = false, uploaded = false, prepped = false;
+    bool connected = false;     // evpk_connect (or evpk_create with a unique id / one rank) has run
     bool fresh = true;          // state planes were (re)loaded from the host since the last prep
     unsigned char *tile_buf = nullptr;   // 6 tile-flag arrays: ice/dat x {A, B} (new / previous evp, swapped) + act_ice, act_any
     int tile_cur = 0;
@@ -190,7 +191,7 @@ struct evpk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
     float loop_ms = 0.f, kernel_ms = 0.f, kernel2_ms = 0.f;
-    int kernel_launches = 0;
+    int kernel_launches = 0, kernel_timed = 0, kernel2_timed = 0;
     std::vector<char> kev_is_double;
     int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around every 7th subcycle kernel launch (default), 2 all
     std::vector<int> kev_slot;     // launch index -> event pair index, -1 not timed
@@ -365,17 +366,23 @@ static int xp_ring(evpk_ctx *c, const double *sW, size_t nSW, const double *sE, 
         if (rc) FAIL(c, "shared-memory relay: exchange failed (%s)", rc & 2 ? "timeout" : "copy / size");
         return 0;
     }
+    // (a failing call must not leave the thread inside an open group: every later RCCL call, ncclCommDestroy included,
+    // would be queued and never issued -- collect the codes, always close the group, then report)
     NCCLCHK(c, ncclGroupStart());
+    ncclResult_t rc = ncclSuccess;
+    auto keep = [&](ncclResult_t e) { if (rc == ncclSuccess) rc = e; };
     if (merged) {
-        if (nSW + nSE) NCCLCHK(c, ncclSend(sW, nSW + nSE, ncclDouble, c->west, c->comm, st));
-        if (nRE + nRW) NCCLCHK(c, ncclRecv(rE, nRE + nRW, ncclDouble, c->west, c->comm, st));
+        if (nSW + nSE) keep(ncclSend(sW, nSW + nSE, ncclDouble, c->west, c->comm, st));
+        if (nRE + nRW) keep(ncclRecv(rE, nRE + nRW, ncclDouble, c->west, c->comm, st));
     } else {
-        if (c->west >= 0 && nSW) NCCLCHK(c, ncclSend(sW, nSW, ncclDouble, c->west, c->comm, st));
-        if (c->east >= 0 && nSE) NCCLCHK(c, ncclSend(sE, nSE, ncclDouble, c->east, c->comm, st));
-        if (c->east >= 0 && nRE) NCCLCHK(c, ncclRecv(rE, nRE, ncclDouble, c->east, c->comm, st));
-        if (c->west >= 0 && nRW) NCCLCHK(c, ncclRecv(rW, nRW, ncclDouble, c->west, c->comm, st));
+        if (c->west >= 0 && nSW) keep(ncclSend(sW, nSW, ncclDouble, c->west, c->comm, st));
+        if (c->east >= 0 && nSE) keep(ncclSend(sE, nSE, ncclDouble, c->east, c->comm, st));
+        if (c->east >= 0 && nRE) keep(ncclRecv(rE, nRE, ncclDouble, c->east, c->comm, st));
+        if (c->west >= 0 && nRW) keep(ncclRecv(rW, nRW, ncclDouble, c->west, c->comm, st));
     }
-    NCCLCHK(c, ncclGroupEnd());
+    const ncclResult_t rce = ncclGroupEnd();
+    if (rc != ncclSuccess) FAIL(c, "ncclSend/ncclRecv failed: %s", ncclGetErrorString(rc));
+    if (rce != ncclSuccess) FAIL(c, "ncclGroupEnd failed: %s", ncclGetErrorString(rce));
     return 0;
 }
 
@@ -579,6 +586,113 @@ static void destroy_impl(evpk_ctx *c) {
 
 extern "C" int evpk_destroy(evpk_ctx *c) { destroy_impl(c); return 0; }
 
+// ---- second phase of the start: everything that involves the other ranks (collective) ----------------------------
+static int connect_impl(evpk_ctx *c, const void *unique_id) {
+    if (c->connected) FAIL(c, "evpk_connect: the context is connected already");
+    Slab &s = c->s;
+    const int i0 = s.i0, i1 = s.i0 + s.nxl - 1;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    if (c->nranks > 1) {
+        if (!unique_id) FAIL(c, "nranks > 1 needs a unique id (evpk_get_unique_id on rank 0, broadcast by the host)");
+        if (strncmp((const char *)unique_id, "EVPKSHM:", 8) == 0) {
+            // test transport: host-staged relay through POSIX shared memory (several ranks on one GPU)
+            char nm[EVPK_UNIQUE_ID_BYTES + 1];
+            memcpy(nm, (const char *)unique_id + 8, EVPK_UNIQUE_ID_BYTES - 8);
+            nm[EVPK_UNIQUE_ID_BYTES - 8] = 0;
+            const size_t slot = std::max<size_t>((size_t)2 * c->cslot * sizeof(double2),
+                                                 (size_t)c->max_nf * 2 * (size_t)s.nxg * sizeof(double)) + 4096;
+            c->relay = new ShmRelay();
+            std::string err;
+            if (c->relay->open(nm, c->rank, c->nranks, slot, err)) FAIL(c, "%s", err.c_str());
+        } else {
+            ncclUniqueId u;
+            memcpy(&u, unique_id, sizeof(u));
+            NCCLCHK(c, ncclCommInitRank(&c->comm, c->nranks, u, c->rank));
+        }
+        // every rank learns all slab starts (for the tripole fold) : all-gather of i0
+        int *d_i0 = nullptr, *d_all = nullptr;
+        HIPCHK(c, hipMalloc(&d_i0, sizeof(int)));
+        HIPCHK(c, hipMalloc(&d_all, sizeof(int) * c->nranks));
+        HIPCHK(c, hipMemcpyAsync(d_i0, &i0, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if (xp_allgather(c, d_i0, d_all, sizeof(int))) return 1;
+        c->slab_i0.resize(c->nranks + 1);
+        HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * c->nranks, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(d_i0); (void)hipFree(d_all);
+        c->slab_i0[c->nranks] = s.nxg + 1;
+        c->wmax = 0;
+        for (int r = 0; r < c->nranks; r++) {
+            if (c->slab_i0[r + 1] <= c->slab_i0[r]) FAIL(c, "slabs are not ordered west to east by rank");
+            c->wmax = std::max(c->wmax, c->slab_i0[r + 1] - c->slab_i0[r]);
+        }
+        if (c->slab_i0[c->rank] != i0 || c->slab_i0[c->rank + 1] != i1 + 1) FAIL(c, "slabs do not tile the global x range");
+        if (c->ns == EVPK_BND_TRIPOLE) {
+            HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+            HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax * c->nranks));
+            HIPCHK(c, hipMalloc(&c->d_slab_i0, sizeof(int) * (c->nranks + 1)));
+            HIPCHK(c, hipMemcpy(c->d_slab_i0, c->slab_i0.data(), sizeof(int) * (c->nranks + 1), hipMemcpyHostToDevice));
+        }
+    } else {
+        c->slab_i0 = {1, s.nxg + 1};
+        c->wmax = s.nxg;
+        if (c->force_exchange && c->ns == EVPK_BND_TRIPOLE) {
+            HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+            HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+            HIPCHK(c, hipMalloc(&c->d_slab_i0, sizeof(int) * 2));
+            HIPCHK(c, hipMemcpy(c->d_slab_i0, c->slab_i0.data(), sizeof(int) * 2, hipMemcpyHostToDevice));
+        }
+    }
+
+    {   // two subcycles per launch: single rank, no tripole fold between the subcycles (EVPK_DOUBLE=0 disables)
+        const char *e = getenv("EVPK_DOUBLE");
+        // (the choice must be the same on every rank: it decides which exchanges the ranks post)
+        int minw = s.nxl;
+        for (int r = 0; r < c->nranks; r++) minw = std::min(minw, c->slab_i0[r + 1] - c->slab_i0[r]);
+        c->use_double = !(e && atoi(e) == 0) && minw >= 4;
+        if (c->ns == EVPK_BND_TRIPOLE) {
+            // the fold mixes mirrored columns between the two fused subcycles: only the rows next to the fold are affected,
+            // they are redone by band launches (x-slabs: without the edge/interior overlap, the fold all-gathers in between)
+            c->band_mode = c->use_double = c->use_double && s.nyl >= 8;
+        }
+        // ghost-zone depth: zM launches per exchange, zones of 2*zM columns; every slab must be able to supply them
+        const char *zm = getenv("EVPK_ZONE_M");
+        int m = zm ? atoi(zm) : ZW_MAX / 2;
+        m = std::max(1, std::min(m, std::min(ZW_MAX / 2, minw / 2)));
+        if (c->band_mode) m = 1;          // the fold is all-gathered after every subcycle anyway
+        c->zM = m; c->zW = 2 * m;
+        std::vector<int> band(c->ncx);
+        for (int k = 0; k < c->ncx; k++) band[k] = k;
+        HIPCHK(c, hipMalloc(&c->d_band, sizeof(int) * c->ncx));
+        HIPCHK(c, hipMemcpy(c->d_band, band.data(), sizeof(int) * c->ncx, hipMemcpyHostToDevice));
+    }
+    {   // resident workgroups of the two-subcycle kernel variant this context launches (strip-height tuner)
+        int nb = 0;
+        const void *fn = !c->prefetch ? (const void *)k_subcycle2<false, false>
+                                      : (c->compact ? (const void *)k_subcycle2p<false, false, true> : (const void *)k_subcycle2p<false, false, false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0)
+            c->slots2 = nb * prop.multiProcessorCount;
+    }
+    c->connected = true;
+    return 0;
+}
+
+extern "C" int evpk_connect(evpk_ctx *c, const void *unique_id) {
+    if (!c) return 1;
+    return connect_impl(c, unique_id);
+}
+
+extern "C" int evpk_device_check(int32_t device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void)hipGetLastError(); g_create_err = "no HIP device: libevpk has no CPU fallback"; return 1; }
+    if (device < 0 || device >= ndev) { g_create_err = "device " + std::to_string(device) + " out of range (" + std::to_string(ndev) + " devices)"; return 1; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); g_create_err = "hipGetDeviceProperties failed"; return 1; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_create_err = std::string("device is ") + prop.gcnArchName + ", libevpk is built for gfx950 only"; return 1; }
+    return 0;
+}
+
 static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     if (!g) FAIL(c, "geom is NULL");
     if (g->nblocks < 1 || g->nx_block < 3 || g->ny_block < 3) FAIL(c, "bad block shape");
@@ -742,57 +856,6 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         HIPCHK(c, hipMemsetAsync(c->foldbuf, 0, sizeof(double) * (size_t)c->max_nf * 2 * s.nxg, c->stream));
     }
 
-    if (g->nranks > 1) {
-        if (!g->unique_id) FAIL(c, "nranks > 1 needs unique_id");
-        if (strncmp((const char *)g->unique_id, "EVPKSHM:", 8) == 0) {
-            // test transport: host-staged relay through POSIX shared memory (several ranks on one GPU)
-            char nm[EVPK_UNIQUE_ID_BYTES + 1];
-            memcpy(nm, (const char *)g->unique_id + 8, EVPK_UNIQUE_ID_BYTES - 8);
-            nm[EVPK_UNIQUE_ID_BYTES - 8] = 0;
-            const size_t slot = std::max<size_t>((size_t)2 * c->cslot * sizeof(double2),
-                                                 (size_t)c->max_nf * 2 * (size_t)g->nx_global * sizeof(double)) + 4096;
-            c->relay = new ShmRelay();
-            std::string err;
-            if (c->relay->open(nm, g->rank, g->nranks, slot, err)) FAIL(c, "%s", err.c_str());
-        } else {
-            ncclUniqueId u;
-            memcpy(&u, g->unique_id, sizeof(u));
-            NCCLCHK(c, ncclCommInitRank(&c->comm, g->nranks, u, g->rank));
-        }
-        // every rank learns all slab starts (for the tripole fold) : all-gather of i0
-        int *d_i0 = nullptr, *d_all = nullptr;
-        HIPCHK(c, hipMalloc(&d_i0, sizeof(int)));
-        HIPCHK(c, hipMalloc(&d_all, sizeof(int) * g->nranks));
-        HIPCHK(c, hipMemcpyAsync(d_i0, &i0, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        if (xp_allgather(c, d_i0, d_all, sizeof(int))) return 1;
-        c->slab_i0.resize(g->nranks + 1);
-        HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * g->nranks, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(d_i0); (void)hipFree(d_all);
-        c->slab_i0[g->nranks] = g->nx_global + 1;
-        c->wmax = 0;
-        for (int r = 0; r < g->nranks; r++) {
-            if (c->slab_i0[r + 1] <= c->slab_i0[r]) FAIL(c, "slabs are not ordered west to east by rank");
-            c->wmax = std::max(c->wmax, c->slab_i0[r + 1] - c->slab_i0[r]);
-        }
-        if (c->slab_i0[g->rank] != i0 || c->slab_i0[g->rank + 1] != i1 + 1) FAIL(c, "slabs do not tile the global x range");
-        if (g->ns_boundary == EVPK_BND_TRIPOLE) {
-            HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
-            HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax * g->nranks));
-            HIPCHK(c, hipMalloc(&c->d_slab_i0, sizeof(int) * (g->nranks + 1)));
-            HIPCHK(c, hipMemcpy(c->d_slab_i0, c->slab_i0.data(), sizeof(int) * (g->nranks + 1), hipMemcpyHostToDevice));
-        }
-    } else {
-        c->slab_i0 = {1, g->nx_global + 1};
-        c->wmax = g->nx_global;
-        if (c->force_exchange && g->ns_boundary == EVPK_BND_TRIPOLE) {
-            HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
-            HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
-            HIPCHK(c, hipMalloc(&c->d_slab_i0, sizeof(int) * 2));
-            HIPCHK(c, hipMemcpy(c->d_slab_i0, c->slab_i0.data(), sizeof(int) * 2, hipMemcpyHostToDevice));
-        }
-    }
-
     // time-invariant planes
     struct { const double *h; int f; } gp[] = {
         {g->dxt, F_DXT}, {g->dyt, F_DYT}, {g->dxhy, F_DXHY}, {g->dyhx, F_DYHX}, {g->cxp, F_CXP}, {g->cyp, F_CYP},
@@ -823,37 +886,10 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         // (they are divisors in to_ugrid / to_tgrid; the reference never visits them)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    {   // two subcycles per launch: single rank, no tripole fold between the subcycles (EVPK_DOUBLE=0 disables)
-        const char *e = getenv("EVPK_DOUBLE");
-        // (the choice must be the same on every rank: it decides which exchanges the ranks post)
-        int minw = s.nxl;
-        for (int r = 0; r < g->nranks; r++) minw = std::min(minw, c->slab_i0[r + 1] - c->slab_i0[r]);
-        c->use_double = !(e && atoi(e) == 0) && minw >= 4;
-        if (g->ns_boundary == EVPK_BND_TRIPOLE) {
-            // the fold mixes mirrored columns between the two fused subcycles: only the rows next to the fold are affected,
-            // they are redone by band launches (x-slabs: without the edge/interior overlap, the fold all-gathers in between)
-            c->band_mode = c->use_double = c->use_double && s.nyl >= 8;
-        }
-        // ghost-zone depth: zM launches per exchange, zones of 2*zM columns; every slab must be able to supply them
-        const char *zm = getenv("EVPK_ZONE_M");
-        int m = zm ? atoi(zm) : ZW_MAX / 2;
-        m = std::max(1, std::min(m, std::min(ZW_MAX / 2, minw / 2)));
-        if (c->band_mode) m = 1;          // the fold is all-gathered after every subcycle anyway
-        c->zM = m; c->zW = 2 * m;
-        std::vector<int> band(c->ncx);
-        for (int k = 0; k < c->ncx; k++) band[k] = k;
-        HIPCHK(c, hipMalloc(&c->d_band, sizeof(int) * c->ncx));
-        HIPCHK(c, hipMemcpy(c->d_band, band.data(), sizeof(int) * c->ncx, hipMemcpyHostToDevice));
-    }
-    {   // resident workgroups of the two-subcycle kernel variant this context launches (strip-height tuner)
-        int nb = 0;
-        const void *fn = !c->prefetch ? (const void *)k_subcycle2<false, false>
-                                      : (c->compact ? (const void *)k_subcycle2p<false, false, true> : (const void *)k_subcycle2p<false, false, false>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0)
-            c->slots2 = nb * prop.multiProcessorCount;
-    }
     const char *tk = getenv("EVPK_TIME_KERNELS");
     c->time_kernels = tk ? std::max(0, std::min(atoi(tk), 2)) : 1;
+    // a multi-rank context without a unique id stays unconnected until evpk_connect (two-phase start)
+    if (g->nranks == 1 || g->unique_id) return connect_impl(c, g->unique_id);
     return 0;
 }
 
@@ -889,6 +925,7 @@ extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
 extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state *st) {
     if (!c || !in) return 1;
     if (!c->have_params) FAIL(c, "evpk_set_params has not been called");
+    if (!c->connected) FAIL(c, "evpk_connect has not been called (multi-rank context created without a unique id)");
     if (!st && !c->uploaded) FAIL(c, "the first evpk_upload needs the state");
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1146,8 +1183,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     return 0;
 }
 
-extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
-    if (!c) return 1;
+static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     if (!c->prepped) FAIL(c, "evpk_prep has not been called");
     if (nsub < 0) FAIL(c, "nsub < 0");
     Slab &s = c->s;
@@ -1157,6 +1193,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
     c->kernel_ms = 0.f;
     c->kernel2_ms = 0.f;
     c->kernel_launches = 0;
+    c->kernel_timed = c->kernel2_timed = 0;
     c->kev_is_double.assign((size_t)nsub + 1, 0);
     if (c->time_kernels) {
         while ((int)c->kev.size() < 2 * nsub + 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
@@ -1347,8 +1384,20 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
         }
         if (n2) c->kernel2_ms = (float)(sum2 / n2 * c->double_launches);
         if (n1) c->kernel_ms = (float)(sum1 / n1 * (c->kernel_launches - c->double_launches));
+        c->kernel_timed = n1; c->kernel2_timed = n2;
     }
     return 0;
+}
+
+extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
+    if (!c) return 1;
+    const int rc = subcycle_impl(c, nsub);
+    if (rc) {   // an error return must not leave work or event waits outstanding on either stream
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+    }
+    return rc;
 }
 
 extern "C" int evpk_finish(evpk_ctx *c) {
@@ -1432,7 +1481,19 @@ extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
     for (int n = 0; n < nrep; n++)   // WORK1/WORK2 pair plane: scratch, rewritten by the next prep/finish
         hipLaunchKernelGGL(k_calib_copy_pair, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, (int)(F_WORK1 & ~1), (int)(F_WORK1 & ~1));   // in place: same bytes read and written
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // ... and EVPK_CALIB_BIG_BYTES (1 GiB) each way between two buffers of their own: four times the Infinity Cache, so that
+    // neither the reads nor the writes can be served on the die (MI355X_MICROARCH.md, Infinity Cache)
+    double2 *a = nullptr, *b = nullptr;
+    const size_t n = EVPK_CALIB_BIG_BYTES / sizeof(double2);
+    HIPCHK(c, hipMalloc(&a, EVPK_CALIB_BIG_BYTES));
+    if (hipMalloc(&b, EVPK_CALIB_BIG_BYTES) != hipSuccess) { (void)hipFree(a); FAIL(c, "evpk_calibrate: hipMalloc failed"); }
+    (void)hipMemsetAsync(a, 0x11, EVPK_CALIB_BIG_BYTES, c->stream);
+    (void)hipMemsetAsync(b, 0x22, EVPK_CALIB_BIG_BYTES, c->stream);
+    for (int k = 0; k < nrep; k++)
+        hipLaunchKernelGGL(k_calib_copy_big, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double2 *)a, b, n);
+    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(a); (void)hipFree(b);
+    if (e1 != hipSuccess || e2 != hipSuccess) FAIL(c, "evpk_calibrate: copy failed");
     return 0;
 }
 
@@ -1447,6 +1508,12 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->kernel2_ms = c->kernel2_ms; o->kernel2_launches = c->double_launches;
     o->strip_rows = c->R; o->strip_rows2 = c->use_double ? c->R2 : 0; o->nstrips2 = c->use_double ? c->nstrips2 : 0;
     o->zone_cols = c->zone_mode ? c->zW : 0; o->zone_exchanges = c->zone_exchanges; o->zone_bytes = c->zone_bytes;
-    o->overlap_split = !c->ov_fixed ? -1 : (c->overlap ? 1 : 0); o->reserved_ = 0;
+    o->overlap_split = !c->ov_fixed ? -1 : (c->overlap ? 1 : 0);
+    o->tile_kernel = 0;
+    o->kernel_timed = c->kernel_timed; o->kernel2_timed = c->kernel2_timed;
+    o->bound_ms = 0.f; o->bound_updates = 0;
+    o->compact_metrics = c->compact ? 1 : 0;
+    o->transport = c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
+    o->reserved_ = 0;
     return 0;
 }

@@ -400,6 +400,13 @@ __global__ void k_calib_copy_pair(Slab s, int fsrc_even, int fdst_even) {
     *dst = *src;
 }
 
+// profiling aid, second form: a streaming copy between two buffers far larger than the 256 MiB Infinity Cache (16 B per
+// lane, coalesced): n double2 read, n double2 written, nothing the caches can absorb
+__global__ void k_calib_copy_big(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] = src[k];
+}
+
 // ------------------------------------------------------------------------------------
 // evp_prep2 (ice_dyn_shared.F90:377-614) on the slab.  State lives in buffer `cur` on entry; both
 // buffers are left identical (the velocity ring is completed by the halo update + ring copy that

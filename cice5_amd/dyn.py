@@ -72,7 +72,7 @@ class EvpDynamics:
     def __init__(self, decomp: Decomp, fields: Dict[str, np.ndarray], *, ndte: int = 120, revised_evp: bool = False,
                  device: int = 0, unique_id: Optional[bytes] = None, cosw: float = C.cosw, sinw: float = C.sinw,
                  tilt_from_slope: bool = False, wind_on_ugrid: bool = False, xmin: Optional[float] = None,
-                 pin_host: bool = False, device_strength: Optional[dict] = None):
+                 pin_host: bool = False, device_strength: Optional[dict] = None, defer_connect: bool = False):
         """pin_host: page-lock the arrays of `fields` (evpk_pin_host) as a host model does once for its module arrays;
         evp() then moves them in place over PCIe.  The arrays must stay the same objects until close()."""
         self.decomp, self.fields = decomp, fields
@@ -83,11 +83,15 @@ class EvpDynamics:
             # kstrength / krdg_partic / krdg_redist / ncat / mu_rdg / Cf; kstrength = 1 reads fields["aicen", "vicen", "aice0"]
             self._opts.update(device_strength)
         self._xmin = xmin
-        self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id)
+        self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id, defer_connect=defer_connect)
         self.ctx.device_strength = device_strength is not None
         self.params: Optional[evpk.Params] = None
         self._pinned = [a for a in fields.values() if isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
                         and evpk.pin_host(a)] if pin_host else []
+
+    def connect(self, unique_id: bytes):
+        """second phase of a multi-rank start (EvpDynamics(..., defer_connect=True)): collective over the ranks"""
+        self.ctx.connect(unique_id)
 
     def set_evp_parameters(self, dt: float):
         xmin = self._xmin if self._xmin is not None else local_min_dx(self.fields, self.decomp)

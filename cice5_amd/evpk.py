@@ -71,13 +71,17 @@ class Stats(ct.Structure):
                 ("kernel2_ms", ct.c_float), ("kernel2_launches", ct.c_int32),
                 ("strip_rows", ct.c_int32), ("strip_rows2", ct.c_int32), ("nstrips2", ct.c_int32),
                 ("zone_cols", ct.c_int32), ("zone_exchanges", ct.c_int32), ("zone_bytes", ct.c_int64),
-                ("overlap_split", ct.c_int32), ("reserved_", ct.c_int32)]
+                ("overlap_split", ct.c_int32), ("tile_kernel", ct.c_int32), ("kernel_timed", ct.c_int32),
+                ("kernel2_timed", ct.c_int32), ("bound_ms", ct.c_float), ("bound_updates", ct.c_int32),
+                ("compact_metrics", ct.c_int32), ("transport", ct.c_int32), ("reserved_", ct.c_int32)]
+
+XP_NAMES = {0: "none", 1: "rccl", 2: "shm relay", 3: "ipc peer-mapped", 4: "self (forced exchange)"}
 
 
 EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",
            "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
            "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
-           "evpk_unpin_host"]
+           "evpk_unpin_host", "evpk_connect", "evpk_device_check"]
 
 _lib = None
 
@@ -114,6 +118,8 @@ def lib():
         L.evpk_slab_layout.argtypes = [ct.c_int32] * 6 + [c_i32p]
         L.evpk_pin_host.argtypes = [ct.c_void_p, ct.c_size_t]
         L.evpk_unpin_host.argtypes = [ct.c_void_p]
+        L.evpk_connect.argtypes = [ctxp, ct.c_void_p]
+        L.evpk_device_check.argtypes = [ct.c_int32]
         for n in EXPORTS:
             if n != "evpk_last_error":
                 getattr(L, n).restype = ct.c_int
@@ -154,6 +160,14 @@ def get_unique_id() -> bytes:
     return buf.raw
 
 
+def device_check(device: int) -> Optional[str]:
+    """None if `device` is a usable gfx950 part, else the reason (evpk_device_check)."""
+    L = lib()
+    if L.evpk_device_check(int(device)):
+        return L.evpk_last_error(None).decode()
+    return None
+
+
 def slab_layout(nx_global, nranks, rank, ew_boundary, i0, i1):
     out = (ct.c_int32 * 5)()
     if lib().evpk_slab_layout(nx_global, nranks, rank, ew_boundary, i0, i1, out):
@@ -164,7 +178,10 @@ def slab_layout(nx_global, nranks, rank, ew_boundary, i0, i1):
 class Context:
     """Owns one evpk_ctx (one GPU, one rank)."""
 
-    def __init__(self, decomp, fields: Dict[str, np.ndarray], device: int = 0, unique_id: Optional[bytes] = None):
+    def __init__(self, decomp, fields: Dict[str, np.ndarray], device: int = 0, unique_id: Optional[bytes] = None,
+                 defer_connect: bool = False):
+        """defer_connect (nprocs > 1): evpk_create without a unique id -- nothing collective happens until connect(),
+        so the host can first agree across ranks that every create succeeded."""
         L = lib()
         self._L = L
         self._ctx = ct.c_void_p()
@@ -176,6 +193,8 @@ class Context:
         for n in ("ilo", "ihi", "jlo", "jhi", "iglob_lo", "jglob_lo"):
             setattr(g, n, _p32(ga[n]))
         g.rank, g.nranks, g.device = decomp.rank, decomp.nprocs, device
+        if defer_connect:
+            unique_id = None
         self._uid = ct.create_string_buffer(unique_id, UNIQUE_ID_BYTES) if unique_id is not None else None
         g.unique_id = ct.cast(self._uid, ct.c_void_p) if self._uid is not None else None
         for n in GEOM_F64:
@@ -190,6 +209,11 @@ class Context:
     def _chk(self, rc, what):
         if rc:
             raise EvpkError(f"{what}: " + self._L.evpk_last_error(self._ctx).decode())
+
+    def connect(self, unique_id: bytes):
+        """evpk_connect: the collective half of the start (communicator / peer mapping)."""
+        self._uid = ct.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        self._chk(self._L.evpk_connect(self._ctx, ct.cast(self._uid, ct.c_void_p)), "evpk_connect")
 
     def set_params(self, p: Params):
         self._chk(self._L.evpk_set_params(self._ctx, ct.byref(p)), "evpk_set_params")

@@ -224,7 +224,9 @@ class SynthCase:
         if name == "ss_tlty":
             return np.where(ins, 1.0e-6 * np.cos(3.0 * x - y), 0.0)
         if name == "Cdn_ocn":
-            return np.full(I.shape, C.dragio)
+            # the ocean drag coefficient is a per-cell field in the reference (Cw = Cdn_ocn(:,:,iblk), ice_dyn_evp.F90:383;
+            # form drag makes it vary in space, ice_atmo.F90:40): +-30 % around dragio, smooth plus cell-scale noise
+            return C.dragio * (1.0 + 0.25 * np.sin(5.0 * x + 0.3) * np.cos(3.0 * y - 0.2) + 0.1 * (_hash01(Iw, J, 8, s) - 0.5))
         if name == "strength":   # Hibler (1979), ice_mechred.F90:2258-2265
             a, v = self_.field("aice", I, J), self_.field("vice", I, J)
             return C.Pstar * v * np.exp(-C.Cstar * (1.0 - a))

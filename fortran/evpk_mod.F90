@@ -78,7 +78,9 @@
          integer (c_int32_t) :: strip_rows, strip_rows2, nstrips2
          integer (c_int32_t) :: zone_cols, zone_exchanges
          integer (c_int64_t) :: zone_bytes
-         integer (c_int32_t) :: overlap_split, reserved_
+         integer (c_int32_t) :: overlap_split, tile_kernel, kernel_timed, kernel2_timed
+         real (c_float) :: bound_ms
+         integer (c_int32_t) :: bound_updates, compact_metrics, transport, reserved_
       end type evpk_stats
 
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EVPK_VERSION 1
+#define EVPK_VERSION 2
 
 /* boundary types: ice_domain.F90 domain_nml ew_boundary_type / ns_boundary_type */
 enum { EVPK_BND_CYCLIC = 0, EVPK_BND_OPEN = 1, EVPK_BND_CLOSED = 2, EVPK_BND_TRIPOLE = 3 };
@@ -142,8 +142,19 @@ typedef struct {
     int64_t zone_bytes;                /* bytes this rank sent in them */
     int32_t overlap_split;             /* x-slabs: 1 the exchange launches are split into edge + interior strips on two streams, 0 whole
                                           launches, -1 still trying both (first three evps; EVPK_OVERLAP fixes it) */
+    int32_t tile_kernel;               /* 1: the pairs of the last call ran the small-slab tile variant (k_subcycle2t), 0: the marching one */
+    int32_t kernel_timed, kernel2_timed;   /* launches of each kind that were actually bracketed by HIP events (kernel_ms / kernel2_ms are
+                                          their mean x the number of launches) */
+    float bound_ms;                    /* halo / fold / ghost-zone work of the last evpk_subcycle call (pack, transport, unpack): mean of the
+                                          HIP-event-timed updates x their number -- what the reference books under timer_bound
+                                          (ice_dyn_evp.F90:392-400) */
+    int32_t bound_updates;             /* ... and their number */
+    int32_t compact_metrics;           /* 1: the kernels rebuild the eight metric planes from HTN / HTE (evpk_geom) */
+    int32_t transport;                 /* EVPK_XP_*: what carries the exchanges between ranks */
     int32_t reserved_;
 } evpk_stats;
+
+enum { EVPK_XP_NONE = 0, EVPK_XP_RCCL = 1, EVPK_XP_SHM_RELAY = 2, EVPK_XP_IPC = 3, EVPK_XP_SELF = 4 };
 
 /* rank 0 creates the RCCL id; the host model broadcasts the bytes (MPI_Bcast in CICE,
  * torch.distributed in bench.py) and every rank passes them to evpk_create.
@@ -153,6 +164,13 @@ typedef struct {
 int evpk_get_unique_id(void *id /* EVPK_UNIQUE_ID_BYTES */);
 
 int evpk_create(const evpk_geom *g, evpk_ctx **out);
+/* Two-phase start for nranks > 1: evpk_create with unique_id == NULL allocates and uploads everything but touches no other
+ * rank; the host then agrees across ranks (MPI_Allreduce in CICE, gloo in bench.py) that every create succeeded and only
+ * then calls evpk_connect, which is collective (communicator / peer mapping, slab starts).  A rank that failed early can
+ * therefore not leave the others hanging inside the communicator bootstrap.  evpk_create with a unique_id does both. */
+int evpk_connect(evpk_ctx *c, const void *unique_id /* EVPK_UNIQUE_ID_BYTES */);
+/* 0 if `device` exists and is a gfx950 part this library can run on (no context needed; error text via evpk_last_error(NULL)) */
+int evpk_device_check(int32_t device);
 int evpk_set_params(evpk_ctx *c, const evpk_params *p);
 
 /* whole evp(dt): upload + prep + ndte subcycles + finish + download */
@@ -176,6 +194,9 @@ int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
 /* Profiling aid: nrep device-to-device copies of one scratch pair plane with the hot kernel's access
  * shape (16 B per lane, coalesced).  Each moves exactly (nxl+2)*(nyl+2)*16 bytes each way: a known
  * byte count in the PMC trace to calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
+/* Each call also runs nrep copies of EVPK_CALIB_BIG_BYTES from one buffer to another (kernel k_calib_copy_big): both far
+ * larger than the 256 MiB Infinity Cache, the byte count the FETCH_SIZE correction is checked against. */
+#define EVPK_CALIB_BIG_BYTES (1ull << 30)
 int evpk_calibrate(evpk_ctx *c, int32_t nrep);
 int evpk_destroy(evpk_ctx *c);
 

@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""HBM traffic of k_subcycle from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), calibrated on
-the k_calib_copy_pair launches of the same run (known byte count, same 16 B/lane access shape), as
-MI355X_MICROARCH.md prescribes ("calibrate on a known byte count in your own access pattern").
+"""HBM traffic of the subcycle kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; the two do not fit in one
+pass: MI355X_MICROARCH.md, rocprofv3 PMC slots), corrected as that guide's HBM section prescribes for gfx950:
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <nxl> <nyl> [out.json]
+    bytes read    = FETCH_SIZE [KiB] x 1024 x 2      (FETCH_SIZE tallies 128-B requests at 64 B for 16 B-per-lane reads)
+    bytes written = WRITE_SIZE [KiB] x 1024 x 1
+
+and checked in the same run against copies of a known byte count with the hot kernel's access shape (16 B per lane):
+k_calib_copy_big moves 1 GiB each way between two buffers four times the Infinity Cache (the factor the correction must
+reproduce: 2.0 / 1.0), k_calib_copy_pair one 155 MB pair plane in place (cache-resident: its reads are partly served
+on the die, which is why round 1's own factor came out at 1.77).
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [label]
 """
 import collections
 import csv
 import json
 import sys
+
+BIG = float(1 << 30)
 
 
 def means(path, counter):
@@ -21,24 +30,25 @@ def means(path, counter):
 
 def main():
     fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
-    nxl, nyl = int(sys.argv[3]), int(sys.argv[4])
-    known = (nxl + 2) * (nyl + 2) * 16.0                     # bytes each way per calibration copy
-    cf = known / (fetch["evpk::k_calib_copy_pair"][0] * 1024.0)
-    cw = known / (write["evpk::k_calib_copy_pair"][0] * 1024.0)
-    out = {"unit": "bytes per launch", "calibration": {"known_bytes_each_way": known, "fetch_factor": cf, "write_factor": cw,
-                                                       "fetch_KiB": fetch["evpk::k_calib_copy_pair"][0],
-                                                       "write_KiB": write["evpk::k_calib_copy_pair"][0]}}
+    out = {"unit": "bytes per launch", "correction": {"fetch": 2.0, "write": 1.0, "source": "MI355X_MICROARCH.md, HBM"},
+           "label": sys.argv[4] if len(sys.argv) > 4 else ""}
+    cal = {}
+    for k, known in (("evpk::k_calib_copy_big", BIG), ("evpk::k_calib_copy_pair", None)):
+        if k in fetch and k in write:
+            f, w = fetch[k][0] * 1024.0, write[k][0] * 1024.0
+            cal[k] = {"fetch_raw_bytes": f, "write_raw_bytes": w, "launches": fetch[k][1]}
+            if known:
+                cal[k].update({"known_bytes_each_way": known, "fetch_factor": known / f, "write_factor": known / w})
+    out["calibration"] = cal
     for k in sorted(fetch):
         if "k_subcycle" in k:
             f, n = fetch[k]
             w = write.get(k, (0.0, 0))[0]
             out[k] = {"launches": n, "fetch_KiB_raw": f, "write_KiB_raw": w,
-                      "read_bytes": f * 1024.0 * cf, "write_bytes": w * 1024.0 * cw,
-                      "hbm_bytes": f * 1024.0 * cf + w * 1024.0 * cw,
-                      "hbm_bytes_guide_correction": f * 1024.0 * 2.0 + w * 1024.0}
+                      "read_bytes": f * 1024.0 * 2.0, "write_bytes": w * 1024.0,
+                      "hbm_bytes": f * 1024.0 * 2.0 + w * 1024.0}
     print(json.dumps(out, indent=1))
-    if len(sys.argv) > 5:
-        json.dump(out, open(sys.argv[5], "w"), indent=1)
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Upserts one entry of profiles/traffic.json (what bench.py reports as roofline.traffic) from a PMC pass.
+
+usage: update_traffic.py <pmc_traffic.json> <bench.json of the same command> <path the summary is kept under>
+
+The entry is keyed by the workload string AND by the hash of the kernel sources (bench.py: source_sha), so a number
+measured on another build of the kernels is never reported against this one."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    pmc = json.load(open(sys.argv[1]))
+    line = [l for l in open(sys.argv[2]).read().splitlines() if l.startswith("{")][-1]
+    bench = json.loads(line)
+    kerns = {k: v for k, v in pmc.items() if k.startswith("evpk::k_subcycle")}
+    if not kerns:
+        raise SystemExit("no subcycle kernel in " + sys.argv[1])
+    name = max(kerns, key=lambda k: kerns[k]["launches"])          # the dominant one
+    e = {"workload": bench["config"]["workload"], "source_sha": bench["roofline"]["source_sha"], "kernel": name,
+         "launches_profiled": kerns[name]["launches"], "hbm_bytes_per_launch": kerns[name]["hbm_bytes"],
+         "read_bytes": kerns[name]["read_bytes"], "write_bytes": kerns[name]["write_bytes"],
+         "correction": pmc.get("correction"), "calibration": pmc.get("calibration"), "profile": sys.argv[3]}
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    db = json.load(open(path)) if os.path.exists(path) else {"entries": []}
+    db["entries"] = [x for x in db["entries"] if not (x["workload"] == e["workload"] and x["source_sha"] == e["source_sha"])] + [e]
+    json.dump(db, open(path, "w"), indent=1)
+    print(f"{name}: {e['hbm_bytes_per_launch'] / 1e9:.4f} GB per launch, sha {e['source_sha']}, workload {e['workload'][:60]}")
+
+
+if __name__ == "__main__":
+    main()

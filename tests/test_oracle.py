@@ -171,7 +171,7 @@ def test_free_drift_balance():
     u, v = f["uvel"][m], f["vvel"][m]
     aiu, fm = f["aiu"][m], f["fm"][m]
     du, dv = f["uocn"][m] - u, f["vocn"][m] - v
-    vrel = aiu * C.rhow * C.dragio * np.sqrt(du ** 2 + dv ** 2)
+    vrel = aiu * C.rhow * f["Cdn_ocn"][m] * np.sqrt(du ** 2 + dv ** 2)
     fx = f["strairx"][m] + f["strtltx"][m]
     fy = f["strairy"][m] + f["strtlty"][m]
     rx = fx + vrel * du + fm * v

@@ -520,6 +520,76 @@ def test_full_size_3600x2700_properties():
     assert not util.compare(d, h1, h2)
 
 
+def test_full_size_3600x2700_tripole_config5():
+    """BASELINE config 5: 3600x2700 with ns_boundary_type = 'tripole', on one GPU, against the oracle on the whole grid.
+    (a) the first 4 subcycles of an ndte = 240 evp: two inside pairs of the two-subcycle kernel, each with its two band
+        launches and folds next to the main launch (ice_dyn_evp.F90:392-400, serial/ice_boundary.F90:801-888);
+    (b) a whole evp with ndte = 4: one inside pair, then the LAST2 launch + LAST band launch that end the evp, the twelve
+        ice_HaloUpdate_stress folds (ice_dyn_evp.F90:416-481), evp_finish and the U->T averages -- every output compared;
+    (c) ndte = 240 (the configuration's subcycle count): finite, bounded, inactive cells untouched, the fold symmetry of
+        the top row, and restart exactness through a new context."""
+    nx, ny = 3600, 2700
+    case, d, f = util.make_case(nx, ny, 450, 2700, ns="tripole", land="continents", dt=450.0)
+    xmin = synth.global_min_dx(case)
+    # (a)
+    fo = util.clone(f)
+    nt, nu, _ = orc.evp(d, orc.make_params(450.0, 240, xmin), fo, nsub=4)
+    s = dyn.EvpDynamics(d, f, ndte=240, xmin=xmin)
+    s.init_evp(450.0)
+    g = util.clone(f)
+    s.fields = g
+    s.ctx.upload(g); s.ctx.prep(); s.ctx.subcycle(4); s.ctx.finish(); s.ctx.download(g)
+    st = s.ctx.stats()
+    assert (st.icellt, st.icellu) == (nt, nu)
+    assert st.kernel2_launches == 2            # the two-subcycle kernel ran, with its band launches
+    bad = util.compare(d, g, fo, names=["uvel", "vvel", "strocnx", "strocny", "strocnxT", "strocnyT", "aiu", "umass", "fm",
+                                        "iceumask"] + util.SIGMA)
+    assert not bad, bad[:6]
+    s.close()
+    # (b)
+    fo = util.clone(f)
+    orc.evp(d, orc.make_params(450.0, 4, xmin), fo)
+    g = util.clone(f)
+    s = dyn.EvpDynamics(d, g, ndte=4, xmin=xmin)
+    s.init_evp(450.0)
+    s.evp(450.0)
+    assert s.ctx.stats().kernel2_launches == 2
+    bad = util.compare(d, g, fo)
+    assert not bad, bad[:6]
+    s.close()
+    del fo
+    # (c)
+    g = util.clone(f)
+    s = dyn.EvpDynamics(d, g, ndte=240, xmin=xmin)
+    s.init_evp(450.0)
+    s.evp(450.0)
+    assert s.ctx.stats().kernel2_launches == 120
+    phys = util.cell_mask(d, "phys")
+    for n in ["uvel", "vvel", "divu", "shear", "strintx", "strocnxT"] + util.SIGMA:
+        assert np.isfinite(g[n][phys]).all(), n
+    speed = np.hypot(g["uvel"], g["vvel"])[phys]
+    assert 0.01 < speed.max() < 3.0
+    off = phys & (g["iceumask"] == 0)
+    assert not g["uvel"][off].any() and not g["vvel"][off].any()
+    offT = phys & (g["icetmask"] == 0)
+    assert not g["stressp_1"][offT].any() and not g["divu"][offT].any()
+    # the fold leaves the top row antisymmetric about the poles: u(i, ny) = -u(nx - i, ny)  (serial/ice_boundary.F90:818-824)
+    U = blocks.gather_global(d, g["uvel"]); V = blocks.gather_global(d, g["vvel"])
+    i = np.arange(1, nx)
+    assert np.array_equal(U[ny - 1, i - 1], -U[ny - 1, nx - i - 1]) and np.array_equal(V[ny - 1, i - 1], -V[ny - 1, nx - i - 1])
+    assert np.abs(U[ny - 1]).max() > 1e-4
+    del U, V
+    h1, h2 = util.clone(g), util.clone(g)
+    s.fields = h1
+    s.evp(450.0)
+    s.close()
+    s2 = dyn.EvpDynamics(d, h2, ndte=240, xmin=xmin)
+    s2.set_evp_parameters(450.0)
+    s2.evp(450.0)
+    s2.close()
+    assert not util.compare(d, h1, h2)
+
+
 def test_caller_arrays_in_device_memory():
     """A host model whose fields already live on the GPU passes device pointers in place of host arrays (same block
     layout): the library reads and writes them in place.  Here the arrays are torch tensors on the device."""
