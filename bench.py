@@ -312,7 +312,7 @@ def roofline(r, icellt, icellu, revp):
             "effective_vs_reference_accounting": {"bytes_per_cell_update": ALG_BYTES_STRESS + ALG_BYTES_STEPU,
                                                   "GBps": ref / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
                                                   "frac_of_peak": ref / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0},
-            "other_kernel": {"name": "k_subcycle (tripole band launches / odd remainder)", "launches": int(r["k1_n"]),
+            "other_kernel": {"name": "k_subcycle on the main stream (odd remainder; the tripole band launches run beside the main kernel on the second stream and are not in this count)", "launches": int(r["k1_n"]),
                              "launches_timed": int(r["k1_timed"]), "avg_launch_ms": r["k1_ms"] / max(r["k1_n"], 1)}}
 
 

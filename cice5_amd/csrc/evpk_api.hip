@@ -168,6 +168,9 @@ struct evpk_ctx {
     int R2 = 16, nry2 = 0;           // their height, tuned to the active area (tune_R2)
     long long tuned_icellt = -1;
     int slots2 = 512;                // resident 256-thread workgroups of k_subcycle2 on the whole chip
+    int nsimd = 1024;                // SIMDs of the chip (4 per CU)
+    bool tile_mode = false;          // the pairs run k_subcycle2t (one row per wave, no march): chosen by tune_R2 when strips are scarce
+    int tile_force = -1;             // EVPK_TILE=0 / 1 fixes the choice
     unsigned int *d_tune = nullptr;
     bool use_double = false;
     unsigned char *d_flags2 = nullptr;
@@ -505,6 +508,13 @@ static int halo_stress12(evpk_ctx *c, int f0) {
 
 // ---- launch of the two-subcycle kernel (plain or LDS-prefetch variant) ------------------------------------
 static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp, bool last2) {
+    if (c->tile_mode) {      // small-slab variant: one workgroup of R + 3 waves per strip, one row per wave
+        const dim3 gt(((a.nstrips + 7) / 8) * 8), bt((a.R + 3) * 64);
+        const size_t lds = (size_t)(a.R + 3) * 4096;
+        if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, true>), gt, bt, lds, st, a); }
+        else       { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false>), gt, bt, lds, st, a); }
+        return;
+    }
     const dim3 g((((a.nstrips + 3) / 4 + 7) / 8) * 8), b(256);     // multiple of 8: XCD remap in the kernel
     if (c->prefetch) {
 #define EVPK_L2P(RV, L2, CMX) hipLaunchKernelGGL((k_subcycle2p<RV, L2, CMX>), g, b, 0, st, a)
@@ -822,6 +832,8 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->ov_fixed = (e != nullptr);
     }
     { const char *e = getenv("EVPK_PREFETCH"); c->prefetch = !(e && atoi(e) == 0); }
+    { const char *e = getenv("EVPK_TILE"); c->tile_force = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+    c->nsimd = 4 * prop.multiProcessorCount;
 
     // neighbours on the slab ring
     int lay[5];
@@ -1003,36 +1015,53 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
 // cheapest  rounds x (R+5).  Re-tuned when the active area changed by more than 5 %.
 static int tune_R2(evpk_ctx *c) {
     const char *e = getenv("EVPK_STRIP_ROWS");
-    if (e && atoi(e) > 0) { c->R2 = std::max(1, std::min(atoi(e), 64)); c->nry2 = (c->s.nyl + 1 + c->R2 - 1) / c->R2; return 0; }
+    if (e && atoi(e) > 0) {
+        c->tile_mode = (c->tile_force == 1);
+        c->R2 = std::max(1, std::min(atoi(e), c->tile_mode ? 13 : 64)); c->nry2 = (c->s.nyl + 1 + c->R2 - 1) / c->R2;
+        return 0;
+    }
     // icellt of this prep is not known yet on the host; use the previous one as the trigger
     if (c->tuned_icellt >= 0 && std::llabs(c->icellt - c->tuned_icellt) * 20 <= c->tuned_icellt) return 0;
     static const int cand[] = {2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48};
-    const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
+    static const int tcand[] = {2, 3, 4, 5, 6, 8, 10, 13};        // tile heights of k_subcycle2t: R + 3 <= 16 waves per workgroup
+    const int ncand = (int)(sizeof(cand) / sizeof(cand[0])), ntc = (int)(sizeof(tcand) / sizeof(tcand[0]));
     Slab &s = c->s;
     HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int) * 32, c->stream));
     const int cyc = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;
     const int G = c->zone_mode ? c->zW - 2 : 0;
-    for (int k = 0; k < ncand; k++) {
-        const int R = cand[k], nry = (s.nyl + 1 + R - 1) / R, tot = c->ncx2 * nry;
+    for (int k = 0; k < ncand + ntc; k++) {
+        const int R = k < ncand ? cand[k] : tcand[k - ncand], nry = (s.nyl + 1 + R - 1) / R, tot = c->ncx2 * nry;
         hipLaunchKernelGGL(k_strip_flags2, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, nry, R, cyc, G,
                            (unsigned char *)nullptr, c->d_tune + k);
     }
     unsigned int cnt[32];
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_tune, sizeof(unsigned int) * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    double best = 1e300;
-    int bestR = c->R2;
+    // both variants in units of one wave's march step alone on its SIMD (~2.5-3 us, VALU-bound)
+    double best = 1e300, bestT = 1e300;
+    int bestR = c->R2, bestH = 4;
     for (int k = 0; k < ncand; k++) {
         const long long nwg = (cnt[k] + 3) / 4;
         if (nwg == 0) continue;
         const long long rounds = (nwg + c->slots2 - 1) / c->slots2;
         // a round that is less than ~70 % full hides memory latency worse: charge it a little
         const double fill = (double)nwg / (double)(rounds * c->slots2);
-        // a strip marches R+3 rows plus about two rows' worth of prologue / drain
-        const double cost = (double)rounds * (cand[k] + 5) * (fill < 0.7 ? 1.0 + 0.5 * (0.7 - fill) : 1.0);
+        // a strip marches R+3 rows plus about two rows' worth of prologue / drain; two waves on a SIMD take turns at its VALU
+        const double share = std::min(2.0, std::max(1.0, (double)cnt[k] / (double)(rounds * c->nsimd)));
+        const double cost = (double)rounds * (cand[k] + 5) * (fill < 0.7 ? 1.0 + 0.5 * (0.7 - fill) : 1.0) * share;
         if (cost < best * 0.999) { best = cost; bestR = cand[k]; }
     }
-    c->R2 = bestR;
+    for (int k = 0; k < ntc; k++) {
+        const unsigned int nt = cnt[ncand + k];
+        if (nt == 0) continue;
+        // every wave does one row: wave-steps over the SIMDs, + one step's worth of load latency and three barriers; no
+        // LDS prefetch and more redundant rows than a tall marching strip
+        const double cost = std::max(1.0, (double)nt * (tcand[k] + 3) / (double)c->nsimd) * 1.2 + 1.0;
+        if (cost < bestT * 0.999) { bestT = cost; bestH = tcand[k]; }
+    }
+    c->tile_mode = c->tile_force >= 0 ? (c->tile_force == 1) : (bestT < best);
+    if (best > 1e299 && bestT > 1e299) c->tile_mode = false;
+    c->R2 = c->tile_mode ? bestH : bestR;
     c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
     c->tuned_icellt = -2;      // set from the counts of this prep below
     return 0;
@@ -1509,7 +1538,7 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->strip_rows = c->R; o->strip_rows2 = c->use_double ? c->R2 : 0; o->nstrips2 = c->use_double ? c->nstrips2 : 0;
     o->zone_cols = c->zone_mode ? c->zW : 0; o->zone_exchanges = c->zone_exchanges; o->zone_bytes = c->zone_bytes;
     o->overlap_split = !c->ov_fixed ? -1 : (c->overlap ? 1 : 0);
-    o->tile_kernel = 0;
+    o->tile_kernel = (c->use_double && c->tile_mode) ? 1 : 0;
     o->kernel_timed = c->kernel_timed; o->kernel2_timed = c->kernel2_timed;
     o->bound_ms = 0.f; o->bound_updates = 0;
     o->compact_metrics = c->compact ? 1 : 0;

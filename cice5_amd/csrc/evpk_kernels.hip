@@ -1565,6 +1565,170 @@ template __global__ void k_subcycle2<true, false>(SubArgs);
 template __global__ void k_subcycle2<false, true>(SubArgs);
 template __global__ void k_subcycle2<true, true>(SubArgs);
 
+// ------------------------------------------------------------------------------------
+// k_subcycle2t: the two fused subcycles of k_subcycle2 WITHOUT the north march -- the small-slab variant.
+// k_subcycle2 gives one wave a strip of 61 columns x R rows and lets it march north, R + 3 dependent steps of ~3 us each:
+// fine when there are more strips than wave slots, but a 320 x 384 grid (or one eighth of the 3600 x 2700 grid per GPU)
+// has fewer, and the launch then lasts as long as ONE wave's serial march whatever the chip could do in parallel.
+// Here a workgroup of R + 3 waves takes the same strip and every wave takes ONE row of it, r = jb - 1 + w:
+//   phase A  T1(r)      all waves            -> LDS: the four terms the U row below needs (str3, str6, str4/str8 of the east cell)
+//   phase B  U1(r)      waves 0 .. R+1       -> LDS: (u, v) after the first subcycle at columns c and c-1
+//   phase C  T2(r)      waves 1 .. R+1       -> LDS: the same four terms of the second subcycle; sigma stored for waves 1 .. R
+//   phase D  U2(r)      waves 1 .. R         -> (u, v) stored
+// three workgroup barriers instead of R + 3 march steps; E-W neighbours still travel by DPP wave shifts.  Same strips,
+// same column / ghost-zone / tripole-band (jmax) rules, same arithmetic in the same order: bit-identical to k_subcycle2.
+// LDS: two arrays of [waves][4][64] doubles (the first one serves phases A and C).
+// ------------------------------------------------------------------------------------
+template <bool REVP, bool LAST2>
+__global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
+    extern __shared__ double tl[];
+    const Slab &s = a.s;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = blockDim.x >> 6;                   // R + 3
+    const int chunk = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (wg >= a.nstrips) return;                      // (the whole workgroup leaves: no barrier is left waiting)
+    const int st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
+    const int cx = st % a.ncx, ry = st / a.ncx;
+    const int R = a.R, nxl = s.nxl, nyl = s.nyl;
+    const int G = a.G;
+    const int c = cx * STRIP2_W + lane - G;
+    const int jb = ry * R + 1;
+    const bool cyc = a.wrap != 0;
+    int ci = c, cm1 = c - 1;
+    bool okc, okm;
+    if (cyc) {
+        ci = (c - 1) % nxl; if (ci < 0) ci += nxl; ci += 1;
+        cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
+        okc = okm = true;
+    } else {
+        okc = (c >= -1 - G && c <= nxl + 2 + G);
+        okm = (cm1 >= -1 - G && cm1 <= nxl + 2 + G);
+        if (!okc) ci = 0;
+        if (!okm) cm1 = 0;
+    }
+    const bool tcol = cyc ? true : (c >= -G && c <= nxl + 2 + G);
+    const bool ucol = cyc ? true : (c >= -G && c <= nxl + 1 + G);
+    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);
+
+    const size_t pp = (size_t)s.pitch * 16;
+    const size_t rowb = (size_t)s.rstride * 16;
+    const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
+    const int SR = a.sr, SW = a.sw;
+    char *const base = reinterpret_cast<char *>(s.F);
+    double *const X = tl, *const Y = tl + (size_t)NW * 256;
+    double *const Xw = X + (size_t)w * 256 + lane, *const Yw = Y + (size_t)w * 256 + lane;
+
+    const int r = jb - 1 + w;                         // this wave's row
+    const bool rowok = (r >= 0 && r <= nyl + 1);
+    char *const rb = base + (size_t)(rowok ? r : 0) * rowb;
+
+    // ---------------- phase A: T1(r) ----------------
+    unsigned char m = 0;
+    double un_c = 0.0, vn_c = 0.0, un_m = 0.0, vn_m = 0.0;        // u_old at (c, r), (c-1, r)
+    double uo_c = 0.0, vo_c = 0.0, uo_m = 0.0, vo_m = 0.0;        // ... at (c, r-1), (c-1, r-1)
+    if (rowok) {
+        if (okc) {
+            m = s.cmask[(size_t)r * s.pitch + C0 + ci];
+            const double2 q = ldp(rb, pp, SR + S_U, lo); un_c = q.x; vn_c = q.y;
+        }
+        if (okm) { const double2 q = ldp(rb, pp, SR + S_U, lom); un_m = q.x; vn_m = q.y; }
+    }
+    if (r - 1 >= 0 && r - 1 <= nyl + 1) {
+        const char *rs = base + (size_t)(r - 1) * rowb;
+        if (okc) { const double2 q = ldp(rs, pp, SR + S_U, lo); uo_c = q.x; vo_c = q.y; }
+        if (okm) { const double2 q = ldp(rs, pp, SR + S_U, lom); uo_m = q.x; vo_m = q.y; }
+    }
+    const bool t1act = tcol && (m & CM_T) != 0;
+    const bool u1act = (w <= NW - 2) && ucol && (m & CM_U) != 0 && r >= 1 && r <= nyl;
+    Str8 o1{0, 0, 0, 0, 0, 0, 0, 0};
+    Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    UStat q1{0, 0, 0, 0, 0, 0, 0, 0};
+    double ui1 = 0.0, vi1 = 0.0;
+    if (__any(t1act)) {
+        if (t1act) { mt = load_tmet(rb, pp, lo); g1 = load_sig(rb, pp, SR, lo); }
+    }
+    if (__any(u1act)) {      // the stepu inputs of this row serve both subcycles; fetched beside the T planes
+        if (u1act) {
+            q1 = load_ustat(rb, pp, lo);
+            if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo); ui1 = iv.x; vi1 = iv.y; }
+        }
+    }
+    if (__any(t1act)) {
+        if (t1act) {
+            Diag dg;
+            stress_cell<false>(mt, un_c, un_m, uo_c, uo_m, vn_c, vn_m, vo_c, vo_m, a.ecci, a.arlx1i, a.denom1, 0.0, g1, o1, dg);
+        }
+    }
+    const double a2n = shfl_dn1(o1.s2), a4n = shfl_dn1(o1.s4), a7n = shfl_dn1(o1.s7), a8n = shfl_dn1(o1.s8);
+    Xw[0] = o1.s3; Xw[64] = o1.s6; Xw[128] = a4n; Xw[192] = a8n;
+    __syncthreads();
+
+    // ---------------- phase B: U1(r) ----------------
+    double u1_c = un_c, v1_c = vn_c;                  // an inactive cell keeps its velocity
+    if (__any(u1act)) {
+        if (u1act) {
+            const double *Xn = Xw + 256;              // the row above
+            double sxi, syi;
+            stepu_cell(q1, un_c, vn_c, ui1, vi1, ((o1.s1 + a2n) + Xn[0]) + Xn[128], ((o1.s5 + Xn[64]) + a7n) + Xn[192],
+                       a.brlx, a.revp, a.cosw, a.sinw, u1_c, v1_c, sxi, syi);
+        }
+    }
+    const double u1_m = shfl_up1(u1_c), v1_m = shfl_up1(v1_c);      // (c-1, r); lane 0 is not used below
+    Yw[0] = u1_c; Yw[64] = v1_c; Yw[128] = u1_m; Yw[192] = v1_m;
+    __syncthreads();
+
+    // ---------------- phase C: T2(r) ----------------
+    const bool t2act = (w >= 1) && (w <= NW - 2) && t1act && lane >= 1;
+    Str8 o2{0, 0, 0, 0, 0, 0, 0, 0};
+    if (__any(t2act)) {
+        if (t2act) {
+            const double *Ys = Yw - 256;              // the row below, after the first subcycle
+            Sig g2 = g1;
+            Diag dg;
+            double tarear = 0.0;
+            if (LAST2) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
+            stress_cell<LAST2>(mt, u1_c, u1_m, Ys[0], Ys[128], v1_c, v1_m, Ys[64], Ys[192], a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
+            if (own && w <= R && r <= a.jmax) {
+                store_sig(rb, pp, SW, lo, g2);
+                if (cyc && c == 1) store_sig(rb, pp, SW, lo + (unsigned)nxl * 16u, g2);     // east ghost T column = image of column 1
+                if (LAST2) {
+                    st1(rb, pp, F_DIVU, lo, dg.divu);       st1(rb, pp, F_RDGCONV, lo, dg.rdg_conv);
+                    st1(rb, pp, F_RDGSHEAR, lo, dg.rdg_shear); st1(rb, pp, F_SHEAR, lo, dg.shear);
+                    st1(rb, pp, F_PRSSIG, lo, dg.prs);
+                }
+            }
+        }
+    }
+    const double b2n = shfl_dn1(o2.s2), b4n = shfl_dn1(o2.s4), b7n = shfl_dn1(o2.s7), b8n = shfl_dn1(o2.s8);
+    Xw[0] = o2.s3; Xw[64] = o2.s6; Xw[128] = b4n; Xw[192] = b8n;
+    __syncthreads();
+
+    // ---------------- phase D: U2(r) ----------------
+    const bool u2act = (w >= 1) && (w <= R) && own && (m & CM_U) != 0 && r <= nyl && r <= a.jmax;
+    if (__any(u2act)) {
+        if (u2act) {
+            const double *Xn = Xw + 256;
+            double un, vn, sxi, syi;
+            stepu_cell(q1, u1_c, v1_c, ui1, vi1, ((o2.s1 + b2n) + Xn[0]) + Xn[128], ((o2.s5 + Xn[64]) + b7n) + Xn[192],
+                       a.brlx, a.revp, a.cosw, a.sinw, un, vn, sxi, syi);
+            stp(rb, pp, SW + S_U, lo, un, vn);
+            if (cyc) {
+                if (c == 1) stp(rb, pp, SW + S_U, lo + (unsigned)nxl * 16u, un, vn);
+                if (c == nxl) stp(rb, pp, SW + S_U, lo - (unsigned)nxl * 16u, un, vn);
+            }
+            if (LAST2) { st1(rb, pp, F_STRINTX, lo, sxi); st1(rb, pp, F_STRINTY, lo, syi); }
+        }
+    }
+}
+
+template __global__ void k_subcycle2t<false, false>(SubArgs);
+template __global__ void k_subcycle2t<true, false>(SubArgs);
+template __global__ void k_subcycle2t<false, true>(SubArgs);
+template __global__ void k_subcycle2t<true, true>(SubArgs);
+
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
 // cells: if given, also counts the active T / U cells on the physical cells each strip owns (icellt, icellu of the rank)

@@ -19,7 +19,7 @@ def main():
     kerns = {k: v for k, v in pmc.items() if k.startswith("evpk::k_subcycle")}
     if not kerns:
         raise SystemExit("no subcycle kernel in " + sys.argv[1])
-    name = max(kerns, key=lambda k: kerns[k]["launches"])          # the dominant one
+    name = max(kerns, key=lambda k: kerns[k]["launches"] * kerns[k]["hbm_bytes"])          # the dominant one: most bytes in all
     e = {"workload": bench["config"]["workload"], "source_sha": bench["roofline"]["source_sha"], "kernel": name,
          "launches_profiled": kerns[name]["launches"], "hbm_bytes_per_launch": kerns[name]["hbm_bytes"],
          "read_bytes": kerns[name]["read_bytes"], "write_bytes": kerns[name]["write_bytes"],

@@ -241,6 +241,64 @@ def test_two_subcycle_kernel_equals_single(monkeypatch):
         assert not util.compare(d, outs[1], outs[0])
 
 
+@pytest.mark.parametrize("H", ["", "2", "5", "13"])
+def test_tile_kernel_equals_oracle(H, monkeypatch):
+    """k_subcycle2t (EVPK_TILE=1: one row per wave, three workgroup barriers instead of the north march -- the small-slab
+    variant of the two-subcycle kernel) against the oracle: BASELINE configs 2 and 3, padded blocks, revised EVP, an open
+    E-W boundary, the tripole band launches beside it, ghost zones (forced exchange) at two depths, odd ndte and subcycles
+    issued in pieces.  H = tile height (EVPK_STRIP_ROWS; '' = tuned)."""
+    monkeypatch.setenv("EVPK_TILE", "1")
+    if H:
+        monkeypatch.setenv("EVPK_STRIP_ROWS", H)
+    seen = []
+    real = dyn.EvpDynamics.close
+
+    def close(self):
+        seen.append(int(self.ctx.stats().tile_kernel))
+        real(self)
+
+    monkeypatch.setattr(dyn.EvpDynamics, "close", close)
+    _both(320, 384, 320, 384, ndte=30)                                         # config 2
+    _both(360, 300, 15, 300, land="continents", ndte=24, ncalls=2)             # config 3
+    _both(100, 116, 32, 40, land="continents", ndte=31)                        # padded blocks, odd ndte
+    _both(130, 60, 130, 60, ice="full", ndte=18, revised_evp=True)
+    _both(48, 40, 12, 10, ns="tripole", land="continents", ndte=40, ncalls=2)
+    _both(260, 140, 65, 35, ns="tripole", ice="full", ndte=14)
+    assert seen and all(seen)
+    if H in ("", "5"):
+        for m in ("1", "4"):
+            monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+            monkeypatch.setenv("EVPK_ZONE_M", m)
+            _both(200, 96, 50, 48, land="continents", ndte=31, ncalls=2)
+            _both(200, 96, 50, 48, ns="tripole", ice="full", ndte=12)
+        monkeypatch.delenv("EVPK_FORCE_EXCHANGE")
+        monkeypatch.delenv("EVPK_ZONE_M")
+        # open E-W boundary, subcycles in pieces
+        case = synth.SynthCase(nx=64, ny=48, ew_boundary=C.BND_OPEN)
+        d = blocks.create_distrb_cart(64, 48, 16, 16, ew_boundary_type="open")
+        f = synth.make_block_fields(case, d)
+        xmin = synth.global_min_dx(case)
+        fo, fg = util.clone(f), util.clone(f)
+        orc.evp(d, orc.make_params(3600.0, 30, xmin), fo)
+        s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+        s.init_evp(3600.0)
+        s.ctx.upload(fg); s.ctx.prep(); s.ctx.subcycle(7); s.ctx.subcycle(12); s.ctx.subcycle(11); s.ctx.finish(); s.ctx.download(fg)
+        assert s.ctx.stats().tile_kernel == 1
+        assert not util.compare(d, fg, fo)
+        s.close()
+
+
+def test_tile_kernel_is_chosen_for_small_slabs_only():
+    """the tuner takes the tile variant where strips are scarce (gx1, 360x300) and the marching one on the headline grid"""
+    for (nx, ny, bsx, bsy, want) in ((320, 384, 320, 384, 1), (360, 300, 60, 300, 1)):
+        case, d, f = util.make_case(nx, ny, bsx, bsy, land="continents")
+        s = dyn.EvpDynamics(d, f, ndte=4, xmin=synth.global_min_dx(case))
+        s.init_evp(3600.0)
+        s.evp(3600.0)
+        assert s.ctx.stats().tile_kernel == want, (nx, ny)
+        s.close()
+
+
 def test_staged_api_equals_run():
     """upload/prep/subcycle/finish/download == evpk_run; subcycles may be issued in pieces."""
     case, d, f = util.make_case(100, 116, 25, 29, land="continents")
