@@ -1037,26 +1037,29 @@ static int tune_R2(evpk_ctx *c) {
     unsigned int cnt[32];
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_tune, sizeof(unsigned int) * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // both variants in units of one wave's march step alone on its SIMD (~2.5-3 us, VALU-bound)
+    // Both variants in microseconds per launch, from measurements on MI355X (profiles/r02_*/tile_ab.txt): one wave alone on
+    // its SIMD takes ~5.3 us per march step (a dependent fp64 chain), ~7.5 us when a second wave shares the SIMD; the first
+    // R + 3 - 1.5 steps of a strip are full ones.  A tile workgroup of R + 3 waves sits on ONE CU, ceil((R+3)/4) waves per
+    // SIMD, ~3.6 us per wave-row when enough waves overlap; a workgroup that fills the CU alone (more than 8 waves) has
+    // nothing to hide its three barriers behind.
     double best = 1e300, bestT = 1e300;
-    int bestR = c->R2, bestH = 4;
+    int bestR = c->R2, bestH = 5;
     for (int k = 0; k < ncand; k++) {
         const long long nwg = (cnt[k] + 3) / 4;
         if (nwg == 0) continue;
         const long long rounds = (nwg + c->slots2 - 1) / c->slots2;
-        // a round that is less than ~70 % full hides memory latency worse: charge it a little
-        const double fill = (double)nwg / (double)(rounds * c->slots2);
-        // a strip marches R+3 rows plus about two rows' worth of prologue / drain; two waves on a SIMD take turns at its VALU
-        const double share = std::min(2.0, std::max(1.0, (double)cnt[k] / (double)(rounds * c->nsimd)));
-        const double cost = (double)rounds * (cand[k] + 5) * (fill < 0.7 ? 1.0 + 0.5 * (0.7 - fill) : 1.0) * share;
+        const double per_round = (double)cnt[k] / (double)rounds;
+        const double step_us = per_round > (double)c->nsimd ? 7.5 : 5.3;
+        const double cost = (double)rounds * ((cand[k] + 1.5) * step_us + 4.0);
         if (cost < best * 0.999) { best = cost; bestR = cand[k]; }
     }
-    for (int k = 0; k < ntc; k++) {
+    for (int k = ntc - 1; k >= 0; k--) {
         const unsigned int nt = cnt[ncand + k];
         if (nt == 0) continue;
-        // every wave does one row: wave-steps over the SIMDs, + one step's worth of load latency and three barriers; no
-        // LDS prefetch and more redundant rows than a tall marching strip
-        const double cost = std::max(1.0, (double)nt * (tcand[k] + 3) / (double)c->nsimd) * 1.2 + 1.0;
+        const int nw = tcand[k] + 3;
+        const double util = (double)((16 / nw) * nw) / 16.0;          // 16 waves per CU at 128 VGPRs: whole workgroups only
+        const double per_simd = std::max((double)((nw + 3) / 4), (double)nt * nw / (double)c->nsimd / util * (nw > 8 ? 1.25 : 1.0));
+        const double cost = 3.6 * per_simd + 6.0;
         if (cost < bestT * 0.999) { bestT = cost; bestH = tcand[k]; }
     }
     c->tile_mode = c->tile_force >= 0 ? (c->tile_force == 1) : (bestT < best);
@@ -1293,12 +1296,14 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 if (zone_exchange(a.sr)) return 1;
             }
             SubArgs b1 = a, b2 = a;
+            // (band launches: k_subcycle_t, one row per wave -- the band sequence is on the critical path of every pair)
             auto launch_band = [&](const SubArgs &bb, hipStream_t st, bool last = false) {
-                const dim3 g((((c->ncx + 3) / 4 + 7) / 8) * 8), b(256);
-                if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, st, bb);
-                else if (last) hipLaunchKernelGGL((k_subcycle<true, false>), g, b, 0, st, bb);
-                else if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, st, bb);
-                else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, st, bb);
+                const dim3 g(bb.nstrips), b((bb.R + 1) * 64);
+                const size_t lds = (size_t)(bb.R + 1) * 2048;
+                if (last && revp) hipLaunchKernelGGL((k_subcycle_t<true, true>), g, b, lds, st, bb);
+                else if (last) hipLaunchKernelGGL((k_subcycle_t<true, false>), g, b, lds, st, bb);
+                else if (revp) hipLaunchKernelGGL((k_subcycle_t<false, true>), g, b, lds, st, bb);
+                else hipLaunchKernelGGL((k_subcycle_t<false, false>), g, b, lds, st, bb);
             };
             if (c->band_mode) {
                 b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0; b1.G = 0;

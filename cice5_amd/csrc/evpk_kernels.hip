@@ -1083,6 +1083,104 @@ template __global__ void k_subcycle<false, true>(SubArgs);
 template __global__ void k_subcycle<true, true>(SubArgs);
 
 // ------------------------------------------------------------------------------------
+// k_subcycle_t: k_subcycle without the north march, for launches of a few rows (the tripole top-band launches: 3-4 rows
+// across the whole slab, on the critical path of every pair of subcycles).  A workgroup of R + 1 waves takes one strip,
+// wave w the T row j = jb + w: stress of T(i, j) -> LDS (str3, str6 and the east cell's str4, str8) -> one workgroup barrier
+// -> U(i, j) from its own row and the row above.  One row's latency instead of R + 1 march steps; same arithmetic.
+// ------------------------------------------------------------------------------------
+template <bool LAST, bool REVP>
+__global__ __launch_bounds__(512) void k_subcycle_t(SubArgs a) {
+    extern __shared__ double tl[];
+    const Slab &s = a.s;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sid = blockIdx.x;
+    if (sid >= a.nstrips) return;
+    const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
+    const int cx = st % a.ncx, ry = st / a.ncx;
+    const int R = a.R;
+    const int i = cx * STRIP_W + 1 + lane;
+    const int jb = a.jb0 > 0 ? a.jb0 : ry * R + 1;
+    const int j = jb + w;                                 // this wave's T row (and U row, for w < R)
+    const bool rowok = (j <= s.nyl + 1);
+    const bool colT = (i <= s.nxl + 1) && rowok;
+    const bool ownT = colT && (lane < STRIP_W);
+    const bool colU = (i <= s.nxl) && (lane < STRIP_W) && rowok;
+    const size_t pp = (size_t)s.pitch * 16;
+    const size_t rowb = (size_t)s.rstride * 16;
+    const unsigned lo = (unsigned)(C0 + i) * 16u;
+    const int SR = a.sr, SW = a.sw;
+    char *const base = reinterpret_cast<char *>(s.F);
+    char *const rb = base + (size_t)(rowok ? j : 0) * rowb;
+    double *const Xw = tl + (size_t)w * 256 + lane;
+
+    unsigned char m = 0;
+    double u_ij = 0.0, u_mj = 0.0, v_ij = 0.0, v_mj = 0.0, u_im = 0.0, u_mm = 0.0, v_im = 0.0, v_mm = 0.0;
+    if (colT) {
+        m = s.cmask[(size_t)j * s.pitch + C0 + i];
+        const double2 a0 = ldp(rb, pp, SR + S_U, lo), a1 = ldp(rb, pp, SR + S_U, lo - 16u);
+        u_ij = a0.x; v_ij = a0.y; u_mj = a1.x; v_mj = a1.y;
+        const char *rs = rb - rowb;                       // j >= 1: jb >= 1
+        const double2 b0 = ldp(rs, pp, SR + S_U, lo), b1 = ldp(rs, pp, SR + S_U, lo - 16u);
+        u_im = b0.x; v_im = b0.y; u_mm = b1.x; v_mm = b1.y;
+    }
+    const bool tact = (m & CM_T) != 0;
+    const bool uact = colU && (w < R) && (m & CM_U) != 0;
+    Str8 o{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    UStat q{0, 0, 0, 0, 0, 0, 0, 0};
+    double ui = 0.0, vi = 0.0;
+    if (__any(uact)) {
+        if (uact) {
+            q = load_ustat(rb, pp, lo);
+            if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo); ui = iv.x; vi = iv.y; }
+        }
+    }
+    if (__any(tact)) {
+        if (tact) {
+            const TMet mt = load_tmet(rb, pp, lo);
+            Sig g = load_sig(rb, pp, SR, lo);
+            double tarear = 0.0;
+            if (LAST) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
+            Diag dg;
+            stress_cell<LAST>(mt, u_ij, u_mj, u_im, u_mm, v_ij, v_mj, v_im, v_mm, a.ecci, a.arlx1i, a.denom1, tarear, g, o, dg);
+            if (ownT && w < R) {
+                store_sig(rb, pp, SW, lo, g);
+                if (LAST) {
+                    st1(rb, pp, F_DIVU, lo, dg.divu);       st1(rb, pp, F_RDGCONV, lo, dg.rdg_conv);
+                    st1(rb, pp, F_RDGSHEAR, lo, dg.rdg_shear); st1(rb, pp, F_SHEAR, lo, dg.shear);
+                    st1(rb, pp, F_PRSSIG, lo, dg.prs);
+                }
+            }
+        }
+    }
+    const double s2n = shfl_dn1(o.s2), s4n = shfl_dn1(o.s4), s7n = shfl_dn1(o.s7), s8n = shfl_dn1(o.s8);
+    Xw[0] = o.s3; Xw[64] = o.s6; Xw[128] = s4n; Xw[192] = s8n;
+    __syncthreads();
+    if (__any(uact)) {
+        if (uact) {
+            const double *Xn = Xw + 256;                  // the T row above
+            double un, vn, strintx, strinty;
+            stepu_cell(q, u_ij, v_ij, ui, vi, ((o.s1 + s2n) + Xn[0]) + Xn[128], ((o.s5 + Xn[64]) + s7n) + Xn[192],
+                       a.brlx, a.revp, a.cosw, a.sinw, un, vn, strintx, strinty);
+            stp(rb, pp, SW + S_U, lo, un, vn);
+            if (a.wrap) {
+                if (i == 1) stp(rb, pp, SW + S_U, lo + (unsigned)s.nxl * 16u, un, vn);
+                if (i == s.nxl) stp(rb, pp, SW + S_U, lo - (unsigned)s.nxl * 16u, un, vn);
+            }
+            if (LAST) {
+                st1(rb, pp, F_STRINTX, lo, strintx);
+                st1(rb, pp, F_STRINTY, lo, strinty);
+            }
+        }
+    }
+}
+
+template __global__ void k_subcycle_t<false, false>(SubArgs);
+template __global__ void k_subcycle_t<true, false>(SubArgs);
+template __global__ void k_subcycle_t<false, true>(SubArgs);
+template __global__ void k_subcycle_t<true, true>(SubArgs);
+
+// ------------------------------------------------------------------------------------
 // TWO subcycles per launch (temporal blocking): sigma, the grid metrics and the stepu input planes
 // cross HBM once per two subcycles.  Single rank, no tripole fold (the fold needs the mirrored
 // columns between the two subcycles).  One wave = 61 U columns x R U rows of the SECOND subcycle:
