@@ -1476,9 +1476,13 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
         {st->strocny, F_STROCNY}, {st->strocnxT, F_STROCNXT}, {st->strocnyT, F_STROCNYT}, {st->strairx, F_STRAIRX},
         {st->strairy, F_STRAIRY}, {st->strtltx, F_STRTLTX}, {st->strtlty, F_STRTLTY}, {st->fm, F_FM},
         {st->tmass, F_TMASS}, {st->aiu, F_AIU}, {st->umass, F_UMASS}, {st->uvel_init, F_UVEL_INIT}, {st->vvel_init, F_VVEL_INIT}};
-    for (auto &e : op)
-        if (download_f(c, e.h, e.f, MODE_PHYS)) return 1;
-    if (c->strength_dev && download_f(c, st->strength, F_STRENGTH, MODE_ALL)) return 1;
+    for (auto &e : op) {
+        // strairx/y after t2ugrid_vector: to_ugrid zeroes the whole array before it fills the physical cells (ice_grid.F90:1852)
+        const bool zg = (e.f == F_STRAIRX || e.f == F_STRAIRY) && !c->p.wind_on_ugrid;
+        if (download_f(c, e.h, e.f, zg ? MODE_PHYS_ZG : MODE_PHYS)) return 1;
+    }
+    // the strength with its ghost cells halo-updated, as evp leaves it (ice_dyn_evp.F90:311-312) -- also when it was an input
+    if (download_f(c, st->strength, F_STRENGTH, MODE_ALL)) return 1;
     if (st->icetmask) {
         // icetmask travels as a 0/1 double plane on the device; convert through the staging buffer
         std::vector<double> tmp((size_t)c->nblocks * c->nyb * c->nxb, 0.0);

@@ -18,7 +18,8 @@ namespace evpk {
 // ------------------------------------------------------------------------------------
 // gather / scatter between the reference's block layout and the slab
 // ------------------------------------------------------------------------------------
-enum { MODE_PHYS = 0, MODE_ALL = 1, MODE_NE = 2, MODE_NE_FOLD = 3 };
+enum { MODE_PHYS = 0, MODE_ALL = 1, MODE_NE = 2, MODE_NE_FOLD = 3,
+       MODE_PHYS_ZG = 4 };   // physical cells delivered, the block's ghost cells zeroed (to_ugrid: work2(:,:,:) = c0, ice_grid.F90:1852)
 
 // Which block cells feed the slab: every physical cell, plus ghost cells that land on the slab's
 // ghost ring -- but only from the block whose own columns (rows) the ring cell continues, so a
@@ -92,6 +93,14 @@ __global__ void k_scatter_f(Slab s, const BlockDesc *bd, int nxb, int nyb, int f
     const int b = blockIdx.z;
     if (i > nxb) return;
     int si, sj;
+    if (mode == MODE_PHYS_ZG) {
+        const BlockDesc d = bd[b];
+        const bool phys = (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
+        double v = 0.0;
+        if (phys) { (void)scatter_take(s, d, i, j, MODE_PHYS, si, sj); v = FD(s, f, cell(s, si, sj)); }
+        dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = v;      // (padding cells of a short edge block are ghost cells too)
+        return;
+    }
     if (!scatter_take(s, bd[b], i, j, mode, si, sj)) return;
     dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = FD(s, f, cell(s, si, sj));
 }

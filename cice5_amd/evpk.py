@@ -235,7 +235,7 @@ class Context:
         for n in STATE_OUT_F64:
             setattr(st, n, _p64(f.get(n)))
         st.icetmask = _p32(f.get("icetmask"))
-        st.strength = _p64(f.get("strength")) if self.device_strength else None
+        st.strength = _p64(f.get("strength"))        # comes back with its ghost cells halo-updated (ice_dyn_evp.F90:311-312)
         return st
 
     def run(self, f):

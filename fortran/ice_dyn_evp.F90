@@ -344,11 +344,10 @@
       sin%Cdn_ocn = loc_r8(Cdn_ocn)
       sin%strength = loc_r8(strength)
       sin%aicen = c_null_ptr;  sin%vicen = c_null_ptr;  sin%aice0 = c_null_ptr
-      st%strength = c_null_ptr
+      st%strength = loc_r8(strength)          ! comes back halo-updated (reference: ice_dyn_evp.F90:311-312)
       if (evpk_device_strength) then
          sin%strength = c_null_ptr
          sin%aicen = loc_r8(aicen);  sin%vicen = loc_r8(vicen);  sin%aice0 = loc_r8(aice0)
-         st%strength = loc_r8(strength)
       endif
 
       st%uvel = loc_r8(uvel);  st%vvel = loc_r8(vvel)

@@ -119,7 +119,8 @@ typedef struct {
     double *tmass;                             /* AusCOM: sicemass = tmass (ice_dyn_evp.F90:205-207) */
     double *aiu, *umass, *uvel_init, *vvel_init;
     int32_t *icetmask;
-    double *strength;                          /* out, all cells: the strength the library computed (ignored when it was an input) */
+    double *strength;                          /* out, all cells: the strength with its ghost cells halo-updated, as evp leaves it
+                                                  (ice_dyn_evp.F90:311-312); may be the array evpk_step_in.strength points to */
 } evpk_state;
 
 typedef struct {

@@ -40,6 +40,8 @@ def _both(nx, ny, bsx, bsy, *, ndte=120, dt=3600.0, ncalls=1, revised_evp=False,
         assert (st.icellt, st.icellu) == (nt, nu)
         bad = util.compare(d, fg, fo)
         assert not bad, f"call {call}: {bad[:6]}"
+        if not wind_on_ugrid:      # t2ugrid_vector leaves zeros in every ghost cell (to_ugrid: work2(:,:,:) = c0, ice_grid.F90:1852)
+            assert np.array_equal(fg["strairx"], fo["strairx"]) and np.array_equal(fg["strairy"], fo["strairy"])
     assert nu > 0 and np.abs(fo["uvel"]).max() > 1e-3
     solver.close()
     return fo, fg

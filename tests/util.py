@@ -11,7 +11,7 @@ from cice5_amd import blocks, constants as C, synth
 
 SIGMA = synth.STRESS_FIELDS
 # cells the reference leaves defined after evp():
-ALL_CELLS = ["uvel", "vvel"]                       # ghost cells halo-updated (ice_dyn_evp.F90:392-407)
+ALL_CELLS = ["uvel", "vvel", "strength"]           # ghost cells halo-updated (ice_dyn_evp.F90:392-407, :311-312)
 NE_CELLS = SIGMA                                   # physical + N/E ghost T cells (ice_dyn_shared.F90:528-537)
 PHYS_CELLS = ["divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strintx", "strinty", "strocnx", "strocny",
               "strocnxT", "strocnyT", "strairx", "strairy", "strtltx", "strtlty", "fm", "tmass", "aiu", "umass",
