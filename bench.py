@@ -362,14 +362,18 @@ def cpu_baseline(d, f, a, xmin):
     p = orc.make_params(a.dt, a.ndte, xmin)
     threads = orc._limit_threads()
     nt, nu, secs = orc.evp(d, p, f, nsub=a.cpu_subcycles)
+    halo = orc.last_halo_seconds
     cores = min(threads, d.nblocks)
-    v = 0.5 * (nt + nu) * a.cpu_subcycles / secs
-    return {"value": v, "unit": "cell-updates/s", "cores": cores, "kind": "port", "per_core": v / cores,
+    n = 0.5 * (nt + nu) * a.cpu_subcycles
+    return {"value": n / secs, "unit": "cell-updates/s", "cores": cores, "kind": "port", "per_core": n / secs / cores,
+            "loop_only": n / max(secs - halo, 1e-9), "with_halo": n / secs, "halo_share": halo / secs,
             "reference_per_core_survey": 1.1e7,
             "sample": f"first {a.cpu_subcycles} of {a.ndte} subcycles of the same {d.nx_global}x{d.ny_global} state "
-                      f"({d.nblocks} blocks of {d.block_size_x}x{d.block_size_y}, OpenMP over blocks: "
-                      f"stress + stepu + halo copies), {secs:.2f} s of CPU wall time; reference_per_core_survey = the "
-                      f"reference's own whole evp on gx3, one Xeon core (SURVEY.md S8c)"}
+                      f"({d.nblocks} blocks of {d.block_size_x}x{d.block_size_y}, OpenMP over blocks as the reference's THRD "
+                      f"build): stress + stepu ({secs - halo:.2f} s) + the per-subcycle halo update of (u, v) through a "
+                      f"precomputed ghost-cell schedule ({halo:.2f} s); a C PORT of the reference loop (kind = port), "
+                      f"value = with_halo; reference_per_core_survey = the reference's own whole evp on gx3 on one "
+                      f"Xeon core (SURVEY.md S8c)"}
 
 
 if __name__ == "__main__":

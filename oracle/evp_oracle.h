@@ -169,7 +169,7 @@ void orc_halo_stress(const orc_geom *g, double *a1, const double *a2);
    nsub_override > 0 runs that many subcycles instead of ndte (the "last subcycle"
    diagnostics still fire on ksub == ndte only, as in the reference). */
 void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_override,
-             int64_t counts[2], double *loop_seconds /* wall time of the subcycle loop, may be NULL */);
+             int64_t counts[2], double *loop_seconds /* [0] wall time of the subcycle loop, [1] the halo updates' share of it; may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,7 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+last_halo_seconds = 0.0
 
 
 def _limit_threads():
@@ -99,7 +100,7 @@ def lib():
         _lib.orc_set_num_threads(nthr)
         _lib.orc_set_evp_parameters.argtypes = [ct.c_double, ct.c_int32, ct.c_int32, ct.c_double, ct.POINTER(OrcParams)]
         _lib.orc_evp.argtypes = [ct.POINTER(OrcGeom), ct.POINTER(OrcParams), ct.POINTER(OrcFields), ct.c_int,
-                                 ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double)]
+                                 ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double)]      # loop_seconds[2]
         _lib.orc_halo_r8.argtypes = [ct.POINTER(OrcGeom), c_f64p, ct.c_int, ct.c_int, ct.c_double]
         _lib.orc_halo_i4.argtypes = [ct.POINTER(OrcGeom), c_i32p, ct.c_int32]
         _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
@@ -169,10 +170,12 @@ def evp(d, params: OrcParams, f: Dict[str, np.ndarray], nsub: int = 0):
     g, keep = make_geom(d)
     of = make_fields(f)
     counts = (ct.c_int64 * 2)()
-    secs = ct.c_double(0.0)
-    lib().orc_evp(ct.byref(g), ct.byref(params), ct.byref(of), int(nsub), counts, ct.byref(secs))
+    secs = (ct.c_double * 2)(0.0, 0.0)
+    lib().orc_evp(ct.byref(g), ct.byref(params), ct.byref(of), int(nsub), counts, secs)
     del keep
-    return int(counts[0]), int(counts[1]), float(secs.value)
+    global last_halo_seconds
+    last_halo_seconds = float(secs[1])          # the halo updates' share of the loop time returned below
+    return int(counts[0]), int(counts[1]), float(secs[0])
 
 
 def halo_r8(d, a: np.ndarray, loc: int, kind: int, fill: float = 0.0):
