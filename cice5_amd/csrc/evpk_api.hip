@@ -195,6 +195,9 @@ struct evpk_ctx {
     std::vector<hipEvent_t> kev;
     float loop_ms = 0.f, kernel_ms = 0.f, kernel2_ms = 0.f;
     int kernel_launches = 0, kernel_timed = 0, kernel2_timed = 0;
+    std::vector<hipEvent_t> bev;   // event pairs around sampled halo / fold / ghost-zone updates of the subcycle loop (timer_bound)
+    int bound_updates = 0, bound_timed = 0;
+    float bound_ms = 0.f;
     std::vector<char> kev_is_double;
     int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around every 7th subcycle kernel launch (default), 2 all
     std::vector<int> kev_slot;     // launch index -> event pair index, -1 not timed
@@ -590,6 +593,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->evB1) (void)hipEventDestroy(c->evB1);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (auto e : c->kev) (void)hipEventDestroy(e);
+    for (auto e : c->bev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1246,6 +1250,23 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         c->nkev++;
         return rc;
     };
+    // the same sampling for the halo / fold / ghost-zone updates (what the reference books under timer_bound): an event pair
+    // on the stream the update runs on, every 5th update by default
+    c->bound_updates = 0; c->bound_timed = 0; c->bound_ms = 0.f;
+    bool bound_open = false;
+    auto bound_begin = [&](hipStream_t st) {
+        bound_open = c->time_kernels == 2 || (c->time_kernels == 1 && c->bound_updates % 5 == 2);
+        c->bound_updates++;
+        if (!bound_open) return;
+        while ((int)c->bev.size() < 2 * c->bound_timed + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { bound_open = false; return; } c->bev.push_back(e); }
+        (void)hipEventRecord(c->bev[2 * c->bound_timed], st);
+    };
+    auto bound_end = [&](hipStream_t st) {
+        if (!bound_open) return;
+        (void)hipEventRecord(c->bev[2 * c->bound_timed + 1], st);
+        c->bound_timed++;
+        bound_open = false;
+    };
     const bool ov_trying = c->zone_mode && !c->band_mode && !c->ov_fixed && c->ksub == 0 && nsub == c->p.ndte;
     if (ov_trying) c->overlap = (c->ov_trial != 2);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1262,7 +1283,9 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     };
     // refresh the ghost zones of state buffer `SBUF` from the neighbours (it must hold the current state)
     auto zone_exchange = [&](int SBUF) -> int {
+        bound_begin(c->stream);
         if (exchange_cols(c, state_pairs(SBUF), c->zcompact)) return 1;
+        bound_end(c->stream);
         c->zone_exchanges++;
         c->zone_bytes += (long long)(NSTATE / 2) * c->zW * 16 *
                          ((c->west >= 0 ? (c->zcompact ? c->zn[0] : s.nyl + 2) : 0) + (c->east >= 0 ? (c->zcompact ? c->zn[1] : s.nyl + 2) : 0));
@@ -1313,10 +1336,14 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 HIPCHK(c, hipEventRecord(c->evB0, c->stream));          // the previous pair (and its exchange) is complete
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evB0, 0));
                 launch_band(b1, c->stream2);
+                bound_begin(c->stream2);
                 if (halo(c, F_STATE2 + S_U, 2, true, true, 0.0, -1, c->stream2, false, a.sr + S_U)) return 1;
+                bound_end(c->stream2);
                 launch_band(b2, c->stream2, pair_ends_evp);
+                bound_begin(c->stream2);
                 // (x-slabs: the ghost-zone exchange after the pair delivers the E-W ghost columns of the new state, all rows)
                 if (halo(c, a.sw + S_U, 2, true, true, 0.0, -1, c->stream2, c->zone_mode, F_STATE2 + S_U, s.nyl - 1)) return 1;
+                bound_end(c->stream2);
                 HIPCHK(c, hipEventRecord(c->evB1, c->stream2));
                 a.jmax = s.nyl - 2;
             }
@@ -1390,7 +1417,9 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         evE_valid = false;
         c->cur ^= 1;
         if (need_halo) {                                                          // ice_dyn_evp.F90:392-400
+            bound_begin(c->stream);
             if (halo(c, (c->cur ? F_STATE1 : F_STATE0) + S_U, 2, true, true, 0.0, -1, nullptr, false, a.sr + S_U)) return 1;
+            bound_end(c->stream);
         }
         if (c->zone_mode) { c->zone_left = 0; c->inner_ok = true; }     // one ghost column is current, the deeper zone is not
     }
@@ -1404,6 +1433,15 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     if (ov_trying) {
         if (c->ov_trial >= 1) c->ov_ms[c->ov_trial - 1] = c->loop_ms;
         if (++c->ov_trial == 3) { c->overlap = (c->ov_ms[0] <= c->ov_ms[1]); c->ov_fixed = true; }
+    }
+    if (c->bound_timed) {
+        double sum = 0.0;
+        for (int k = 0; k < c->bound_timed; k++) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->bev[2 * k], c->bev[2 * k + 1]));
+            sum += ms;
+        }
+        c->bound_ms = (float)(sum / c->bound_timed * c->bound_updates);
     }
     if (c->time_kernels) {
         // mean of the timed launches of each kind, scaled to all launches of that kind
@@ -1513,6 +1551,99 @@ extern "C" int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2) {
     return 0;
 }
 
+// ---- the dynamics records of the binary restart (source/ice_restart_driver.F90:122-176 dumpfile, :295-412 restartfile) ---------
+// uvel, vvel, strocnxT, strocnyT, the twelve stresses in the order 1,3,2,4 ("read and scattered in pairs in order to properly
+// match corner values across a tripole grid cut", :343-345) and iceumask as real 0/1: one Fortran sequential unformatted
+// record each (4-byte length, the (nx_global, ny_global) real*8 array as the master task holds it after gather_global,
+// 4-byte length; io_binary/ice_restart.F90:641-684 -> ice_write 'ruf8'), big-endian under the production flags
+// (bld/Macros.nci: -convert big_endian).  Straight from / into the state resident on the device.
+static const int kRestartOrder[4] = {0, 2, 1, 3};      // sigma_1, sigma_3, sigma_2, sigma_4
+
+static void swap8(double *a, size_t n) {
+    for (size_t k = 0; k < n; k++) {
+        uint64_t v; memcpy(&v, &a[k], 8);
+        v = __builtin_bswap64(v);
+        memcpy(&a[k], &v, 8);
+    }
+}
+
+static std::vector<int> restart_fields(const evpk_ctx *c) {
+    const int SB = c->cur ? F_STATE1 : F_STATE0;
+    std::vector<int> f = {SB + S_U, SB + S_V, F_STROCNXT, F_STROCNYT};
+    for (int fam : {S_SP, S_SM, S_S12}) for (int q = 0; q < 4; q++) f.push_back(SB + fam + kRestartOrder[q]);
+    f.push_back(-1);                                   // iceumask
+    return f;
+}
+
+extern "C" int evpk_restart_write(evpk_ctx *c, const char *path, int32_t append, int32_t big_endian) {
+    if (!c || !path) return 1;
+    if (!c->uploaded) FAIL(c, "evpk_restart_write: no state on the device");
+    if (c->nranks != 1) FAIL(c, "evpk_restart_write: one rank only (the reference gathers to the master task, ice_gather_scatter.F90; download and use the host path)");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)s.nxg * s.nyg;
+    if (n * 8 > 0x7fffffffu) FAIL(c, "evpk_restart_write: record longer than a 4-byte length marker holds");
+    double *dG = nullptr;
+    HIPCHK(c, hipMalloc(&dG, n * 8));
+    std::vector<double> h(n);
+    FILE *fp = fopen(path, append ? "ab" : "wb");
+    if (!fp) { (void)hipFree(dG); FAIL(c, "evpk_restart_write: cannot open %s", path); }
+    int rc = 0;
+    for (int f : restart_fields(c)) {
+        (void)hipMemsetAsync(dG, 0, n * 8, c->stream);                     // cells of eliminated land blocks: 0
+        hipLaunchKernelGGL(k_slab_to_global, dim3((s.nxl + 127) / 128, s.nyl), dim3(128), 0, c->stream, s, f, dG);
+        if (hipMemcpyAsync(h.data(), dG, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = 1; break; }
+        uint32_t mark = (uint32_t)(n * 8);
+        if (big_endian) { swap8(h.data(), n); mark = __builtin_bswap32(mark); }
+        if (fwrite(&mark, 4, 1, fp) != 1 || fwrite(h.data(), 8, n, fp) != n || fwrite(&mark, 4, 1, fp) != 1) { rc = 2; break; }
+    }
+    fclose(fp);
+    (void)hipFree(dG);
+    if (rc) FAIL(c, "evpk_restart_write: %s", rc == 1 ? "device copy failed" : "write failed");
+    return 0;
+}
+
+extern "C" int evpk_restart_read(evpk_ctx *c, const char *path, int64_t byte_offset, int32_t big_endian) {
+    if (!c || !path) return 1;
+    if (!c->connected) FAIL(c, "evpk_connect has not been called");
+    if (c->nranks != 1) FAIL(c, "evpk_restart_read: one rank only (read on the host and upload)");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)s.nxg * s.nyg;
+    double *dG = nullptr;
+    HIPCHK(c, hipMalloc(&dG, n * 8));
+    std::vector<double> h(n);
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { (void)hipFree(dG); FAIL(c, "evpk_restart_read: cannot open %s", path); }
+    if (byte_offset > 0 && fseek(fp, (long)byte_offset, SEEK_SET) != 0) { fclose(fp); (void)hipFree(dG); FAIL(c, "evpk_restart_read: bad offset"); }
+    c->cur = 0;                                        // the state is read into buffer 0, as evpk_upload leaves it
+    int rc = 0;
+    for (int f : restart_fields(c)) {
+        uint32_t m0 = 0, m1 = 0;
+        if (fread(&m0, 4, 1, fp) != 1 || fread(h.data(), 8, n, fp) != n || fread(&m1, 4, 1, fp) != 1) { rc = 2; break; }
+        if (big_endian) { m0 = __builtin_bswap32(m0); m1 = __builtin_bswap32(m1); swap8(h.data(), n); }
+        if (m0 != (uint32_t)(n * 8) || m1 != m0) { rc = 3; break; }
+        if (hipMemcpyAsync(dG, h.data(), n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = 1; break; }
+        hipLaunchKernelGGL(k_global_to_slab, dim3((s.nxl + 127) / 128, s.nyl), dim3(128), 0, c->stream, s, f, (const double *)dG);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = 1; break; }
+    }
+    fclose(fp);
+    (void)hipFree(dG);
+    if (rc) FAIL(c, "evpk_restart_read: %s", rc == 1 ? "device copy failed" : rc == 2 ? "short read" : "record length marker does not match the grid (size / byte order?)");
+    // ghost cells as restartfile leaves them: scatter_global's halo fill by field location / type (u, v: NE corner vectors,
+    // :306-309; strocnxT/yT: centre vectors; stresses: centre scalars), then on tripole grids the twelve
+    // ice_HaloUpdate_stress calls that pair the corners across the cut (:370-395)
+    if (halo(c, F_STATE0 + S_U, 2, true, true, 0.0)) return 1;
+    if (halo(c, F_STROCNXT, 2, false, true, 0.0)) return 1;
+    if (halo(c, F_STATE0 + S_SP, 12, false, false, 0.0)) return 1;
+    if (c->ns == EVPK_BND_TRIPOLE && halo_stress12(c, F_STATE0 + S_SP)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    c->prepped = false;
+    c->fresh = true;
+    return 0;
+}
+
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
     if (!c) return 1;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1549,7 +1680,7 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->overlap_split = !c->ov_fixed ? -1 : (c->overlap ? 1 : 0);
     o->tile_kernel = (c->use_double && c->tile_mode) ? 1 : 0;
     o->kernel_timed = c->kernel_timed; o->kernel2_timed = c->kernel2_timed;
-    o->bound_ms = 0.f; o->bound_updates = 0;
+    o->bound_ms = c->bound_ms; o->bound_updates = c->bound_updates;
     o->compact_metrics = c->compact ? 1 : 0;
     o->transport = c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
     o->reserved_ = 0;

@@ -115,6 +115,22 @@ __global__ void k_scatter_m(Slab s, const BlockDesc *bd, int nxb, int nyb, const
     dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = src[mcell(s, si, sj)];
 }
 
+// restart records: physical cells of one field <-> a (ny_global, nx_global) array in global order (the layout
+// gather_global / scatter_global give the master task, ice_gather_scatter.F90); f < 0: the iceumask plane as 0 / 1
+__global__ void k_slab_to_global(Slab s, int f, double *G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y + 1;
+    if (i > s.nxl) return;
+    const double v = f >= 0 ? FD(s, f, cell(s, i, j)) : (s.iceumask[mcell(s, i, j)] ? 1.0 : 0.0);
+    G[(size_t)(s.j0 + j - 2) * s.nxg + (s.i0 + i - 2)] = v;
+}
+__global__ void k_global_to_slab(Slab s, int f, const double *G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y + 1;
+    if (i > s.nxl) return;
+    const double v = G[(size_t)(s.j0 + j - 2) * s.nxg + (s.i0 + i - 2)];
+    if (f >= 0) FD(s, f, cell(s, i, j)) = v;
+    else s.iceumask[mcell(s, i, j)] = v > 0.5 ? 1 : 0;                     // ice_restart_driver.F90:399-409
+}
+
 __global__ void k_fill_plane(Slab s, int f, double v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;

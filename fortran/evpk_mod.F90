@@ -86,7 +86,8 @@
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &
                 evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string, &
                 evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
-                evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download
+                evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
+                evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read
 
       interface
          integer (c_int) function evpk_get_unique_id (id) bind(C, name='evpk_get_unique_id')
@@ -154,6 +155,29 @@
          integer (c_int) function evpk_unpin_host (ptr) bind(C, name='evpk_unpin_host')
             import :: c_int, c_ptr
             type (c_ptr), value :: ptr
+         end function
+         ! two-phase start (nranks > 1): evpk_create with unique_id = c_null_ptr, agree across ranks, then connect
+         integer (c_int) function evpk_connect (ctx, id) bind(C, name='evpk_connect')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ctx, id
+         end function
+         integer (c_int) function evpk_device_check (device) bind(C, name='evpk_device_check')
+            import :: c_int, c_int32_t
+            integer (c_int32_t), value :: device
+         end function
+         ! the dynamics records of the binary restart (ice_restart_driver.F90:122-176, :295-412) from / into the device state
+         integer (c_int) function evpk_restart_write (ctx, path, append, big_endian) bind(C, name='evpk_restart_write')
+            import :: c_int, c_ptr, c_char, c_int32_t
+            type (c_ptr), value :: ctx
+            character (kind=c_char), dimension(*), intent(in) :: path      ! null-terminated
+            integer (c_int32_t), value :: append, big_endian
+         end function
+         integer (c_int) function evpk_restart_read (ctx, path, byte_offset, big_endian) bind(C, name='evpk_restart_read')
+            import :: c_int, c_ptr, c_char, c_int32_t, c_int64_t
+            type (c_ptr), value :: ctx
+            character (kind=c_char), dimension(*), intent(in) :: path
+            integer (c_int64_t), value :: byte_offset
+            integer (c_int32_t), value :: big_endian
          end function
          integer (c_int) function evpk_destroy (ctx) bind(C, name='evpk_destroy')
             import :: c_int, c_ptr

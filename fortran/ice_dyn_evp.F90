@@ -38,7 +38,15 @@
       public :: evp
       public :: evpk_npinned      ! (diagnostic) host arrays page-locked for in-place PCIe transfers
       public :: evpk_resident_state, evpk_state_changed_on_host, evpk_device_strength
+      public :: evpk_bound_seconds, evpk_loop_seconds
       save
+
+      ! Device time of all evp calls so far (HIP events inside the library): the ndte loop, and inside it the halo / tripole
+      ! fold / ghost-zone updates -- the share the reference books under timer_bound (ice_dyn_evp.F90:392-400).  ice_timers
+      ! offers no way to add a measured duration to a timer (its accumulators are private, mpi/ice_timers.F90), and the
+      ! updates run asynchronously beside the kernels, so the host clock cannot bracket them: a CICE timing report shows
+      ! the whole call under timer_dynamics, and these two are there to be printed beside it.
+      real (kind=dbl_kind) :: evpk_bound_seconds = 0.0_dbl_kind, evpk_loop_seconds = 0.0_dbl_kind
 
       ! .true.: ice_strength (ice_mechred.F90:2111) runs on the device inside evpk_run, from aice, vice, aicen, vicen,
       ! aice0 and the namelist switches of ice_mechred; the host then skips evp_prep1, the icetmask halo update and
@@ -243,6 +251,7 @@
       type (evpk_params)  :: p
       type (evpk_step_in) :: sin
       type (evpk_state)   :: st
+      type (evpk_stats)   :: stats
 
       call ice_timer_start(timer_dynamics) ! dynamics
 
@@ -404,6 +413,10 @@
       endif
       if (rc /= 0) call abort_ice('evp: evpk_run: '//trim(evpk_error_string(ctx)))
       evpk_state_changed_on_host = .false.
+      if (evpk_get_stats (ctx, stats) == 0) then
+         evpk_bound_seconds = evpk_bound_seconds + 1.0e-3_dbl_kind * real(stats%bound_ms, kind=dbl_kind)
+         evpk_loop_seconds  = evpk_loop_seconds  + 1.0e-3_dbl_kind * real(stats%loop_ms, kind=dbl_kind)
+      endif
 
       iceumask = (iceumask_i == 1)
 

@@ -192,6 +192,18 @@ int evpk_get_stats(evpk_ctx *c, evpk_stats *s);
  * Physical cells of sig1, sig2 (block arrays) are written. */
 int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
 
+/* The dynamics records of the reference's binary restart (source/ice_restart_driver.F90:122-176 dumpfile, :295-412
+ * restartfile; io_binary/ice_restart.F90:641-684): uvel, vvel, strocnxT, strocnyT, stressp_1,3,2,4, stressm_1,3,2,4,
+ * stress12_1,3,2,4, iceumask as real 0/1 -- 17 Fortran sequential unformatted records of the (nx_global, ny_global)
+ * real*8 array, big-endian under the production flags.  Written from / read into the state resident on the device (one
+ * rank; a multi-rank host gathers through its own path as the reference does).  evpk_restart_read fills the ghost
+ * cells as restartfile does (halo by field location and type, then the twelve ice_HaloUpdate_stress pairings on
+ * tripole grids, :370-395) and leaves the context as after evpk_upload: evpk_upload(in, NULL) may follow.
+ * byte_offset: where the first of the 17 records starts in the file (they are consecutive in this library's own files;
+ * in a full CICE restart the radiation fields sit between vvel and strocnxT, so that file goes through the host). */
+int evpk_restart_write(evpk_ctx *c, const char *path, int32_t append, int32_t big_endian);
+int evpk_restart_read(evpk_ctx *c, const char *path, int64_t byte_offset, int32_t big_endian);
+
 /* Profiling aid: nrep device-to-device copies of one scratch pair plane with the hot kernel's access
  * shape (16 B per lane, coalesced).  Each moves exactly (nxl+2)*(nyl+2)*16 bytes each way: a known
  * byte count in the PMC trace to calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */

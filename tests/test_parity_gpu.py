@@ -650,6 +650,77 @@ def test_full_size_3600x2700_tripole_config5():
     assert not util.compare(d, h1, h2)
 
 
+@pytest.mark.parametrize("ns", ["tripole", "open"])
+def test_restart_records_from_the_device_state(ns, tmp_path):
+    """evpk_restart_write / evpk_restart_read: the dynamics records of the binary restart (ice_restart_driver.F90:122-176,
+    :295-412) straight from / into the device state.  'run 2 steps' == 'run 1, write, NEW context, read, run 1', bit for
+    bit, on a tripole grid (ghost cells refilled as restartfile does, incl. the ice_HaloUpdate_stress pairings, :370-395);
+    and the file is byte-identical to what the host-side writer makes of the downloaded arrays."""
+    import io
+    from cice5_amd import restart
+    case, d, f = util.make_case(96, 64, 24, 32, ns=ns, land="continents")
+    xmin = synth.global_min_dx(case)
+
+    def step(ctx, ff, first):
+        if first:
+            ctx.upload(ff)
+        else:
+            ctx.upload_inputs(ff)
+        ctx.prep(); ctx.subcycle(20); ctx.finish()
+
+    def second_inputs(ff):
+        ff["aice"] *= 0.97
+        ff["vice"] *= 0.97
+        ff["strairxT"], ff["strairyT"] = ff["strairyT"].copy(), -ff["strairxT"]
+
+    # A: two steps in one context
+    fa = util.clone(f)
+    sa = dyn.EvpDynamics(d, fa, ndte=20, xmin=xmin)
+    sa.init_evp(3600.0)
+    step(sa.ctx, fa, True)
+    second_inputs(fa)
+    step(sa.ctx, fa, False)
+    sa.ctx.download(fa)
+    sa.close()
+    # B: one step, write
+    fb = util.clone(f)
+    sb = dyn.EvpDynamics(d, fb, ndte=20, xmin=xmin)
+    sb.init_evp(3600.0)
+    step(sb.ctx, fb, True)
+    path = str(tmp_path / "iced.dyn")
+    sb.ctx.restart_write(path)
+    sb.ctx.download(fb)
+    sb.close()
+    buf = io.BytesIO()
+    restart.write_dynamics_records(buf, d, fb)
+    assert open(path, "rb").read() == buf.getvalue()
+    # C: new context, read, second step
+    fc = util.clone(f)
+    second_inputs(fc)
+    sc = dyn.EvpDynamics(d, fc, ndte=20, xmin=xmin)
+    sc.set_evp_parameters(3600.0)
+    sc.ctx.restart_read(path)
+    step(sc.ctx, fc, False)
+    sc.ctx.download(fc)
+    sc.close()
+    assert np.abs(fa["uvel"]).max() > 1e-3
+    bad = util.compare(d, fc, fa)
+    assert not bad, bad[:6]
+
+
+def test_bound_time_is_reported():
+    """evpk_stats.bound_ms: the halo / fold updates of the subcycle loop (timer_bound in the reference) are timed with
+    sampled HIP events: none on a cyclic one-rank open grid (the kernel wraps in place), some on a tripole grid."""
+    for ns, want in (("open", False), ("tripole", True)):
+        case, d, f = util.make_case(130, 96, 130, 96, ns=ns, land="continents")
+        s = dyn.EvpDynamics(d, f, ndte=30, xmin=synth.global_min_dx(case))
+        s.init_evp(3600.0)
+        s.evp(3600.0)
+        st = s.ctx.stats()
+        assert (st.bound_updates > 0) == want and (st.bound_ms > 0.0) == want, (ns, st.bound_updates, st.bound_ms)
+        s.close()
+
+
 def test_caller_arrays_in_device_memory():
     """A host model whose fields already live on the GPU passes device pointers in place of host arrays (same block
     layout): the library reads and writes them in place.  Here the arrays are torch tensors on the device."""
