@@ -111,6 +111,94 @@ struct ShmRelay {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------
+// Peer-mapped transport (unique id "EVPKIPC:<name>"): the rank processes of ONE node map each other's receive buffers
+// (hipIpcGetMemHandle / hipIpcOpenMemHandle; between GPUs the mapping goes over xGMI, between processes on one GPU it
+// is the same HBM), so that a pack kernel stores straight into the neighbour's buffer and no copy engine, host thread or
+// RCCL kernel sits in between.  Completion: a sequence number per ordered (src, dst) pair and channel in a page of
+// page-locked host memory shared by all ranks (POSIX shared memory, hipHostRegister'ed in every process): k_ipc_signal
+// behind the storing kernel, k_ipc_wait in front of the reading one.  Buffers are double buffered by the parity of the
+// sequence number: every exchange of this library is a swap between the two ranks on one stream, so a rank that has
+// received message k+1 knows its partner is done reading message k.  Two channels (0: `stream`, 1: `stream2`) keep the
+// histories of the two streams apart.  The POSIX segment also carries the start-up data (IPC handles, slab starts).
+// ------------------------------------------------------------------------------------------------------
+struct IpcXp {
+    static constexpr int MAXR = 16;
+    int rank = 0, nranks = 0;
+    std::string name;
+    char *base = nullptr;
+    size_t total = 0, flags_off = 0, flags_bytes = 0;
+    unsigned *dflags = nullptr;              // device alias of the flag page(s)
+    bool registered = false;
+    char *mybox = nullptr;
+    char *peer[MAXR] = {};
+    size_t slot[2] = {0, 0}, chan_off[2] = {0, 0}, box_bytes = 0;
+    uint32_t sent[2][MAXR] = {}, recvd[2][MAXR] = {};
+    unsigned *d_err = nullptr;
+    struct Info { int32_t i0; int32_t stage; char pad[56]; };
+    static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+    uint64_t *magic() const { return reinterpret_cast<uint64_t *>(base); }
+    hipIpcMemHandle_t *handle(int r) const { return reinterpret_cast<hipIpcMemHandle_t *>(base + 64 + (size_t)r * 64); }
+    Info *info(int r) const { return reinterpret_cast<Info *>(base + 64 + (size_t)nranks * 64 + (size_t)r * 64); }
+    unsigned *flag(int ch, int src, int dst) const { return dflags + ((size_t)(ch * nranks + src) * nranks + dst) * 16; }
+    size_t slot_off(int ch, int parity, int src) const { return chan_off[ch] + ((size_t)parity * nranks + src) * slot[ch]; }
+    bool wait_stage(int stage, std::string &err) const {
+        const double t0 = now();
+        for (int r = 0; r < nranks; r++)
+            while (__atomic_load_n(&info(r)->stage, __ATOMIC_ACQUIRE) < stage) {
+                usleep(200);
+                if (now() - t0 > 120.0) { err = "ipc transport: rank " + std::to_string(r) + " never reached start-up stage " + std::to_string(stage); return false; }
+            }
+        return true;
+    }
+    void set_stage(int stage) { __atomic_store_n(&info(rank)->stage, stage, __ATOMIC_RELEASE); }
+    int open(const std::string &nm, int r, int n, std::string &err) {
+        if (n > MAXR) { err = "ipc transport: more than 16 ranks"; return 1; }
+        rank = r; nranks = n; name = "/" + nm;
+        flags_off = ((64 + (size_t)n * 128 + 4095) / 4096) * 4096;
+        flags_bytes = (((size_t)2 * n * n * 64 + 4095) / 4096) * 4096;
+        total = flags_off + flags_bytes;
+        int fd = -1;
+        if (r == 0) {
+            shm_unlink(name.c_str());
+            fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)total) != 0) { err = "ipc transport: cannot create " + name; return 1; }
+        } else {
+            const double t0 = now();
+            while ((fd = shm_open(name.c_str(), O_RDWR, 0600)) < 0) {
+                usleep(1000);
+                if (now() - t0 > 120.0) { err = "ipc transport: timeout opening " + name; return 1; }
+            }
+            struct stat st;
+            while (fstat(fd, &st) == 0 && (size_t)st.st_size < total) {
+                usleep(1000);
+                if (now() - t0 > 120.0) { err = "ipc transport: segment never sized"; return 1; }
+            }
+        }
+        base = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (base == MAP_FAILED) { base = nullptr; err = "ipc transport: mmap failed"; return 1; }
+        if (r == 0) { memset(base, 0, total); __atomic_store_n(magic(), 0x4950434bULL, __ATOMIC_RELEASE); }
+        else {
+            const double t0 = now();
+            while (__atomic_load_n(magic(), __ATOMIC_ACQUIRE) != 0x4950434bULL) {
+                usleep(200);
+                if (now() - t0 > 120.0) { err = "ipc transport: rank 0 never initialised the segment"; return 1; }
+            }
+        }
+        return 0;
+    }
+    void close_() {
+        if (d_err) (void)hipFree(d_err);
+        for (int q = 0; q < nranks; q++) if (q != rank && peer[q]) (void)hipIpcCloseMemHandle(peer[q]);
+        if (mybox) (void)hipFree(mybox);
+        if (registered) (void)hipHostUnregister(base + flags_off);
+        if (base) munmap(base, total);
+        base = nullptr;
+        if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
+    }
+};
+
 struct evpk_ctx {
     Slab s{};
     DevParams p{};
@@ -160,6 +248,11 @@ struct evpk_ctx {
     bool prefetch = true;           // k_subcycle2p (next row through LDS) instead of k_subcycle2; EVPK_PREFETCH=0 disables
     ncclComm_t comm = nullptr;
     ShmRelay *relay = nullptr;      // test transport instead of RCCL (unique id "EVPKSHM:<name>")
+    IpcXp *ipc = nullptr;           // peer-mapped transport (unique id "EVPKIPC:<name>")
+    // tripole fold between x-slab ranks: who needs this rank's top rows, whose rows this rank needs (mirror ranks)
+    std::vector<int> fold_dst, fold_src;
+    double *foldseg = nullptr;      // this rank's own segment (it is its own fold partner too) / local send buffer
+    double *foldrcv = nullptr;      // receive buffers, one segment of wmax columns per source rank (transports without mapped buffers)
     double *stage = nullptr;   // nblocks*nyb*nxb doubles (also reused as int32)
     size_t stage_n = 0;
     // strips
@@ -349,25 +442,71 @@ static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int 
     return 0;
 }
 
-// ---- transport primitives (device pointers, ordered on c->stream) -----------------------------------
-// ring exchange with the west / east neighbour; counts in doubles: nSW to the west, nSE to the east, nRE from the
-// east, nRW from the west.  With two ranks on a cyclic ring the neighbours coincide and one message [sW | sE] goes each
-// way, received as [rE | rW] (sE must follow sW and rW follow rE in memory).
-static int xp_ring(evpk_ctx *c, const double *sW, size_t nSW, const double *sE, size_t nSE, double *rE, size_t nRE, double *rW, size_t nRW,
-                   hipStream_t st = nullptr) {
+// ---- transport primitives (device pointers, ordered on the stream given) -----------------------------------
+static inline int xp_channel(const evpk_ctx *c, hipStream_t st) { return (st && st == c->stream2) ? 1 : 0; }
+
+// peer-mapped transport: buffers of the NEXT message to / from a rank on a channel (half `part` of the slot), then the
+// signal / wait that turn the page
+static double *ipc_send_ptr(evpk_ctx *c, int ch, int dst, int part) {
+    IpcXp &x = *c->ipc;
+    return reinterpret_cast<double *>(x.peer[dst] + x.slot_off(ch, (x.sent[ch][dst] + 1) & 1, x.rank) + (size_t)part * (x.slot[ch] / 2));
+}
+static double *ipc_recv_ptr(evpk_ctx *c, int ch, int src, int part) {
+    IpcXp &x = *c->ipc;
+    return reinterpret_cast<double *>(x.mybox + x.slot_off(ch, (x.recvd[ch][src] + 1) & 1, src) + (size_t)part * (x.slot[ch] / 2));
+}
+static int ipc_signal(evpk_ctx *c, int ch, int dst, hipStream_t st) {
+    IpcXp &x = *c->ipc;
+    hipLaunchKernelGGL(k_ipc_signal, dim3(1), dim3(1), 0, st, x.flag(ch, x.rank, dst), (unsigned)++x.sent[ch][dst]);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+static int ipc_wait(evpk_ctx *c, int ch, int src, hipStream_t st) {
+    IpcXp &x = *c->ipc;
+    hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(1), 0, st, (const unsigned *)x.flag(ch, src, x.rank), (unsigned)++x.recvd[ch][src], x.d_err,
+                       2000000000ull /* 20 s of the 100 MHz clock */);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// Ring exchange with the west / east neighbour in two steps, so that a transport with mapped buffers can hand out the
+// NEIGHBOUR'S memory as the place to pack into.  xp_ring_bufs: where the pack kernel puts the message for the west (sW) and
+// east (sE) neighbour and where the unpack kernel will find the messages from the east (rE) and west (rW) neighbour;
+// lsend / lrecv: local buffers [to west | to east] / [from east | from west] for the transports that move the bytes
+// themselves.  xp_ring: deliver (counts in doubles).  With two ranks on a cyclic ring the neighbours coincide and one
+// message [sW | sE] goes each way, received as [rE | rW].
+struct RingBufs { double *sW, *sE, *rE, *rW; };
+static void xp_ring_bufs(evpk_ctx *c, hipStream_t st, double *lsend, size_t nSW, double *lrecv, size_t nRE, RingBufs *b) {
+    b->sW = lsend; b->sE = lsend + nSW; b->rE = lrecv; b->rW = lrecv + nRE;
+    if (c->ipc) {
+        const int ch = xp_channel(c, st);
+        if (c->west >= 0) { b->sW = ipc_send_ptr(c, ch, c->west, 0); b->rW = ipc_recv_ptr(c, ch, c->west, 1); }
+        if (c->east >= 0) { b->sE = ipc_send_ptr(c, ch, c->east, 1); b->rE = ipc_recv_ptr(c, ch, c->east, 0); }
+    }
+}
+static int xp_ring(evpk_ctx *c, const RingBufs &b, size_t nSW, size_t nSE, size_t nRE, size_t nRW, hipStream_t st = nullptr) {
     if (!st) st = c->stream;
     const bool merged = (c->west == c->east && c->west >= 0);
-    if (merged && (sE != sW + nSW || rW != rE + nRE)) FAIL(c, "xp_ring: merged message needs contiguous buffers");
+    if (c->ipc) {
+        const int ch = xp_channel(c, st);
+        if ((nSW > c->ipc->slot[ch] / 16) || (nSE > c->ipc->slot[ch] / 16)) FAIL(c, "ipc transport: message larger than its slot");
+        if (c->west >= 0 && ipc_signal(c, ch, c->west, st)) return 1;
+        if (c->east >= 0 && !merged && ipc_signal(c, ch, c->east, st)) return 1;
+        if (c->east >= 0 && ipc_wait(c, ch, c->east, st)) return 1;
+        if (c->west >= 0 && !merged && ipc_wait(c, ch, c->west, st)) return 1;
+        return 0;
+    }
+    if (merged && (b.sE != b.sW + nSW || b.rW != b.rE + nRE)) FAIL(c, "xp_ring: merged message needs contiguous buffers");
     if (c->relay) {
         int rc = 0;
         if (merged) {
-            rc |= c->relay->send(c->west, sW, (nSW + nSE) * 8, st);
-            rc |= c->relay->recv(c->west, rE, (nRE + nRW) * 8, st);
+            rc |= c->relay->send(c->west, b.sW, (nSW + nSE) * 8, st);
+            rc |= c->relay->recv(c->west, b.rE, (nRE + nRW) * 8, st);
         } else {
-            if (c->west >= 0) rc |= c->relay->send(c->west, sW, nSW * 8, st);
-            if (c->east >= 0) rc |= c->relay->send(c->east, sE, nSE * 8, st);
-            if (c->east >= 0) rc |= c->relay->recv(c->east, rE, nRE * 8, st);
-            if (c->west >= 0) rc |= c->relay->recv(c->west, rW, nRW * 8, st);
+            if (c->west >= 0) rc |= c->relay->send(c->west, b.sW, nSW * 8, st);
+            if (c->east >= 0) rc |= c->relay->send(c->east, b.sE, nSE * 8, st);
+            if (c->east >= 0) rc |= c->relay->recv(c->east, b.rE, nRE * 8, st);
+            if (c->west >= 0) rc |= c->relay->recv(c->west, b.rW, nRW * 8, st);
         }
         if (rc) FAIL(c, "shared-memory relay: exchange failed (%s)", rc & 2 ? "timeout" : "copy / size");
         return 0;
@@ -378,17 +517,63 @@ static int xp_ring(evpk_ctx *c, const double *sW, size_t nSW, const double *sE, 
     ncclResult_t rc = ncclSuccess;
     auto keep = [&](ncclResult_t e) { if (rc == ncclSuccess) rc = e; };
     if (merged) {
-        if (nSW + nSE) keep(ncclSend(sW, nSW + nSE, ncclDouble, c->west, c->comm, st));
-        if (nRE + nRW) keep(ncclRecv(rE, nRE + nRW, ncclDouble, c->west, c->comm, st));
+        if (nSW + nSE) keep(ncclSend(b.sW, nSW + nSE, ncclDouble, c->west, c->comm, st));
+        if (nRE + nRW) keep(ncclRecv(b.rE, nRE + nRW, ncclDouble, c->west, c->comm, st));
     } else {
-        if (c->west >= 0 && nSW) keep(ncclSend(sW, nSW, ncclDouble, c->west, c->comm, st));
-        if (c->east >= 0 && nSE) keep(ncclSend(sE, nSE, ncclDouble, c->east, c->comm, st));
-        if (c->east >= 0 && nRE) keep(ncclRecv(rE, nRE, ncclDouble, c->east, c->comm, st));
-        if (c->west >= 0 && nRW) keep(ncclRecv(rW, nRW, ncclDouble, c->west, c->comm, st));
+        if (c->west >= 0 && nSW) keep(ncclSend(b.sW, nSW, ncclDouble, c->west, c->comm, st));
+        if (c->east >= 0 && nSE) keep(ncclSend(b.sE, nSE, ncclDouble, c->east, c->comm, st));
+        if (c->east >= 0 && nRE) keep(ncclRecv(b.rE, nRE, ncclDouble, c->east, c->comm, st));
+        if (c->west >= 0 && nRW) keep(ncclRecv(b.rW, nRW, ncclDouble, c->west, c->comm, st));
     }
     const ncclResult_t rce = ncclGroupEnd();
     if (rc != ncclSuccess) FAIL(c, "ncclSend/ncclRecv failed: %s", ncclGetErrorString(rc));
     if (rce != ncclSuccess) FAIL(c, "ncclGroupEnd failed: %s", ncclGetErrorString(rce));
+    return 0;
+}
+
+// The tripole fold between x-slab ranks: every rank's two top rows of `nf` planes go to its fold partners (the mirror rank
+// and the neighbours of it that hold the one or two columns beyond, mpi/ice_boundary.F90:2737-2913) and to itself; what
+// arrives is scattered into the global-row buffer c->foldbuf.  One packed message per partner and direction.
+static int fold_p2p(evpk_ctx *c, int fp, int nf, int fprev, hipStream_t st) {
+    Slab &s = c->s;
+    const int tx = 128, ch = xp_channel(c, st);
+    const size_t nseg = (size_t)nf * 2 * s.nxl, segcap = (size_t)c->max_nf * 2 * c->wmax;
+    DstList dl{};
+    SrcList sl{};
+    dl.p[dl.n++] = c->foldseg;
+    sl.p[sl.n] = c->foldseg; sl.i0[sl.n] = s.i0; sl.w[sl.n++] = s.nxl;
+    if (c->ipc) {
+        if (nseg * 8 > c->ipc->slot[ch] / 2) FAIL(c, "ipc transport: fold message larger than its slot");
+        for (int q : c->fold_dst) dl.p[dl.n++] = ipc_send_ptr(c, ch, q, 0);
+        for (int q : c->fold_src) { sl.p[sl.n] = ipc_recv_ptr(c, ch, q, 0); sl.i0[sl.n] = c->slab_i0[q]; sl.w[sl.n++] = c->slab_i0[q + 1] - c->slab_i0[q]; }
+    } else {
+        size_t k = 0;
+        for (int q : c->fold_src) { sl.p[sl.n] = c->foldrcv + (k++) * segcap; sl.i0[sl.n] = c->slab_i0[q]; sl.w[sl.n++] = c->slab_i0[q + 1] - c->slab_i0[q]; }
+    }
+    hipLaunchKernelGGL(k_fold_pack_multi, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, st, s, fp, nf, dl, fprev);
+    HIPCHK(c, hipGetLastError());
+    if (c->ipc) {
+        for (int q : c->fold_dst) if (ipc_signal(c, ch, q, st)) return 1;
+        for (int q : c->fold_src) if (ipc_wait(c, ch, q, st)) return 1;
+    } else if (c->relay) {
+        int rc = 0;
+        for (int q : c->fold_dst) rc |= c->relay->send(q, c->foldseg, nseg * 8, st);
+        size_t k = 0;
+        for (int q : c->fold_src) rc |= c->relay->recv(q, c->foldrcv + (k++) * segcap, (size_t)nf * 2 * (c->slab_i0[q + 1] - c->slab_i0[q]) * 8, st);
+        if (rc) FAIL(c, "shared-memory relay: fold exchange failed");
+    } else {
+        NCCLCHK(c, ncclGroupStart());
+        ncclResult_t rc = ncclSuccess;
+        auto keep = [&](ncclResult_t e) { if (rc == ncclSuccess) rc = e; };
+        for (int q : c->fold_dst) keep(ncclSend(c->foldseg, nseg, ncclDouble, q, c->comm, st));
+        size_t k = 0;
+        for (int q : c->fold_src) keep(ncclRecv(c->foldrcv + (k++) * segcap, (size_t)nf * 2 * (c->slab_i0[q + 1] - c->slab_i0[q]), ncclDouble, q, c->comm, st));
+        const ncclResult_t rce = ncclGroupEnd();
+        if (rc != ncclSuccess) FAIL(c, "fold exchange: ncclSend/ncclRecv failed: %s", ncclGetErrorString(rc));
+        if (rce != ncclSuccess) FAIL(c, "fold exchange: ncclGroupEnd failed: %s", ncclGetErrorString(rce));
+    }
+    hipLaunchKernelGGL(k_fold_unpack, dim3((c->wmax + tx - 1) / tx, sl.n), dim3(tx), 0, st, nf, s.nxg, sl, c->foldbuf);
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 
@@ -404,6 +589,16 @@ static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes, h
         return 0;
     }
     NCCLCHK(c, ncclAllGather(src, dst, bytes / 4, ncclInt32, c->comm, st));
+    return 0;
+}
+
+// peer-mapped transport: did a wait kernel give up (a partner rank that died or fell more than 20 s behind)?  Call after a
+// stream synchronisation.
+static int xp_check(evpk_ctx *c) {
+    if (!c->ipc || !c->ipc->d_err) return 0;
+    unsigned e = 0;
+    HIPCHK(c, hipMemcpy(&e, c->ipc->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e) FAIL(c, "ipc transport: %u wait(s) on a partner rank timed out; the results of this call are invalid", e);
     return 0;
 }
 
@@ -435,21 +630,25 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         const int fp = stress_mode ? fsrc_fold : f;
         if (c->nranks == 1 && !c->force_exchange) {
             hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, st, s, fp, nf, c->foldbuf, s.i0 - 1, fprev);
+        } else if (c->nranks > 1) {
+            // x-slabs: packed send / recv with the mirror ranks only
+            if (fold_p2p(c, fp, nf, fprev, st)) return 1;
         } else {
-            // pack own segment [nf][2][wmax], all-gather, re-pack into [nf][2][nxg]
+            // forced exchange on one rank (tests): own segment [nf][2][wmax] through the all-gather path, re-packed into [nf][2][nxg]
             HIPCHK(c, hipMemsetAsync(c->foldloc, 0, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax, st));
             Slab t = s; t.nxg = c->wmax;   // local segment addressed with gofs = 0
             hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, st, t, fp, nf, c->foldloc, 0, fprev);
             const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
-            if (c->nranks > 1 || c->comm) {
+            if (c->comm) {
                 if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double), st)) return 1;
             } else
                 HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(k_fold_repack, dim3((s.nxg + tx - 1) / tx), dim3(tx), 0, st, nf, c->max_nf, c->nranks, c->wmax, s.nxg,
                                (const int *)c->d_slab_i0, (const double *)c->foldall, c->foldbuf);
         }
+        // (x-slab ranks fold their own columns; the ghost columns of the two rows come with the E-W exchange that follows)
         hipLaunchKernelGGL(k_fold_apply, dim3(gcol), dim3(tx), 0, st, s, f, nf, (const double *)c->foldbuf,
-                           (necorner && !stress_mode) ? 1 : 0, (vector && !stress_mode) ? -1.0 : 1.0);
+                           (necorner && !stress_mode) ? 1 : 0, (vector && !stress_mode) ? -1.0 : 1.0, (c->nranks > 1 && !stress_mode) ? 1 : 0);
         HIPCHK(c, hipGetLastError());
         if (stress_mode) return 0;
     } else {
@@ -463,22 +662,22 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     if (c->nranks == 1 && !c->force_exchange) {
         hipLaunchKernelGGL(k_halo_ew_local, dim3(grow), dim3(tx), 0, st, s, f, nf, c->ew == EVPK_BND_CYCLIC ? 1 : 0, fill);
     } else {
-        // edge columns over all rows: sendbuf = [my W edge | my E edge], recvbuf = [east ghost | west ghost].
+        // edge columns over all rows: [my W edge | my E edge] out, [east ghost | west ghost] in.
         // The W edge goes to the west neighbour (it is their east ghost), the E edge to the east one.
         const size_t cnt = (size_t)nf * (s.nyl + 2);
-        c->sendW = c->sendbuf; c->sendE = c->sendbuf + cnt;
-        c->recvE = c->recvbuf; c->recvW = c->recvbuf + cnt;
-        hipLaunchKernelGGL(k_ew_pack, dim3(grow), dim3(tx), 0, st, s, f, nf, c->sendW, c->sendE);
+        RingBufs rb;
+        xp_ring_bufs(c, st, c->sendbuf, cnt, c->recvbuf, cnt, &rb);
+        hipLaunchKernelGGL(k_ew_pack, dim3(grow), dim3(tx), 0, st, s, f, nf, rb.sW, rb.sE);
         if (c->nranks == 1 && !c->comm) {   // forced exchange with myself (cyclic): my W edge is my own east ghost
             if (c->west >= 0) {
-                HIPCHK(c, hipMemcpyAsync(c->recvE, c->sendW, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
-                HIPCHK(c, hipMemcpyAsync(c->recvW, c->sendE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(rb.rE, rb.sW, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(rb.rW, rb.sE, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
             }
         } else {
-            if (xp_ring(c, c->sendW, cnt, c->sendE, cnt, c->recvE, cnt, c->recvW, cnt, st)) return 1;
+            if (xp_ring(c, rb, cnt, cnt, cnt, cnt, st)) return 1;
         }
-        hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, st, s, f, nf, (const double *)c->recvW,
-                           (const double *)c->recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
+        hipLaunchKernelGGL(k_ew_unpack, dim3(grow), dim3(tx), 0, st, s, f, nf, (const double *)rb.rW,
+                           (const double *)rb.rE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0, fill);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -492,12 +691,14 @@ static int halo_stress12(evpk_ctx *c, int f0) {
     if (nf > c->max_nf) FAIL(c, "halo_stress12: buffer too small");
     if (c->nranks == 1 && !c->force_exchange) {
         hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, s, f0, nf, c->foldbuf, s.i0 - 1, -1);
+    } else if (c->nranks > 1) {
+        if (fold_p2p(c, f0, nf, -1, c->stream)) return 1;
     } else {
         HIPCHK(c, hipMemsetAsync(c->foldloc, 0, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax, c->stream));
         Slab t = s; t.nxg = c->wmax;
         hipLaunchKernelGGL(k_fold_pack, dim3((s.nxl + tx - 1) / tx), dim3(tx), 0, c->stream, t, f0, nf, c->foldloc, 0, -1);
         const size_t seg = (size_t)c->max_nf * 2 * c->wmax;
-        if (c->nranks > 1 || c->comm) {
+        if (c->comm) {
             if (xp_allgather(c, c->foldloc, c->foldall, seg * sizeof(double))) return 1;
         } else
             HIPCHK(c, hipMemcpyAsync(c->foldall, c->foldloc, sizeof(double) * seg, hipMemcpyDeviceToDevice, c->stream));
@@ -551,7 +752,9 @@ static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact) {
     // double2 elements per message; the slots are laid out back to back with the actual sizes (merged messages)
     const size_t nSW = (size_t)npl * zr.sW.n * W, nSE = (size_t)npl * zr.sE.n * W;
     const size_t nRE = (size_t)npl * zr.rE.n * W, nRW = (size_t)npl * zr.rW.n * W;
-    double2 *sendW = c->cbuf, *sendE = sendW + nSW, *recvE = c->cbuf + 2 * c->cslot, *recvW = recvE + nRE;
+    RingBufs rb;      // (double2 elements counted in doubles for the transport)
+    xp_ring_bufs(c, c->stream, (double *)c->cbuf, 2 * nSW, (double *)(c->cbuf + 2 * c->cslot), 2 * nRE, &rb);
+    double2 *sendW = (double2 *)rb.sW, *sendE = (double2 *)rb.sE, *recvE = (double2 *)rb.rE, *recvW = (double2 *)rb.rW;
     const int tx = 256;
     const int nps = std::max(zr.sW.n, zr.sE.n) * W, npr = std::max(zr.rE.n, zr.rW.n) * W;
     if (nps > 0) hipLaunchKernelGGL(k_cols_pack, dim3((nps + tx - 1) / tx), dim3(tx), 0, c->stream, s, pl, W, zr, sendW, sendE);
@@ -562,7 +765,7 @@ static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact) {
             if (nSE) HIPCHK(c, hipMemcpyAsync(recvW, sendE, sizeof(double2) * nSE, hipMemcpyDeviceToDevice, c->stream));
         }
     } else {
-        if (xp_ring(c, (const double *)sendW, 2 * nSW, (const double *)sendE, 2 * nSE, (double *)recvE, 2 * nRE, (double *)recvW, 2 * nRW)) return 1;
+        if (xp_ring(c, rb, 2 * nSW, 2 * nSE, 2 * nRE, 2 * nRW)) return 1;
     }
     if (npr > 0) hipLaunchKernelGGL(k_cols_unpack, dim3((npr + tx - 1) / tx), dim3(tx), 0, c->stream, s, pl, W, zr, (const double2 *)recvW,
                        (const double2 *)recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0);
@@ -581,8 +784,9 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->relay) { c->relay->close_(); delete c->relay; }
+    if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -610,31 +814,43 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     if (c->nranks > 1) {
         if (!unique_id) FAIL(c, "nranks > 1 needs a unique id (evpk_get_unique_id on rank 0, broadcast by the host)");
+        char nm[EVPK_UNIQUE_ID_BYTES + 1];
+        memcpy(nm, (const char *)unique_id + 8, EVPK_UNIQUE_ID_BYTES - 8);
+        nm[EVPK_UNIQUE_ID_BYTES - 8] = 0;
         if (strncmp((const char *)unique_id, "EVPKSHM:", 8) == 0) {
             // test transport: host-staged relay through POSIX shared memory (several ranks on one GPU)
-            char nm[EVPK_UNIQUE_ID_BYTES + 1];
-            memcpy(nm, (const char *)unique_id + 8, EVPK_UNIQUE_ID_BYTES - 8);
-            nm[EVPK_UNIQUE_ID_BYTES - 8] = 0;
             const size_t slot = std::max<size_t>((size_t)2 * c->cslot * sizeof(double2),
                                                  (size_t)c->max_nf * 2 * (size_t)s.nxg * sizeof(double)) + 4096;
             c->relay = new ShmRelay();
             std::string err;
             if (c->relay->open(nm, c->rank, c->nranks, slot, err)) FAIL(c, "%s", err.c_str());
+        } else if (strncmp((const char *)unique_id, "EVPKIPC:", 8) == 0) {
+            // peer-mapped transport: start-up data through the POSIX segment (stage 1: slab starts)
+            c->ipc = new IpcXp();
+            std::string err;
+            if (c->ipc->open(nm, c->rank, c->nranks, err)) FAIL(c, "%s", err.c_str());
+            c->ipc->info(c->rank)->i0 = i0;
+            c->ipc->set_stage(1);
+            if (!c->ipc->wait_stage(1, err)) FAIL(c, "%s", err.c_str());
         } else {
             ncclUniqueId u;
             memcpy(&u, unique_id, sizeof(u));
             NCCLCHK(c, ncclCommInitRank(&c->comm, c->nranks, u, c->rank));
         }
-        // every rank learns all slab starts (for the tripole fold) : all-gather of i0
-        int *d_i0 = nullptr, *d_all = nullptr;
-        HIPCHK(c, hipMalloc(&d_i0, sizeof(int)));
-        HIPCHK(c, hipMalloc(&d_all, sizeof(int) * c->nranks));
-        HIPCHK(c, hipMemcpyAsync(d_i0, &i0, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        if (xp_allgather(c, d_i0, d_all, sizeof(int))) return 1;
+        // every rank learns all slab starts (the tripole fold partners follow from them)
         c->slab_i0.resize(c->nranks + 1);
-        HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * c->nranks, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(d_i0); (void)hipFree(d_all);
+        if (c->ipc) {
+            for (int r = 0; r < c->nranks; r++) c->slab_i0[r] = c->ipc->info(r)->i0;
+        } else {
+            int *d_i0 = nullptr, *d_all = nullptr;
+            HIPCHK(c, hipMalloc(&d_i0, sizeof(int)));
+            HIPCHK(c, hipMalloc(&d_all, sizeof(int) * c->nranks));
+            HIPCHK(c, hipMemcpyAsync(d_i0, &i0, sizeof(int), hipMemcpyHostToDevice, c->stream));
+            if (xp_allgather(c, d_i0, d_all, sizeof(int))) return 1;
+            HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * c->nranks, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(d_i0); (void)hipFree(d_all);
+        }
         c->slab_i0[c->nranks] = s.nxg + 1;
         c->wmax = 0;
         for (int r = 0; r < c->nranks; r++) {
@@ -643,10 +859,53 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
         }
         if (c->slab_i0[c->rank] != i0 || c->slab_i0[c->rank + 1] != i1 + 1) FAIL(c, "slabs do not tile the global x range");
         if (c->ns == EVPK_BND_TRIPOLE) {
-            HIPCHK(c, hipMalloc(&c->foldloc, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
-            HIPCHK(c, hipMalloc(&c->foldall, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax * c->nranks));
-            HIPCHK(c, hipMalloc(&c->d_slab_i0, sizeof(int) * (c->nranks + 1)));
-            HIPCHK(c, hipMemcpy(c->d_slab_i0, c->slab_i0.data(), sizeof(int) * (c->nranks + 1), hipMemcpyHostToDevice));
+            // fold partners: rank r reads the rows at the mirrored columns nx - g (NE corner) and nx - g + 1 (centre) for
+            // g = i0-1 .. i1+1 (the stress fold also fills its ghost columns), i.e. columns nx - i1 - 1 .. nx - i0 + 2; the
+            // relation is kept symmetric (every pair swaps segments), which also keeps double buffering safe
+            std::vector<char> pr((size_t)c->nranks * c->nranks, 0);
+            auto owner = [&](int g) { while (g < 1) g += s.nxg; while (g > s.nxg) g -= s.nxg; int r = 0; while (g >= c->slab_i0[r + 1]) r++; return r; };
+            for (int r = 0; r < c->nranks; r++)
+                for (int g = s.nxg - (c->slab_i0[r + 1] - 1) - 1; g <= s.nxg - c->slab_i0[r] + 2; g++) {
+                    const int q = owner(g);
+                    if (q != r) pr[(size_t)r * c->nranks + q] = pr[(size_t)q * c->nranks + r] = 1;
+                }
+            for (int q = 0; q < c->nranks; q++) if (pr[(size_t)c->rank * c->nranks + q]) { c->fold_dst.push_back(q); c->fold_src.push_back(q); }
+            if (c->fold_dst.size() > 5) FAIL(c, "tripole fold: %d partner ranks (slab widths too uneven)", (int)c->fold_dst.size());
+            HIPCHK(c, hipMalloc(&c->foldseg, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax));
+            HIPCHK(c, hipMalloc(&c->foldrcv, sizeof(double) * (size_t)c->max_nf * 2 * c->wmax * std::max<size_t>(1, c->fold_src.size())));
+        }
+        if (c->ipc) {
+            // stage 2: receive buffers of identical layout on every rank -- per channel [2 parities][nranks sources][slot]
+            IpcXp &x = *c->ipc;
+            const size_t fold_msg = (size_t)c->max_nf * 2 * c->wmax * sizeof(double);
+            x.slot[0] = 2 * std::max<size_t>(c->cslot * sizeof(double2), fold_msg);
+            x.slot[1] = 2 * std::max<size_t>((size_t)c->max_nf * (s.nyl + 2) * sizeof(double), fold_msg);
+            x.chan_off[0] = 0;
+            x.chan_off[1] = 2 * (size_t)c->nranks * x.slot[0];
+            x.box_bytes = x.chan_off[1] + 2 * (size_t)c->nranks * x.slot[1];
+            std::string err;
+            HIPCHK(c, hipMalloc(&x.mybox, x.box_bytes));
+            HIPCHK(c, hipMemset(x.mybox, 0, x.box_bytes));
+            hipIpcMemHandle_t h;
+            HIPCHK(c, hipIpcGetMemHandle(&h, x.mybox));
+            memcpy(x.handle(c->rank), &h, sizeof(h));
+            x.set_stage(2);
+            if (!x.wait_stage(2, err)) FAIL(c, "%s", err.c_str());
+            for (int q = 0; q < c->nranks; q++) {
+                if (q == c->rank) { x.peer[q] = x.mybox; continue; }
+                hipIpcMemHandle_t hq;
+                memcpy(&hq, x.handle(q), sizeof(hq));
+                void *pq = nullptr;
+                HIPCHK(c, hipIpcOpenMemHandle(&pq, hq, hipIpcMemLazyEnablePeerAccess));
+                x.peer[q] = (char *)pq;
+            }
+            HIPCHK(c, hipHostRegister(x.base + x.flags_off, x.flags_bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+            x.registered = true;
+            HIPCHK(c, hipHostGetDevicePointer((void **)&x.dflags, x.base + x.flags_off, 0));
+            HIPCHK(c, hipMalloc(&x.d_err, sizeof(unsigned)));
+            HIPCHK(c, hipMemset(x.d_err, 0, sizeof(unsigned)));
+            x.set_stage(3);         // everything mapped: from here on only kernels touch the shared pages
+            if (!x.wait_stage(3, err)) FAIL(c, "%s", err.c_str());
         }
     } else {
         c->slab_i0 = {1, s.nxg + 1};
@@ -1211,6 +1470,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         c->zcompact = true;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (xp_check(c)) return 1;
     c->icellt = (long long)cnt[0];
     c->icellu = (long long)cnt[1];
     if (c->tuned_icellt == -2) c->tuned_icellt = c->icellt;
@@ -1430,6 +1690,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
+    if (xp_check(c)) return 1;
     if (ov_trying) {
         if (c->ov_trial >= 1) c->ov_ms[c->ov_trial - 1] = c->loop_ms;
         if (++c->ov_trial == 3) { c->overlap = (c->ov_ms[0] <= c->ov_ms[1]); c->ov_fixed = true; }
@@ -1528,7 +1789,7 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
         for (size_t k = 0; k < tmp.size(); k++) st->icetmask[k] = (int32_t)tmp[k];
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));      // scatter kernels into page-locked host arrays
-    return 0;
+    return xp_check(c);
 }
 
 extern "C" int evpk_run(evpk_ctx *c, const evpk_step_in *in, evpk_state *st) {
@@ -1682,7 +1943,7 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->kernel_timed = c->kernel_timed; o->kernel2_timed = c->kernel2_timed;
     o->bound_ms = c->bound_ms; o->bound_updates = c->bound_updates;
     o->compact_metrics = c->compact ? 1 : 0;
-    o->transport = c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
+    o->transport = c->ipc ? EVPK_XP_IPC : c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
     o->reserved_ = 0;
     return 0;
 }

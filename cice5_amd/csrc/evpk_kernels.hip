@@ -539,13 +539,71 @@ __global__ void k_fold_repack(int nf, int nfmax, int nranks, int wmax, int nxg, 
     for (int q = 0; q < nf * 2; q++) fb[(size_t)q * nxg + (g - 1)] = all[(size_t)r * seg + (size_t)q * wmax + (g - i0[r])];
 }
 
+// ---- the fold between x-slab ranks as a point-to-point exchange with the mirror ranks -------------------------------
+// The rows the fold of MY columns reads sit at the mirrored columns nx - g (NE corner) and nx - g + 1 (centre), g = i0 ..
+// i1: the slab of the mirror rank P-1-r plus one column of each of its neighbours -- what the reference exchanges too
+// (one tripole message per neighbour rank, mpi/ice_boundary.F90:2737-2913, :6128-6168).  Every rank packs the two top rows
+// of its own columns once, [nf][2][nxl], straight into the buffer of each rank that needs them (itself included; through
+// peer-mapped memory where the transport offers it), and scatters what it receives into the global-row buffer the apply
+// kernels read.
+struct DstList { int n; double *p[6]; };
+struct SrcList { int n; const double *p[6]; int i0[6]; int w[6]; };
+
+// segment layout: seg[(q*2 + r)*nxl + (i-1)], r = 0: row nyl-1, r = 1: row nyl; `stale` as in k_fold_pack
+__global__ void k_fold_pack_multi(Slab s, int f, int nf, DstList dl, int fprev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i > s.nxl) return;
+    const bool stale = fprev >= 0 && !(s.cmask[mcell(s, i, s.nyl)] & CM_U);
+    for (int q = 0; q < nf; q++) {
+        const double r0 = FD(s, f + q, cell(s, i, s.nyl - 1));
+        const double r1 = FD(s, (stale ? fprev : f) + q, cell(s, i, s.nyl));
+        for (int d = 0; d < dl.n; d++) {
+            dl.p[d][((size_t)q * 2 + 0) * s.nxl + (i - 1)] = r0;
+            dl.p[d][((size_t)q * 2 + 1) * s.nxl + (i - 1)] = r1;
+        }
+    }
+}
+
+// received segments -> the global fold buffer [nf*2][nxg] (columns no segment covers are not read by this rank's apply)
+__global__ void k_fold_unpack(int nf, int nxg, SrcList sl, double *fb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int src = blockIdx.y;
+    if (src >= sl.n || t >= sl.w[src]) return;
+    const double *seg = sl.p[src];
+    const int w = sl.w[src], g = sl.i0[src] + t;
+    for (int q = 0; q < nf * 2; q++) fb[(size_t)q * nxg + (g - 1)] = seg[(size_t)q * w + t];
+}
+
+// ---- peer-mapped transport: completion flags (page-locked host memory shared by the rank processes) ----------------
+// k_ipc_signal runs behind the kernel that stored into the peer's buffer (the kernel boundary is the release: the stores
+// have landed); k_ipc_wait runs in front of the kernel that reads this rank's buffer (the boundary after it is the
+// acquire).  The spin is bounded twice -- a wall-clock limit and an iteration cap -- and reports through *err instead of
+// hanging: every wave ends.
+__global__ void k_ipc_signal(unsigned *flag, unsigned seq) {
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_ipc_wait(const unsigned *flag, unsigned seq, unsigned *err, unsigned long long limit_ticks /* 100 MHz */) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned it = 0; it < (1u << 26); it++) {
+        // (sequence numbers wrap: compare as a signed distance)
+        if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(20);
+        if (wall_clock64() - t0 > limit_ticks) break;
+    }
+    atomicAdd(err, 1u);
+}
+
 // u-fold copy-out (serial/ice_boundary.F90:801-888, copy lists :3752-3776)
 //   center  : ghost(i,ny+1) = sgn*B2(nx-g+1)
 //   NEcorner: top(i,ny) = sgn*sym(B2)(nx-g), ghost(i,ny+1) = sgn*B1(nx-g), index 0 -> nx
 //   stress  : (ice_HaloUpdate_stress) center rule, no sign, source plane differs from dest
-__global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int necorner, double sgn) {
+__global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int necorner, double sgn, int own_only = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // local col 0..nxl+1
     if (i > s.nxl + 1) return;
+    if (own_only && (i < 1 || i > s.nxl)) return;              // x-slab ranks: the ghost columns come with the E-W exchange that follows
     const int nx = s.nxg;
     int g = s.i0 + i - 1;                                       // global col, wrap
     if (g < 1) g += nx;
@@ -579,9 +637,10 @@ __global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int nec
 // takes the top physical row of its partner (1 <-> 3, 2 <-> 4 within stressp, stressm, stress12) at the mirrored column,
 // center rule, no sign.  The sources are physical rows that none of the twelve updates writes, so their order is immaterial.
 // fb: k_fold_pack of the twelve planes.
-__global__ void k_fold_apply_stress12(Slab s, int fdst0, const double *fb) {
+__global__ void k_fold_apply_stress12(Slab s, int fdst0, const double *fb, int own_only = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // local col 0..nxl+1
     if (i > s.nxl + 1) return;
+    if (own_only && (i < 1 || i > s.nxl)) return;
     const int nx = s.nxg;
     int g = s.i0 + i - 1;
     if (g < 1) g += nx;

@@ -1,8 +1,12 @@
-"""Real multi-rank runs of libevpk on ONE GPU: K processes, each with its own x-slab and context, exchanging
-through the host-staged shared-memory relay (unique id "EVPKSHM:<name>") that stands in for the RCCL
-point-to-point calls, which refuse several ranks on one device.  Everything else is the production
-multi-rank path: slabs with i0 > 1, edge-column / two-column ghost-zone exchange, the edge-first overlap on two
-streams, the tripole fold through the all-gather.  Each rank compares its slab with the single-process oracle."""
+"""Real multi-rank runs of libevpk on ONE GPU: K processes, each with its own x-slab and context, exchanging through
+  * "ipc": the peer-mapped transport (unique id "EVPKIPC:<name>") -- the ranks map each other's receive buffers with
+    hipIpcOpenMemHandle, pack kernels store straight into the neighbour's buffer, completion by flags the consumer's
+    stream waits on; between GPUs the same stores go over xGMI, here all ranks share the one GPU;
+  * "shm": the host-staged shared-memory relay (unique id "EVPKSHM:<name>") with the semantics of the RCCL
+    point-to-point calls, which refuse several ranks on one device.
+Everything else is the production multi-rank path: slabs with i0 > 1, edge-column / ghost-zone exchange, the edge-first
+overlap on two streams, the tripole fold as a packed exchange with the mirror ranks.  Each rank compares its slab with
+the single-process oracle."""
 import os
 import sys
 import traceback
@@ -54,7 +58,8 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
         d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=ns)
         f = synth.make_block_fields(case, d)
         xmin = synth.global_min_dx(case)
-        uid = (b"EVPKSHM:" + tag.encode()).ljust(128, b"\0")
+        xp = env.get("TEST_XP", "shm")
+        uid = ({"shm": b"EVPKSHM:", "ipc": b"EVPKIPC:"}[xp] + tag.encode()).ljust(128, b"\0")
         s = dyn.EvpDynamics(d, f, ndte=ndte, xmin=xmin, device=0, unique_id=uid)
         s.init_evp(3600.0)
         # reference: whole domain, same block size, in this process
@@ -83,14 +88,17 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
             bad += [(call,) + x for x in util.compare(d, f, ref)]
         st = s.ctx.stats()
         s.close()
+        if int(st.transport) != {"shm": 2, "ipc": 3}[xp]:
+            bad.append(("transport", int(st.transport)))
         q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()), time.time() - t0,
                int(st.zone_cols), int(st.zone_exchanges)))
     except Exception:
         q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0, 0, 0))
 
 
-def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None):
+def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None, xp="shm"):
     import multiprocessing as mp
+    env = dict(env or {}, TEST_XP=xp)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     tag = "evpk_t_" + uuid.uuid4().hex[:12]
@@ -118,59 +126,68 @@ def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None):
     return res
 
 
+XPS = ["ipc", "shm"]
+
+
+@pytest.mark.parametrize("xp", XPS)
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_x_slabs_open(world):
-    res = _run(world, "open", 240, 64, 20, 32, ndte=31)
+def test_x_slabs_open(world, xp):
+    res = _run(world, "open", 240, 64, 20, 32, ndte=31, xp=xp)
     assert all(r[3] > 0 for r in res)          # the two-subcycle kernel ran on every rank (ghost-zone mode)
     assert all(r[6] == 8 for r in res)         # default: zones of 8 columns, an exchange every 4th launch
 
 
 @pytest.mark.parametrize("m", [1, 2, 3])
-def test_ghost_zone_depth(m):
+def test_ghost_zone_depth(m, xp="ipc"):
     """EVPK_ZONE_M launches of the two-subcycle kernel per exchange (zones of 2*m columns, default 4): the redundant
     zone columns and the compacted row lists must leave every rank bit-identical to the oracle.  Odd ndte and a
     second call cover the one-subcycle tail and the re-made row lists."""
-    res = _run(3, "open", 240, 64, 20, 32, ndte=31, env={"EVPK_ZONE_M": str(m)})
+    res = _run(3, "open", 240, 64, 20, 32, ndte=31, env={"EVPK_ZONE_M": str(m)}, xp=xp)
     assert all(r[3] > 0 for r in res)
     # 15 two-subcycle launches + the one-subcycle tail (its own one-column halo): an exchange after every m-th launch
     assert all(r[6] == 2 * m and r[7] == 15 // m for r in res), [(r[6], r[7]) for r in res]
-    _run(2, "open", 240, 64, 40, 64, ndte=26, env={"EVPK_ZONE_M": str(m), "EVPK_OVERLAP": "0"})
+    _run(2, "open", 240, 64, 40, 64, ndte=26, env={"EVPK_ZONE_M": str(m), "EVPK_OVERLAP": "0"}, xp=xp)
 
 
 def test_narrow_slabs_limit_the_zone_depth():
     """Slabs of 6 columns can only feed zones of 6 (m = 3); slabs of 4 columns zones of 4."""
-    assert all(r[6] == 6 for r in _run(4, "open", 24, 40, 6, 20, ndte=22))
-    assert all(r[6] == 4 for r in _run(4, "open", 16, 40, 4, 20, ndte=22))
+    assert all(r[6] == 6 for r in _run(4, "open", 24, 40, 6, 20, ndte=22, xp="ipc"))
+    assert all(r[6] == 4 for r in _run(4, "open", 16, 40, 4, 20, ndte=22, xp="shm"))
 
 
+@pytest.mark.parametrize("xp", XPS)
 @pytest.mark.parametrize("ns", ["open", "tripole"])
-def test_soak_wandering_ice_across_slabs(ns):
+def test_soak_wandering_ice_across_slabs(ns, xp):
     """Eight consecutive evp() calls on three x-slabs while the ice cover wanders across the slab boundaries (and, on the
     tripole grid, across the fold): the ghost-zone row lists, strip lists and tile flags change every call."""
-    res = _run(3, ns, 240, 72, 20, 36, ndte=14, env={"TEST_WANDER_CALLS": "8"})
+    res = _run(3, ns, 240, 72, 20, 36, ndte=14, env={"TEST_WANDER_CALLS": "8"}, xp=xp)
     assert all(r[3] > 0 for r in res)
 
 
 def test_cfg4_1440x1080_on_four_ranks():
     """BASELINE config 4 shape: 1440x1080 in 30x27 blocks (bld/config.nci.auscom.1440x1080) on 4 x-slabs;
     a short loop (ndte = 10) keeps the single-process oracle cheap."""
-    _run(4, "open", 1440, 1080, 30, 27, ndte=10)
+    _run(4, "open", 1440, 1080, 30, 27, ndte=10, xp="ipc")
 
 
-def test_cfg5_tripole_slabs_eight_wide_grid():
+@pytest.mark.parametrize("xp", XPS)
+def test_cfg5_tripole_slabs_eight_wide_grid(xp):
     """BASELINE config 5 decomposition in miniature: tripole grid, 4 slabs of a 3600-column grid, few rows."""
-    _run(4, "tripole", 3600, 64, 450, 32, ndte=12)
+    _run(4, "tripole", 3600, 64, 450, 32, ndte=12, xp=xp)
 
 
-def test_x_slabs_tripole():
-    _run(2, "tripole", 240, 64, 20, 32, ndte=24)
-    _run(4, "tripole", 240, 64, 30, 16, ndte=13)
+@pytest.mark.parametrize("xp", XPS)
+def test_x_slabs_tripole(xp):
+    _run(2, "tripole", 240, 64, 20, 32, ndte=24, xp=xp)
+    _run(4, "tripole", 240, 64, 30, 16, ndte=13, xp=xp)
+    _run(3, "tripole", 240, 64, 20, 32, ndte=10, xp=xp)          # uneven mirror: 3 slabs
 
 
 def test_x_slabs_one_subcycle_kernel_and_serial_exchange():
-    _run(3, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"})
-    _run(2, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_OVERLAP": "0"})
-    _run(2, "tripole", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"})
+    _run(3, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"}, xp="ipc")
+    _run(2, "open", 240, 64, 40, 64, ndte=20, env={"EVPK_OVERLAP": "0"}, xp="ipc")
+    _run(2, "tripole", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"}, xp="ipc")
+    _run(2, "tripole", 240, 64, 40, 64, ndte=20, env={"EVPK_DOUBLE": "0"}, xp="shm")
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_MR_N", "8"))))
@@ -195,5 +212,6 @@ def test_random_multirank_configuration(seed):
     if rng.random() < 0.5:
         env["TEST_WANDER_CALLS"] = "3"
     ndte = int(rng.choice([5, 8, 13]))
-    print("config:", world, ns, nx, ny, bsx, bsy, ndte, env)
-    _run(world, ns, nx, ny, bsx, bsy, ndte=ndte, env=env)
+    xp = XPS[seed % 2]
+    print("config:", world, ns, nx, ny, bsx, bsy, ndte, env, xp)
+    _run(world, ns, nx, ny, bsx, bsy, ndte=ndte, env=env, xp=xp)
