@@ -884,7 +884,19 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             x.chan_off[1] = 2 * (size_t)c->nranks * x.slot[0];
             x.box_bytes = x.chan_off[1] + 2 * (size_t)c->nranks * x.slot[1];
             std::string err;
-            HIPCHK(c, hipMalloc(&x.mybox, x.box_bytes));
+            {   // The receive buffers are written by kernels of OTHER devices while this device holds lines of them in
+                // its L2s: uncached (fine-grained) device memory keeps that coherent without relying on the kernel-boundary
+                // invalidates (what RCCL does for its own peer buffers); EVPK_IPC_MEM=coarse takes plain hipMalloc memory.
+                const char *e = getenv("EVPK_IPC_MEM");
+                const bool coarse = e && strcmp(e, "coarse") == 0;
+                void *p = nullptr;
+                if (coarse || (hipExtMallocWithFlags(&p, x.box_bytes, hipDeviceMallocUncached) != hipSuccess &&
+                               hipExtMallocWithFlags(&p, x.box_bytes, hipDeviceMallocFinegrained) != hipSuccess)) {
+                    (void)hipGetLastError();
+                    HIPCHK(c, hipMalloc(&p, x.box_bytes));
+                }
+                x.mybox = (char *)p;
+            }
             HIPCHK(c, hipMemset(x.mybox, 0, x.box_bytes));
             hipIpcMemHandle_t h;
             HIPCHK(c, hipIpcGetMemHandle(&h, x.mybox));
