@@ -262,6 +262,10 @@ struct evpk_ctx {
     long long tuned_icellt = -1;
     int slots2 = 512;                // resident 256-thread workgroups of k_subcycle2 on the whole chip
     int nsimd = 1024;                // SIMDs of the chip (4 per CU)
+    unsigned char *io_raw = nullptr, *io_act = nullptr;   // sparse I/O: tiles whose inputs are uploaded this step
+    long long evp_count = 0;         // evpk_prep calls so far
+    long long last_dl[F_COUNT] = {};  // evp_count at which each field was last downloaded (state fields under their F_STATE0 ids)
+    bool io_sparse_now = false;      // the last evpk_upload was a sparse one: evpk_download may skip inactive tiles too
     bool tile_mode = false;          // the pairs run k_subcycle2t (one row per wave, no march): chosen by tune_R2 when strips are scarce
     int tile_force = -1;             // EVPK_TILE=0 / 1 fixes the choice
     unsigned int *d_tune = nullptr;
@@ -377,7 +381,7 @@ static void *mapped_alias(const void *host) {
 
 // ---- host<->device transfer of one field -------------------------------------------------
 // (asynchronous on c->stream; evpk_upload / evpk_download synchronise once at their end)
-static int upload_f(evpk_ctx *c, const double *host, int f) {
+static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char *act = nullptr) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     const double *src = (const double *)mapped_alias(host);
@@ -387,7 +391,7 @@ static int upload_f(evpk_ctx *c, const double *host, int f) {
     }
     if (!c->full_cover) hipLaunchKernelGGL(k_fill_plane, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, f, 0.0);
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    hipLaunchKernelGGL(k_gather_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, f);
+    hipLaunchKernelGGL(k_gather_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, f, act);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -408,12 +412,12 @@ static int upload_m(evpk_ctx *c, const int32_t *host, int32_t *dev_plane) {
 }
 
 // staged downloads start from the caller's bytes so that cells the reference leaves untouched keep their values
-static int download_f(evpk_ctx *c, double *host, int f, int mode) {
+static int download_f(evpk_ctx *c, double *host, int f, int mode, const unsigned char *act = nullptr) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
     if (double *dst = (double *)mapped_alias(host)) {
-        hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, dst, mode);
+        hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, dst, mode, act);
         HIPCHK(c, hipGetLastError());
         return 0;
     }
@@ -786,7 +790,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1204,6 +1208,7 @@ extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
     d.tilt_from_slope = p->tilt_from_slope; d.wind_on_ugrid = p->wind_on_ugrid;
     d.kstrength = p->kstrength; d.krdg_partic = p->krdg_partic; d.krdg_redist = p->krdg_redist; d.ncat = p->ncat;
     d.mu_rdg = p->mu_rdg; d.Cf = p->Cf;
+    d.sparse_io = p->sparse_io;
     if ((p->revised_evp != 0) != (p->revp == 1.0)) FAIL(c, "revised_evp and revp disagree");
     c->have_params = true;
     return 0;
@@ -1216,6 +1221,23 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
     if (!st && !c->uploaded) FAIL(c, "the first evpk_upload needs the state");
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
+    // sparse transfers (evpk_params.sparse_io, resident state, a prep behind us): aice / vice / vsno whole, the tiles they put
+    // ice in -- or that were active at the previous evp -- for everything else
+    const bool sparse = c->p.sparse_io && !st && c->uploaded && !c->fresh;
+    const unsigned char *act = nullptr;
+    if (sparse) {
+        if (!c->io_raw) {
+            HIPCHK(c, hipMalloc(&c->io_raw, (size_t)s.ntx * s.nty));
+            HIPCHK(c, hipMalloc(&c->io_act, (size_t)s.ntx * s.nty));
+        }
+        if (!in->aice || !in->vice || !in->vsno) FAIL(c, "a required input pointer is NULL");
+        if (upload_f(c, in->aice, F_AICE) || upload_f(c, in->vice, F_VICE) || upload_f(c, in->vsno, F_VSNO)) return 1;
+        hipLaunchKernelGGL(k_io_tiles, grid2d(s, B2D), B2D, 0, c->stream, s, c->p, c->io_raw);
+        hipLaunchKernelGGL(k_io_tiles_dilate, dim3((s.ntx + 63) / 64, s.nty), dim3(64), 0, c->stream, s, (const unsigned char *)c->io_raw, c->io_act);
+        HIPCHK(c, hipGetLastError());
+        act = c->io_act;
+    }
+    c->io_sparse_now = sparse;
     struct { const double *h; int f; bool need; } ip[] = {
         {in->aice, F_AICE, true}, {in->vice, F_VICE, true}, {in->vsno, F_VSNO, true}, {in->aice_init, F_AICE_INIT, true},
         {in->uocn, F_UOCN, true}, {in->vocn, F_VOCN, true}, {in->Cdn_ocn, F_CW, true}, {in->strength, F_STRENGTH, false},
@@ -1225,7 +1247,8 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
         {c->p.wind_on_ugrid ? in->stray : in->strairyT, F_STRAIRYT, true}};
     for (auto &e : ip) {
         if (!e.h) { if (e.need) FAIL(c, "a required input pointer is NULL"); continue; }
-        if (upload_f(c, e.h, e.f)) return 1;
+        if (sparse && (e.f == F_AICE || e.f == F_VICE || e.f == F_VSNO)) continue;      // (uploaded whole above)
+        if (upload_f(c, e.h, e.f, act)) return 1;
     }
     c->strength_dev = (in->strength == nullptr);
     if (c->strength_dev && c->p.kstrength == 1) {
@@ -1488,6 +1511,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     if (c->tuned_icellt == -2) c->tuned_icellt = c->icellt;
     c->ksub = 0;
     c->prepped = true;
+    c->evp_count++;
     return 0;
 }
 
@@ -1772,13 +1796,23 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
     const int SB = c->cur ? F_STATE1 : F_STATE0;
-    if (download_f(c, st->uvel, SB + S_U, MODE_ALL)) return 1;
-    if (download_f(c, st->vvel, SB + S_V, MODE_ALL)) return 1;
+    // sparse transfers: tiles that are inactive now and were at the previous evp hold the same zeros on both sides (s.act_any)
+    // ... which is only known of an array that was also delivered after the previous evp: one that the caller fetches now
+    // and then (restart, history) is delivered whole
+    const unsigned char *act_all = (c->io_sparse_now && c->prepped) ? s.act_any : nullptr;
+    auto dl = [&](double *h, int f, int mode, int id, bool never_sparse = false) -> int {
+        if (!h) return 0;
+        const unsigned char *a = (!never_sparse && act_all && c->last_dl[id] == c->evp_count - 1) ? act_all : nullptr;
+        c->last_dl[id] = c->evp_count;
+        return download_f(c, h, f, mode, a);
+    };
+    if (dl(st->uvel, SB + S_U, MODE_ALL, F_STATE0 + S_U)) return 1;
+    if (dl(st->vvel, SB + S_V, MODE_ALL, F_STATE0 + S_V)) return 1;
     const int smode = (c->ns == EVPK_BND_TRIPOLE) ? MODE_NE_FOLD : MODE_NE;
     for (int q = 0; q < 4; q++) {
-        if (download_f(c, st->stressp[q], SB + S_SP + q, smode)) return 1;
-        if (download_f(c, st->stressm[q], SB + S_SM + q, smode)) return 1;
-        if (download_f(c, st->stress12[q], SB + S_S12 + q, smode)) return 1;
+        if (dl(st->stressp[q], SB + S_SP + q, smode, F_STATE0 + S_SP + q)) return 1;
+        if (dl(st->stressm[q], SB + S_SM + q, smode, F_STATE0 + S_SM + q)) return 1;
+        if (dl(st->stress12[q], SB + S_S12 + q, smode, F_STATE0 + S_S12 + q)) return 1;
     }
     if (download_m(c, st->iceumask, s.iceumask, MODE_PHYS)) return 1;
     struct { double *h; int f; } op[] = {
@@ -1790,7 +1824,7 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
     for (auto &e : op) {
         // strairx/y after t2ugrid_vector: to_ugrid zeroes the whole array before it fills the physical cells (ice_grid.F90:1852)
         const bool zg = (e.f == F_STRAIRX || e.f == F_STRAIRY) && !c->p.wind_on_ugrid;
-        if (download_f(c, e.h, e.f, zg ? MODE_PHYS_ZG : MODE_PHYS)) return 1;
+        if (dl(e.h, e.f, zg ? MODE_PHYS_ZG : MODE_PHYS, e.f, zg)) return 1;
     }
     // the strength with its ghost cells halo-updated, as evp leaves it (ice_dyn_evp.F90:311-312) -- also when it was an input
     if (download_f(c, st->strength, F_STRENGTH, MODE_ALL)) return 1;

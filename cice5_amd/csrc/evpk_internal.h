@@ -86,6 +86,7 @@ struct DevParams {
     int ndte, tilt_from_slope, wind_on_ugrid;
     int kstrength, krdg_partic, krdg_redist, ncat;
     double mu_rdg, Cf;
+    int sparse_io;
 };
 
 // block descriptors on the device (gather / scatter)

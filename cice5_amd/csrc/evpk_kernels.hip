@@ -35,7 +35,9 @@ __device__ __forceinline__ bool gather_take(const Slab &s, const BlockDesc &d, i
 }
 
 // double fields: destination / source is field f of the pair-interleaved slab
-__global__ void k_gather_f(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, int f) {
+// `act` (optional): tile activity flags -- cells of inactive 64x4-cell tiles are not transferred (sparse I/O: with the
+// caller's array page-locked the kernel reads it in place over PCIe, so skipped cells cost no PCIe traffic)
+__global__ void k_gather_f(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, int f, const unsigned char *act = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;   // 1-based block column
     const int j = blockIdx.y + 1;
     const int b = blockIdx.z;
@@ -44,6 +46,7 @@ __global__ void k_gather_f(Slab s, const BlockDesc *bd, int nxb, int nyb, const 
     const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
     const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
     if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
+    if (act && !act[(sj / TILE_Y) * s.ntx + si / TILE_X]) return;
     if (!gather_take(s, d, i, j, si, sj)) return;
     FD(s, f, cell(s, si, sj)) = src[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)];
 }
@@ -87,12 +90,17 @@ __device__ __forceinline__ bool scatter_take(const Slab &s, const BlockDesc &d, 
     return (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
 }
 
-__global__ void k_scatter_f(Slab s, const BlockDesc *bd, int nxb, int nyb, int f, double *dst, int mode) {
+__global__ void k_scatter_f(Slab s, const BlockDesc *bd, int nxb, int nyb, int f, double *dst, int mode, const unsigned char *act = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y + 1;
     const int b = blockIdx.z;
     if (i > nxb) return;
     int si, sj;
+    if (act) {      // sparse download: a cell of a tile that is inactive now and was at the previous evp holds the same zero on both sides
+        const BlockDesc d = bd[b];
+        const int ti = d.iglob_lo + (i - d.ilo) - s.i0 + 1, tj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+        if (ti >= 0 && ti <= s.nxl + 1 && tj >= 0 && tj <= s.nyl + 1 && !act[(tj / TILE_Y) * s.ntx + ti / TILE_X]) return;
+    }
     if (mode == MODE_PHYS_ZG) {
         const BlockDesc d = bd[b];
         const bool phys = (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
@@ -193,6 +201,36 @@ __global__ void k_prep1a(Slab s, DevParams p, int fresh) {
         FD(s, F_RDGCONV, k) = 0.0; FD(s, F_RDGSHEAR, k) = 0.0; FD(s, F_DIVU, k) = 0.0;
         FD(s, F_SHEAR, k) = 0.0; FD(s, F_PRSSIG, k) = 0.0;
     }
+}
+
+// sparse upload: which tiles can matter to this evp -- any cell with ice (the test of evp_prep1, :331-332, or any non-zero
+// aice / tmass at all) on the freshly uploaded aice / vice / vsno, or the ghost ring
+__global__ void k_io_tiles(Slab s, DevParams p, unsigned char *raw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    bool hm = false;
+    if (i <= s.nxl + 1 && j <= s.nyl + 1) {
+        const size_t k = cell(s, i, j);
+        const double tmass = s.tmask[mcell(s, i, j)] ? (p.rhoi * FD(s, F_VICE, k) + p.rhos * FD(s, F_VSNO, k)) : 0.0;
+        hm = (s.tmask[mcell(s, i, j)] && FD(s, F_AICE, k) > p.a_min && tmass > p.m_min) || tmass != 0.0 || FD(s, F_AICE, k) != 0.0;
+    }
+    const int any = __syncthreads_or(hm ? 1 : 0);
+    const bool edge = (blockIdx.x == 0 || blockIdx.x == (unsigned)s.ntx - 1 || blockIdx.y == 0 || blockIdx.y == (unsigned)s.nty - 1);
+    if (threadIdx.x == 0 && threadIdx.y == 0) raw[blockIdx.y * s.ntx + blockIdx.x] = (any || edge) ? 1 : 0;
+}
+// ... dilated by two tiles (the T->U averages and the 3x3 dilation of icetmask reach one cell further, the tiles of the
+// per-evp kernels one tile further), or active at the previous evp (s.act_any still holds that)
+__global__ void k_io_tiles_dilate(Slab s, const unsigned char *raw, unsigned char *act) {
+    const int tx = blockIdx.x * blockDim.x + threadIdx.x, ty = blockIdx.y;
+    if (tx >= s.ntx || ty >= s.nty) return;
+    int a = s.act_any[ty * s.ntx + tx];
+    for (int dy = -2; dy <= 2 && !a; dy++)
+        for (int dx = -2; dx <= 2; dx++) {
+            const int x = tx + dx, y = ty + dy;
+            if (x < 0 || x >= s.ntx || y < 0 || y >= s.nty) continue;
+            a |= raw[y * s.ntx + x];
+        }
+    act[ty * s.ntx + tx] = a ? 1 : 0;
 }
 
 // act = dilate_3x3(new | prev) per tile; `fresh` (state just uploaded): everything is active

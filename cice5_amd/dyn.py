@@ -23,7 +23,7 @@ def set_evp_parameters(dt: float, ndte: int, revised_evp: bool, xmin: float, *,
                        cosw: float = C.cosw, sinw: float = C.sinw,
                        tilt_from_slope: bool = False, wind_on_ugrid: bool = False,
                        kstrength: int = 1, krdg_partic: int = 1, krdg_redist: int = 1, ncat: int = 5,
-                       mu_rdg: float = 3.0, Cf: float = 17.0) -> evpk.Params:
+                       mu_rdg: float = 3.0, Cf: float = 17.0, sparse_io: bool = False) -> evpk.Params:
     """ice_dyn_shared.F90:185-259.  `xmin` = min(global_minval(dxt,tmask), global_minval(dyt,tmask)) (:221-223)."""
     p = evpk.Params()
     dte = dt / float(ndte)                       # :209
@@ -50,6 +50,7 @@ def set_evp_parameters(dt: float, ndte: int, revised_evp: bool, xmin: float, *,
     # ice_strength switches (ice_mechred.F90:54-64; defaults ice_init.F90:273-277), used when the strength is not an input
     p.kstrength, p.krdg_partic, p.krdg_redist, p.ncat = kstrength, krdg_partic, krdg_redist, ncat
     p.mu_rdg, p.Cf = mu_rdg, Cf
+    p.sparse_io = int(sparse_io)       # sparse transfers in resident-state mode (include/evpk.h)
     return p
 
 
@@ -64,6 +65,9 @@ def local_min_dx(fields: Dict[str, np.ndarray], decomp: Decomp) -> float:
     return m
 
 
+EVERY_STEP_OUTPUTS = ["uvel", "vvel", "rdg_conv", "rdg_shear", "divu", "shear", "strocnxT", "strocnyT"]
+
+
 class EvpDynamics:
     """One rank's EVP solver.  Usage mirrors the reference call order:
     `init_evp(dt)` once (CICE_InitMod.F90:103-104), then `evp(dt)` every dynamics step
@@ -72,7 +76,8 @@ class EvpDynamics:
     def __init__(self, decomp: Decomp, fields: Dict[str, np.ndarray], *, ndte: int = 120, revised_evp: bool = False,
                  device: int = 0, unique_id: Optional[bytes] = None, cosw: float = C.cosw, sinw: float = C.sinw,
                  tilt_from_slope: bool = False, wind_on_ugrid: bool = False, xmin: Optional[float] = None,
-                 pin_host: bool = False, device_strength: Optional[dict] = None, defer_connect: bool = False):
+                 pin_host: bool = False, device_strength: Optional[dict] = None, defer_connect: bool = False,
+                 resident: bool = False, outputs: Optional[list] = None, sparse_io: bool = False):
         """pin_host: page-lock the arrays of `fields` (evpk_pin_host) as a host model does once for its module arrays;
         evp() then moves them in place over PCIe.  The arrays must stay the same objects until close()."""
         self.decomp, self.fields = decomp, fields
@@ -82,6 +87,12 @@ class EvpDynamics:
             # ice_strength (ice_mechred.F90:2111) on the device instead of fields["strength"] as an input: a dict of
             # kstrength / krdg_partic / krdg_redist / ncat / mu_rdg / Cf; kstrength = 1 reads fields["aicen", "vicen", "aice0"]
             self._opts.update(device_strength)
+        # resident: uvel, vvel, sigma, iceumask stay on the device between evp() calls (only evp writes them: the host
+        # re-uploads inputs only, evpk_upload(in, NULL)); outputs: the arrays to bring back every call (None = all) -- what a
+        # host model reads every step is uvel, vvel (transport), rdg_conv, rdg_shear (ridging), strocnxT/yT (coupler), divu,
+        # shear; the rest on the steps that write history or a restart; sparse_io: evpk_params.sparse_io
+        self._resident, self._outputs, self._ncalls = resident, outputs, 0
+        self._opts["sparse_io"] = bool(sparse_io)
         self._xmin = xmin
         self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id, defer_connect=defer_connect)
         self.ctx.device_strength = device_strength is not None
@@ -111,7 +122,19 @@ class EvpDynamics:
         """ice_dyn_evp.F90:68: one call of the dynamics, in place on `fields`."""
         if self.params is None or self.params.dt != dt:
             self.set_evp_parameters(dt)        # :153-154 ("needed only if dt changes during runtime")
-        self.ctx.run(self.fields)
+        if not self._resident:
+            self.ctx.run(self.fields)
+            return
+        if self._ncalls == 0:
+            self.ctx.upload(self.fields)
+        else:
+            self.ctx.upload_inputs(self.fields)
+        self._ncalls += 1
+        self.ctx.prep()
+        self.ctx.subcycle(self.ndte)
+        self.ctx.finish()
+        f = self.fields if self._outputs is None else {n: self.fields[n] for n in self._outputs}
+        self.ctx.download(f)
 
     def principal_stress(self):
         """ice_dyn_shared.F90:853: (sig1, sig2) block arrays from the state of the last evp() (physical cells)."""

@@ -50,7 +50,7 @@ class Params(ct.Structure):
                 ("a_min", ct.c_double), ("m_min", ct.c_double),
                 ("tilt_from_slope", ct.c_int32), ("wind_on_ugrid", ct.c_int32),
                 ("kstrength", ct.c_int32), ("krdg_partic", ct.c_int32), ("krdg_redist", ct.c_int32), ("ncat", ct.c_int32),
-                ("mu_rdg", ct.c_double), ("Cf", ct.c_double)]
+                ("mu_rdg", ct.c_double), ("Cf", ct.c_double), ("sparse_io", ct.c_int32), ("reserved_", ct.c_int32)]
 
 
 class StepIn(ct.Structure):
@@ -229,11 +229,12 @@ class Context:
         return si
 
     def _state(self, f) -> State:
+        """evpk_state from the arrays present in `f` (an absent output is a NULL pointer: skipped by evpk_download)"""
         st = State()
-        st.uvel, st.vvel = _p64(f["uvel"]), _p64(f["vvel"])
+        st.uvel, st.vvel = _p64(f.get("uvel")), _p64(f.get("vvel"))
         for k in ("stressp", "stressm", "stress12"):
-            setattr(st, k, (c_f64p * 4)(*[_p64(f[f"{k}_{c}"]) for c in (1, 2, 3, 4)]))
-        st.iceumask = _p32(f["iceumask"])
+            setattr(st, k, (c_f64p * 4)(*[_p64(f.get(f"{k}_{c}")) for c in (1, 2, 3, 4)]))
+        st.iceumask = _p32(f.get("iceumask"))
         for n in STATE_OUT_F64:
             setattr(st, n, _p64(f.get(n)))
         st.icetmask = _p32(f.get("icetmask"))

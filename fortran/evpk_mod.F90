@@ -45,6 +45,8 @@
          integer (c_int32_t) :: wind_on_ugrid
          integer (c_int32_t) :: kstrength, krdg_partic, krdg_redist, ncat    ! ice_strength on the device (strength = c_null_ptr)
          real (c_double) :: mu_rdg, Cf
+         integer (c_int32_t) :: sparse_io = 0     ! 1: sparse transfers in resident-state mode (include/evpk.h)
+         integer (c_int32_t) :: reserved_ = 0
       end type evpk_params
 
       type, bind(C), public :: evpk_step_in

@@ -39,7 +39,16 @@
       public :: evpk_npinned      ! (diagnostic) host arrays page-locked for in-place PCIe transfers
       public :: evpk_resident_state, evpk_state_changed_on_host, evpk_device_strength
       public :: evpk_bound_seconds, evpk_loop_seconds
+      public :: evpk_download_all, evpk_sparse_io
       save
+
+      ! .true. (default): every array the reference's evp leaves modified comes back every call.  .false. (with
+      ! evpk_resident_state): only what the host model reads every step -- uvel, vvel (transport), rdg_conv, rdg_shear
+      ! (ridging), divu, shear, strocnxT, strocnyT (coupler) and iceumask; the caller sets it .true. for the steps that
+      ! write history or a restart (the stresses, strintx/y, strairx/y, ... are then delivered whole).
+      logical (kind=log_kind) :: evpk_download_all = .true.
+      ! .true.: sparse transfers (evpk_params%sparse_io): only the 64x4-cell tiles with ice move, aice / vice / vsno apart
+      logical (kind=log_kind) :: evpk_sparse_io = .false.
 
       ! Device time of all evp calls so far (HIP events inside the library): the ndte loop, and inside it the halo / tripole
       ! fold / ghost-zone updates -- the share the reference books under timer_bound (ice_dyn_evp.F90:392-400).  ice_timers
@@ -287,6 +296,7 @@
 #endif
       p%kstrength = kstrength;  p%krdg_partic = krdg_partic;  p%krdg_redist = krdg_redist
       p%ncat = ncat;  p%mu_rdg = mu_rdg;  p%Cf = Cf
+      p%sparse_io = merge(1, 0, evpk_sparse_io)
       rc = evpk_set_params (ctx, p)
       if (rc /= 0) call abort_ice('evp: evpk_set_params: '//trim(evpk_error_string(ctx)))
 
@@ -400,6 +410,16 @@
          call pin_r8 (uvel_init, size(uvel_init));  call pin_r8 (vvel_init, size(vvel_init))
          rc = evpk_pin_host (c_loc(iceumask_i), int(size(iceumask_i), c_size_t) * 4_c_size_t)
          pinned = .true.
+      endif
+
+      if (evpk_resident_state .and. .not. evpk_download_all) then
+         ! the every-step set only (anything else stays c_null_ptr: skipped by evpk_download)
+         st%stressp = c_null_ptr;  st%stressm = c_null_ptr;  st%stress12 = c_null_ptr
+         st%prs_sig = c_null_ptr;  st%strintx = c_null_ptr;  st%strinty = c_null_ptr
+         st%strocnx = c_null_ptr;  st%strocny = c_null_ptr
+         st%strairx = c_null_ptr;  st%strairy = c_null_ptr;  st%strtltx = c_null_ptr;  st%strtlty = c_null_ptr
+         st%fm = c_null_ptr;  st%aiu = c_null_ptr;  st%umass = c_null_ptr
+         st%uvel_init = c_null_ptr;  st%vvel_init = c_null_ptr;  st%strength = c_null_ptr
       endif
 
       if (evpk_resident_state .and. .not. evpk_state_changed_on_host) then

@@ -86,6 +86,13 @@ typedef struct {
      * ice_mechred.F90:54-64 (defaults ice_init.F90:273-277: 1, 1, 1, mu_rdg = 3, Cf = 17) and ncat (ice_domain_size) */
     int32_t kstrength, krdg_partic, krdg_redist, ncat;
     double mu_rdg, Cf;
+    /* 1: sparse transfers for a host model that keeps the state resident (evpk_upload(in, NULL), page-locked arrays):
+     * aice, vice, vsno are uploaded whole, every other input only in the 64x4-cell tiles that hold ice now or held any at
+     * the previous call (+ two tiles around), and evpk_download skips tiles that are and were ice-free (they hold the same
+     * zeros on both sides).  Identical results provided the T-grid inputs strairxT/yT, aice_init, strength are zero where
+     * there is no ice, as CICE leaves them; 0 (default): every cell of every array moves. */
+    int32_t sparse_io;
+    int32_t reserved_;
 } evpk_params;
 
 /* Per-call inputs: what evp(dt) reads from ice_state / ice_flux / ice_atmo

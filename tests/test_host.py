@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     # field counts of the ctypes mirrors == pointer/scalar counts of the C structs
-    assert ct.sizeof(evpk.Params) == 8 + 4 + 4 + 8 * 13 + 4 + 4 + 4 * 4 + 8 * 2
+    assert ct.sizeof(evpk.Params) == 8 + 4 + 4 + 8 * 13 + 4 + 4 + 4 * 4 + 8 * 2 + 4 * 2
     assert ct.sizeof(evpk.StepIn) == 8 * (14 + 3)
     assert ct.sizeof(evpk.State) == 8 * (2 + 12 + 1 + 21 + 1 + 1)
     assert ct.sizeof(evpk.Geom) == 4 * 7 + 4 + 8 * 6 + 4 * 3 + 4 + 8 + 8 * 16 + 8 * 2

@@ -721,6 +721,39 @@ def test_bound_time_is_reported():
         s.close()
 
 
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_resident_state_sparse_transfers(ns):
+    """The drop-in as a host model drives it step after step: page-locked arrays, the state resident on the device, inputs
+    up, only the every-step outputs down (dyn.EVERY_STEP_OUTPUTS), and evpk_params.sparse_io -- only the tiles with ice
+    move.  Ice wanders, melts away and comes back over eight calls; what is delivered equals the oracle after every call,
+    and on the last call every output is requested (arrays that were not delivered every step arrive whole)."""
+    from tests.test_multirank_gpu import _wander
+    case, d, f = util.make_case(520, 200, 130, 100, ns=ns, land="continents")
+    xmin = synth.global_min_dx(case)
+    base = util.clone(f)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, 12, xmin)
+    every = list(dyn.EVERY_STEP_OUTPUTS)
+    s = dyn.EvpDynamics(d, fg, ndte=12, xmin=xmin, pin_host=True, resident=True, outputs=every, sparse_io=True)
+    s.init_evp(3600.0)
+    ncalls = 8
+    for call in range(ncalls):
+        for ff in (fo, fg):
+            _wander(d, base, ff, call, ns)
+            for n in ("strairxT", "strairyT"):          # the precondition of sparse_io: no T-grid forcing where there is no ice
+                ff[n][...] = np.where(ff["aice"] > 0.0, ff[n], 0.0)
+        if call == ncalls - 1:
+            s._outputs = None
+        nt, nu, _ = orc.evp(d, p, fo)
+        s.evp(3600.0)
+        st = s.ctx.stats()
+        assert (st.icellt, st.icellu) == (nt, nu), call
+        bad = util.compare(d, fg, fo, names=None if call == ncalls - 1 else every)
+        assert not bad, f"call {call}: {bad[:6]}"
+    assert np.abs(fo["uvel"]).max() > 1e-3
+    s.close()
+
+
 def test_caller_arrays_in_device_memory():
     """A host model whose fields already live on the GPU passes device pointers in place of host arrays (same block
     layout): the library reads and writes them in place.  Here the arrays are torch tensors on the device."""
