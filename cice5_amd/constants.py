@@ -29,5 +29,5 @@ BND_CYCLIC, BND_OPEN, BND_CLOSED, BND_TRIPOLE = 0, 1, 2, 3
 BND_NAMES = {"cyclic": BND_CYCLIC, "open": BND_OPEN, "closed": BND_CLOSED, "tripole": BND_TRIPOLE}
 
 # field_loc_* / field_type_* (ice_constants.F90:198-215)
-LOC_CENTER, LOC_NECORNER = 1, 2
+LOC_CENTER, LOC_NECORNER, LOC_NFACE, LOC_EFACE = 1, 2, 3, 4        # ice_constants.F90: field_loc_*
 KIND_SCALAR, KIND_VECTOR = 1, 2

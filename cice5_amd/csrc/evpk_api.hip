@@ -262,6 +262,9 @@ struct evpk_ctx {
     long long tuned_icellt = -1;
     int slots2 = 512;                // resident 256-thread workgroups of k_subcycle2 on the whole chip
     int nsimd = 1024;                // SIMDs of the chip (4 per CU)
+    double *tp_a = nullptr, *tp_b = nullptr, *tp_stage = nullptr;   // transport_upwind: two scratch planes, staging of the work array
+    size_t tp_stage_n = 0;
+    bool have_lengths = false;       // HTN / HTE were given in evpk_geom
     unsigned char *io_raw = nullptr, *io_act = nullptr;   // sparse I/O: tiles whose inputs are uploaded this step
     long long evp_count = 0;         // evpk_prep calls so far
     long long last_dl[F_COUNT] = {};  // evp_count at which each field was last downloaded (state fields under their F_STATE0 ids)
@@ -612,7 +615,7 @@ static int xp_check(evpk_ctx *c) {
 // skip_ew: the caller refreshes the E-W ghost columns itself right after (exchange_cols carries them, all rows)
 // fprev: see k_fold_pack (velocity updates inside the subcycle loop: the state buffer the kernel read)
 static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double fill, int fsrc_fold = -1, hipStream_t st_in = nullptr,
-                bool skip_ew = false, int fprev = -1, int ew_from = 0) {
+                bool skip_ew = false, int fprev = -1, int ew_from = 0, int loc_x = -1 /* 2: E face, 3: N face (k_fold_apply) */) {
     Slab &s = c->s;
     hipStream_t st = st_in ? st_in : c->stream;       // every launch, copy and transport call of this update
     const int tx = 128;
@@ -620,7 +623,7 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
     const bool stress_mode = fsrc_fold >= 0;
     if (nf > c->max_nf) FAIL(c, "halo: nf=%d exceeds buffer", nf);
     if (c->ns == EVPK_BND_CYCLIC) FAIL(c, "ns_boundary_type cyclic is not supported");
-    if (c->ns == EVPK_BND_TRIPOLE && c->nranks == 1 && !c->force_exchange && necorner && !stress_mode && s.nyl >= 3) {
+    if (c->ns == EVPK_BND_TRIPOLE && c->nranks == 1 && !c->force_exchange && necorner && loc_x < 0 && !stress_mode && s.nyl >= 3) {
         // single rank: the whole update of an NE-corner field in one launch
         const int n = std::max(std::max(s.nxg / 2 + 1, s.nxl + 2), s.nyl);
         hipLaunchKernelGGL(k_halo_tripole_ne1, dim3((n + tx - 1) / tx, 2), dim3(tx), 0, st,
@@ -652,7 +655,8 @@ static int halo(evpk_ctx *c, int f, int nf, bool necorner, bool vector, double f
         }
         // (x-slab ranks fold their own columns; the ghost columns of the two rows come with the E-W exchange that follows)
         hipLaunchKernelGGL(k_fold_apply, dim3(gcol), dim3(tx), 0, st, s, f, nf, (const double *)c->foldbuf,
-                           (necorner && !stress_mode) ? 1 : 0, (vector && !stress_mode) ? -1.0 : 1.0, (c->nranks > 1 && !stress_mode) ? 1 : 0);
+                           stress_mode ? 0 : (loc_x >= 0 ? loc_x : (necorner ? 1 : 0)), (vector && !stress_mode) ? -1.0 : 1.0,
+                           (c->nranks > 1 && !stress_mode) ? 1 : 0);
         HIPCHK(c, hipGetLastError());
         if (stress_mode) return 0;
     } else {
@@ -790,7 +794,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1162,6 +1166,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     if (g->HTN && g->HTE) {
         // optional primary lengths: use them in place of the eight metric planes only if they reproduce those bit for bit
         if (upload_f(c, g->HTN, F_HTN) || upload_f(c, g->HTE, F_HTE)) return 1;
+        c->have_lengths = true;
         const char *e = getenv("EVPK_COMPACT_METRICS");
         if (!(e && atoi(e) == 0)) {
             HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int), c->stream));
@@ -1949,6 +1954,55 @@ extern "C" int evpk_restart_read(evpk_ctx *c, const char *path, int64_t byte_off
     c->prepped = false;
     c->fresh = true;
     return 0;
+}
+
+// ---- transport_upwind (source/ice_transport_driver.F90:634-772) on the resident velocities -------------
+extern "C" int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, double *works) {
+    if (!c || !works || narr < 1) return 1;
+    if (!c->uploaded) FAIL(c, "evpk_transport_upwind: no velocities on the device (run evp first)");
+    if (!c->have_lengths) FAIL(c, "evpk_transport_upwind needs HTN and HTE in evpk_geom");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const dim3 g2 = grid2d(s, B2D);
+    const int SB = c->cur ? F_STATE1 : F_STATE0;
+    const size_t np = mask_elems(s), nblk = (size_t)c->nyb * c->nxb, n = (size_t)c->nblocks * narr * nblk;
+    if (!c->tp_a) {
+        HIPCHK(c, hipMalloc(&c->tp_a, sizeof(double) * np));
+        HIPCHK(c, hipMalloc(&c->tp_b, sizeof(double) * np));
+        HIPCHK(c, hipMemsetAsync(c->tp_a, 0, sizeof(double) * np, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->tp_b, 0, sizeof(double) * np, c->stream));
+    }
+    // edge velocities and their halo updates (:688-708): E face / N face vectors, in the sig1 / sig2 planes (scratch between
+    // calls of evpk_principal_stress, which rewrites them whole)
+    hipLaunchKernelGGL(k_edge_vel, g2, B2D, 0, c->stream, s, SB, (int)F_SIG1, (int)F_SIG2);
+    if (halo(c, F_SIG1, 1, false, true, 0.0, -1, nullptr, false, -1, 0, 2)) return 1;
+    if (halo(c, F_SIG2, 1, false, true, 0.0, -1, nullptr, false, -1, 0, 3)) return 1;
+    // the work array: in place where the caller's memory is visible to the device, else through a staging copy
+    double *dev = (double *)mapped_alias(works);
+    const bool staged = (dev == nullptr);
+    if (staged) {
+        if (c->tp_stage_n < n) {
+            if (c->tp_stage) (void)hipFree(c->tp_stage);
+            c->tp_stage = nullptr; c->tp_stage_n = 0;
+            HIPCHK(c, hipMalloc(&c->tp_stage, sizeof(double) * n));
+            c->tp_stage_n = n;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->tp_stage, works, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        dev = c->tp_stage;
+    }
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    for (int a = 0; a < narr; a++) {       // upwind_field (:1667-1687), one array at a time through two scratch planes
+        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dev + (size_t)a * nblk),
+                           (size_t)narr * nblk, c->tp_a);
+        hipLaunchKernelGGL(k_upwind, dim3((s.nxl + 63) / 64, (s.nyl + 3) / 4), B2D, 0, c->stream, s, dt, (int)F_SIG1, (int)F_SIG2,
+                           (const double *)c->tp_a, c->tp_b);
+        hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)c->tp_b,
+                           dev + (size_t)a * nblk, (size_t)narr * nblk);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (staged) HIPCHK(c, hipMemcpyAsync(works, c->tp_stage, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return xp_check(c);
 }
 
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {

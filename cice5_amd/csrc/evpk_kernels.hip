@@ -638,7 +638,10 @@ __global__ void k_ipc_wait(const unsigned *flag, unsigned seq, unsigned *err, un
 //   center  : ghost(i,ny+1) = sgn*B2(nx-g+1)
 //   NEcorner: top(i,ny) = sgn*sym(B2)(nx-g), ghost(i,ny+1) = sgn*B1(nx-g), index 0 -> nx
 //   stress  : (ice_HaloUpdate_stress) center rule, no sign, source plane differs from dest
-__global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int necorner, double sgn, int own_only = 0) {
+// loc: 0 centre, 1 NE corner, 2 E face, 3 N face -- source column nx - g + 1 - ioffset, ioffset = 1 for NE corner and E face;
+// joffset = 1 (NE corner, N face): the top physical row is rewritten from the symmetrised row (pairs (i, nx-i), i < nx/2 for
+// the NE corner, :818-824; pairs (i, nx+1-i), i <= nx/2 for the N face, :836-843) and the ghost row mirrors row ny-1
+__global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int loc, double sgn, int own_only = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // local col 0..nxl+1
     if (i > s.nxl + 1) return;
     if (own_only && (i < 1 || i > s.nxl)) return;              // x-slab ranks: the ghost columns come with the E-W exchange that follows
@@ -646,24 +649,26 @@ __global__ void k_fold_apply(Slab s, int fdst, int nf, const double *fb, int nec
     int g = s.i0 + i - 1;                                       // global col, wrap
     if (g < 1) g += nx;
     if (g > nx) g -= nx;
+    const int ioff = (loc == 1 || loc == 2) ? 1 : 0, joff = (loc == 1 || loc == 3) ? 1 : 0;
+    int src = nx - g + 1 - ioff;
+    if (src == 0) src = nx;
+    if (src > nx) src -= nx;
+    const int h = nx / 2;
     for (int q = 0; q < nf; q++) {
         const double *B1 = fb + ((size_t)q * 2 + 0) * nx - 1;  // 1-based
         const double *B2 = fb + ((size_t)q * 2 + 1) * nx - 1;
-        if (!necorner) {
-            FD(s, fdst + q, cell(s, i, s.nyl + 1)) = sgn * B2[nx - g + 1];
+        if (!joff) {
+            FD(s, fdst + q, cell(s, i, s.nyl + 1)) = sgn * B2[src];
         } else {
-            int src = nx - g;
-            if (src == 0) src = nx;
-            // symmetrised top row at column src (:818-824)
+            // symmetrised top row at column src
             double v;
-            const int h = nx / 2;
-            if (src >= 1 && src <= h - 1) {
-                v = 0.5 * (B2[src] + sgn * B2[nx - src]);
-            } else if (src >= h + 1 && src <= nx - 1) {
-                const int ii = nx - src;
-                v = sgn * (0.5 * (B2[ii] + sgn * B2[src]));
+            if (loc == 1) {
+                if (src >= 1 && src <= h - 1) v = 0.5 * (B2[src] + sgn * B2[nx - src]);
+                else if (src >= h + 1 && src <= nx - 1) { const int ii = nx - src; v = sgn * (0.5 * (B2[ii] + sgn * B2[src])); }
+                else v = B2[src];
             } else {
-                v = B2[src];
+                if (src <= h) v = 0.5 * (B2[src] + sgn * B2[nx + 1 - src]);
+                else { const int ii = nx + 1 - src; v = sgn * (0.5 * (B2[ii] + sgn * B2[src])); }
             }
             FD(s, fdst + q, cell(s, i, s.nyl)) = sgn * v;
             FD(s, fdst + q, cell(s, i, s.nyl + 1)) = sgn * B1[src];
@@ -1985,6 +1990,48 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
         if (flags) flags[sid] = b ? 1 : 0;
         if (count && b) atomicAdd(count, 1u);
     }
+}
+
+// ------------------------------------------------------------------------------------
+// transport_upwind (source/ice_transport_driver.F90:634-772) on the velocities resident on the device
+// ------------------------------------------------------------------------------------
+// cell-edge velocities (:688-701): uee = p5*(uvel(i,j)+uvel(i,j-1)), vnn = p5*(vvel(i,j)+vvel(i-1,j)), physical cells
+__global__ void k_edge_vel(Slab s, int SB, int fu, int fv) {
+    SLAB_IJ_ALL
+    double ue = 0.0, vn = 0.0;
+    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
+        ue = 0.5 * (FD(s, SB + S_U, k) + FD(s, SB + S_U, cell(s, i, j - 1)));
+        vn = 0.5 * (FD(s, SB + S_V, k) + FD(s, SB + S_V, cell(s, i - 1, j)));
+    }
+    FD(s, fu, k) = ue;
+    FD(s, fv, k) = vn;
+}
+
+// upwind_field (:1614-1689) for one array: phi, out are plain planes indexed like the masks (mcell)
+__global__ void k_upwind(Slab s, double dt, int fu, int fv, const double *phi, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    if (i > s.nxl || j > s.nyl) return;
+    // upwind(y1,y2,a,h) = p5*dt*h*((a+abs(a))*y1+(a-abs(a))*y2)   (:1661)
+    auto up = [&](double y1, double y2, double a, double h) { return 0.5 * dt * h * ((a + fabs(a)) * y1 + (a - fabs(a)) * y2); };
+    const size_t k = cell(s, i, j), kw = cell(s, i - 1, j), ks = cell(s, i, j - 1);
+    const double p = phi[mcell(s, i, j)];
+    const double wa = up(p, phi[mcell(s, i + 1, j)], FD(s, fu, k), FD(s, F_HTE, k));
+    const double wam = up(phi[mcell(s, i - 1, j)], p, FD(s, fu, kw), FD(s, F_HTE, kw));
+    const double wb = up(p, phi[mcell(s, i, j + 1)], FD(s, fv, k), FD(s, F_HTN, k));
+    const double wbm = up(phi[mcell(s, i, j - 1)], p, FD(s, fv, ks), FD(s, F_HTN, ks));
+    out[mcell(s, i, j)] = p - (wa - wam + wb - wbm) / FD(s, F_TAREA, k);        // :1680-1682
+}
+
+// physical cells of a plain plane -> one (nx_block, ny_block) slice per block, blocks `bstride` doubles apart
+__global__ void k_scatter_plane(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, double *dst, size_t bstride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    int si, sj;
+    if (!scatter_take(s, bd[b], i, j, MODE_PHYS, si, sj)) return;
+    dst[(size_t)b * bstride + (size_t)(j - 1) * nxb + (i - 1)] = src[mcell(s, si, sj)];
 }
 
 // ------------------------------------------------------------------------------------

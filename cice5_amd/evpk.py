@@ -81,7 +81,8 @@ XP_NAMES = {0: "none", 1: "rccl", 2: "shm relay", 3: "ipc peer-mapped", 4: "self
 EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "evpk_upload", "evpk_prep",
            "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
            "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
-           "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read"]
+           "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
+           "evpk_transport_upwind"]
 
 _lib = None
 
@@ -120,6 +121,7 @@ def lib():
         L.evpk_unpin_host.argtypes = [ct.c_void_p]
         L.evpk_connect.argtypes = [ctxp, ct.c_void_p]
         L.evpk_device_check.argtypes = [ct.c_int32]
+        L.evpk_transport_upwind.argtypes = [ctxp, ct.c_double, ct.c_int32, c_f64p]
         L.evpk_restart_write.argtypes = [ctxp, ct.c_char_p, ct.c_int32, ct.c_int32]
         L.evpk_restart_read.argtypes = [ctxp, ct.c_char_p, ct.c_int64, ct.c_int32]
         for n in EXPORTS:
@@ -277,6 +279,11 @@ class Context:
 
     def principal_stress(self, sig1: np.ndarray, sig2: np.ndarray):
         self._chk(self._L.evpk_principal_stress(self._ctx, _p64(sig1), _p64(sig2)), "evpk_principal_stress")
+
+    def transport_upwind(self, dt: float, works: np.ndarray):
+        """evpk_transport_upwind: works is (nblocks, narr, ny_block, nx_block), advected in place"""
+        assert works.ndim == 4
+        self._chk(self._L.evpk_transport_upwind(self._ctx, float(dt), int(works.shape[1]), _p64(works)), "evpk_transport_upwind")
 
     def restart_write(self, path: str, append: bool = False, big_endian: bool = True):
         self._chk(self._L.evpk_restart_write(self._ctx, path.encode(), int(append), int(big_endian)), "evpk_restart_write")

@@ -89,7 +89,8 @@
                 evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string, &
                 evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
                 evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
-                evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read
+                evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read, &
+                evpk_transport_upwind
 
       interface
          integer (c_int) function evpk_get_unique_id (id) bind(C, name='evpk_get_unique_id')
@@ -180,6 +181,15 @@
             character (kind=c_char), dimension(*), intent(in) :: path
             integer (c_int64_t), value :: byte_offset
             integer (c_int32_t), value :: big_endian
+         end function
+         ! transport_upwind (ice_transport_driver.F90:634-772) on the resident velocities: works(nx_block,ny_block,narr,nblocks)
+         ! as state_to_work fills it, advected in place
+         integer (c_int) function evpk_transport_upwind (ctx, dt, narr, works) bind(C, name='evpk_transport_upwind')
+            import :: c_int, c_ptr, c_double, c_int32_t
+            type (c_ptr), value :: ctx
+            real (c_double), value :: dt
+            integer (c_int32_t), value :: narr
+            type (c_ptr), value :: works
          end function
          integer (c_int) function evpk_destroy (ctx) bind(C, name='evpk_destroy')
             import :: c_int, c_ptr

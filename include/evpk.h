@@ -199,6 +199,14 @@ int evpk_get_stats(evpk_ctx *c, evpk_stats *s);
  * Physical cells of sig1, sig2 (block arrays) are written. */
 int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
 
+/* SURVEY S8 row f-3, first step: transport_upwind (source/ice_transport_driver.F90:634-772) on the velocities the last evp
+ * left on the device.  The cell-edge velocities uee, vnn (:688-701) and their halo updates (E face / N face vectors,
+ * :703-708) and upwind_field (:1614-1689) run on the GPU; `works` is the work array state_to_work (:1382-1513) fills on the
+ * host, real(8) (nx_block, ny_block, narr, nblocks), advected in place on physical cells (ghost cells must be current on
+ * entry -- bound_state -- and are left alone; the reference calls bound_state afterwards, :763).  work_to_state /
+ * compute_tracers stay with the host's tracer bookkeeping.  Needs HTN and HTE in evpk_geom. */
+int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, double *works);
+
 /* The dynamics records of the reference's binary restart (source/ice_restart_driver.F90:122-176 dumpfile, :295-412
  * restartfile; io_binary/ice_restart.F90:641-684): uvel, vvel, strocnxT, strocnyT, stressp_1,3,2,4, stressm_1,3,2,4,
  * stress12_1,3,2,4, iceumask as real 0/1 -- 17 Fortran sequential unformatted records of the (nx_global, ny_global)

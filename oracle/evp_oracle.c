@@ -609,21 +609,36 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
         north = (double *)malloc(sizeof(double) * (size_t)(nxg + 1));
         double *row2 = (double *)malloc(sizeof(double) * (size_t)(nxg + 1));
         for (int i = 1; i <= nxg; i++) row2[i] = G[GIX(i, nyg)];
-        if (loc == ORC_LOC_NECORNER && !stress_mode) {
-            for (int i = 1; i <= nxg / 2 - 1; i++) {                      /* serial/ice_boundary.F90:818-824 */
-                int id = nxg - i;
-                double x1 = row2[i], x2 = row2[id];
-                double xavg = 0.5 * (x1 + s * x2);
-                row2[i] = xavg;
-                row2[id] = s * xavg;
-            }
-            for (int i = 1; i <= nxg; i++) {
-                int is = nxg - i; if (is == 0) is = nxg;                  /* :874-876 */
-                top[i] = s * row2[is];
-                north[i] = s * G[GIX(is, nyg - 1)];
-            }
-        } else {
+        /* offsets and top-row symmetrisation by field location (serial/ice_boundary.F90:801-846, u-fold):
+           centre 0,0; NE corner 1,1 with pairs (i, nx-i), i = 1..nx/2-1; E face 1,0; N face 0,1 with pairs (i, nx+1-i), i = 1..nx/2 */
+        const int ioff = (loc == ORC_LOC_NECORNER || loc == ORC_LOC_EFACE) ? 1 : 0;
+        const int joff = (loc == ORC_LOC_NECORNER || loc == ORC_LOC_NFACE) ? 1 : 0;
+        if (stress_mode) {
             for (int i = 1; i <= nxg; i++) north[i] = s * row2[nxg - i + 1];
+        } else {
+            if (loc == ORC_LOC_NECORNER)
+                for (int i = 1; i <= nxg / 2 - 1; i++) {                  /* :818-824 */
+                    int id = nxg - i;
+                    double x1 = row2[i], x2 = row2[id];
+                    double xavg = 0.5 * (x1 + s * x2);
+                    row2[i] = xavg;
+                    row2[id] = s * xavg;
+                }
+            if (loc == ORC_LOC_NFACE)
+                for (int i = 1; i <= nxg / 2; i++) {                      /* :836-843 */
+                    int id = nxg + 1 - i;
+                    double x1 = row2[i], x2 = row2[id];
+                    double xavg = 0.5 * (x1 + s * x2);
+                    row2[i] = xavg;
+                    row2[id] = s * xavg;
+                }
+            for (int i = 1; i <= nxg; i++) {
+                int is = nxg - i + 1 - ioff;                              /* :872-876 */
+                if (is == 0) is = nxg;
+                if (is > nxg) is -= nxg;
+                if (joff) { top[i] = s * row2[is]; north[i] = s * G[GIX(is, nyg - 1)]; }
+                else north[i] = s * row2[is];
+            }
         }
         free(row2);
     }
@@ -644,7 +659,7 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
                     continue;
                 }
                 if (phys) {
-                    if (top_block && j == jhi && loc == ORC_LOC_NECORNER) ab[IX(i, j)] = top[gi];
+                    if (top_block && j == jhi && (loc == ORC_LOC_NECORNER || loc == ORC_LOC_NFACE)) ab[IX(i, j)] = top[gi];
                     continue;
                 }
                 double v = fill;
@@ -656,7 +671,7 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
                         else if (tripole && gj == nyg + 1) v = north[gi];
                     } else {
                         v = G[GIX(gi, gj)];
-                        if (top_block && j == jhi && loc == ORC_LOC_NECORNER) v = top[gi];
+                        if (top_block && j == jhi && (loc == ORC_LOC_NECORNER || loc == ORC_LOC_NFACE)) v = top[gi];
                     }
                 }
                 ab[IX(i, j)] = v;
@@ -805,6 +820,49 @@ void orc_halo_i4(const orc_geom *g, int32_t *a, int32_t fill) {
     orc_halo_r8(g, t, ORC_LOC_CENTER, ORC_KIND_SCALAR, (double)fill);
     for (size_t k = 0; k < n; k++) a[k] = (int32_t)t[k];
     free(t);
+}
+
+/* ---------------------------------------------------------------------------
+ * transport_upwind (source/ice_transport_driver.F90:634-772), see evp_oracle.h
+ * ------------------------------------------------------------------------- */
+void orc_transport_upwind(const orc_geom *g, double dt, int narr, const double *uvel, const double *vvel,
+                          const double *HTE, const double *HTN, const double *tarea, double *works) {
+    const int nx = g->nx_block, ny = g->ny_block, nb = g->nblocks;
+    const size_t nn = (size_t)nx * ny, tot = nn * nb;
+    double *uee = calloc(tot, 8), *vnn = calloc(tot, 8);
+    for (int b = 0; b < nb; b++) {                                        /* :688-701 */
+        const size_t o = (size_t)b * nn;
+        for (int j = g->jlo[b]; j <= g->jhi[b]; j++)
+            for (int i = g->ilo[b]; i <= g->ihi[b]; i++) {
+                uee[o + IX(i, j)] = p5 * (uvel[o + IX(i, j)] + uvel[o + IX(i, j - 1)]);
+                vnn[o + IX(i, j)] = p5 * (vvel[o + IX(i, j)] + vvel[o + IX(i - 1, j)]);
+            }
+    }
+    orc_halo_r8(g, uee, ORC_LOC_EFACE, ORC_KIND_VECTOR, 0.0);             /* :703-708 */
+    orc_halo_r8(g, vnn, ORC_LOC_NFACE, ORC_KIND_VECTOR, 0.0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < nb; b++) {
+        const size_t o = (size_t)b * nn;
+        const int ilo = g->ilo[b], ihi = g->ihi[b], jlo = g->jlo[b], jhi = g->jhi[b];
+        double *worka = malloc(nn * 8), *workb = malloc(nn * 8);
+        for (int n = 0; n < narr; n++) {                                  /* upwind_field, :1667-1687 */
+            double *phi = works + ((size_t)b * narr + n) * nn;
+            for (int j = 1; j <= jhi; j++)
+                for (int i = 1; i <= ihi; i++) {
+                    /* upwind(y1,y2,a,h) = p5*dt*h*((a+abs(a))*y1+(a-abs(a))*y2)   (:1661) */
+                    double a = uee[o + IX(i, j)], h = HTE[o + IX(i, j)];
+                    worka[IX(i, j)] = p5 * dt * h * ((a + fabs(a)) * phi[IX(i, j)] + (a - fabs(a)) * phi[IX(i + 1, j)]);
+                    a = vnn[o + IX(i, j)]; h = HTN[o + IX(i, j)];
+                    workb[IX(i, j)] = p5 * dt * h * ((a + fabs(a)) * phi[IX(i, j)] + (a - fabs(a)) * phi[IX(i, j + 1)]);
+                }
+            for (int j = jlo; j <= jhi; j++)
+                for (int i = ilo; i <= ihi; i++)
+                    phi[IX(i, j)] = phi[IX(i, j)] - (worka[IX(i, j)] - worka[IX(i - 1, j)]
+                                                     + workb[IX(i, j)] - workb[IX(i, j - 1)]) / tarea[o + IX(i, j)];
+        }
+        free(worka); free(workb);
+    }
+    free(uee); free(vnn);
 }
 
 /* ---------------------------------------------------------------------------

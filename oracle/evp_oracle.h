@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 enum { ORC_BND_CYCLIC = 0, ORC_BND_OPEN = 1, ORC_BND_CLOSED = 2, ORC_BND_TRIPOLE = 3 };
-enum { ORC_LOC_CENTER = 1, ORC_LOC_NECORNER = 2 };        /* ice_constants.F90: field_loc_* */
+enum { ORC_LOC_CENTER = 1, ORC_LOC_NECORNER = 2, ORC_LOC_NFACE = 3, ORC_LOC_EFACE = 4 };   /* ice_constants.F90: field_loc_* */
 enum { ORC_KIND_SCALAR = 1, ORC_KIND_VECTOR = 2 };        /* ice_constants.F90: field_type_* */
 
 /* block decomposition as seen by one process (source/ice_blocks.F90:22-35) */
@@ -168,6 +168,14 @@ void orc_halo_stress(const orc_geom *g, double *a1, const double *a2);
 /* whole evp(dt): returns total active (icellt, icellu) over blocks through counts[2].
    nsub_override > 0 runs that many subcycles instead of ndte (the "last subcycle"
    diagnostics still fire on ksub == ndte only, as in the reference). */
+/* transport_upwind (source/ice_transport_driver.F90:634-772) without its tracer bookkeeping: the edge velocities
+ * uee = p5*(uvel(i,j)+uvel(i,j-1)), vnn = p5*(vvel(i,j)+vvel(i-1,j)) (:697-698) with their halo updates (E face / N face
+ * vectors, :703-708), then upwind_field (:1614-1689) on each of the `narr` arrays of `works` (nx_block, ny_block, narr,
+ * nblocks) -- what state_to_work (:1382) hands it -- in place on physical cells.  The ghost cells of `works` must be
+ * current on entry (bound_state) and are not updated (the reference calls bound_state afterwards, :763). */
+void orc_transport_upwind(const orc_geom *g, double dt, int narr, const double *uvel, const double *vvel,
+                          const double *HTE, const double *HTN, const double *tarea, double *works);
+
 void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_override,
              int64_t counts[2], double *loop_seconds /* [0] wall time of the subcycle loop, [1] the halo updates' share of it; may be NULL */);
 

@@ -103,6 +103,7 @@ def lib():
                                  ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double)]      # loop_seconds[2]
         _lib.orc_halo_r8.argtypes = [ct.POINTER(OrcGeom), c_f64p, ct.c_int, ct.c_int, ct.c_double]
         _lib.orc_halo_i4.argtypes = [ct.POINTER(OrcGeom), c_i32p, ct.c_int32]
+        _lib.orc_transport_upwind.argtypes = [ct.POINTER(OrcGeom), ct.c_double, ct.c_int] + [c_f64p] * 6
         _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
         _lib.orc_principal_stress.argtypes = [ct.c_int, ct.c_int] + [c_f64p] * 6
         _lib.orc_set_halo_callback.argtypes = [HALO_CB, ct.c_void_p]
@@ -176,6 +177,14 @@ def evp(d, params: OrcParams, f: Dict[str, np.ndarray], nsub: int = 0):
     global last_halo_seconds
     last_halo_seconds = float(secs[1])          # the halo updates' share of the loop time returned below
     return int(counts[0]), int(counts[1]), float(secs[0])
+
+
+def transport_upwind(d, dt: float, f: Dict[str, np.ndarray], works: np.ndarray):
+    """orc_transport_upwind: works (nblocks, narr, ny_block, nx_block) advected in place with f["uvel"], f["vvel"]"""
+    g, keep = make_geom(d)
+    lib().orc_transport_upwind(ct.byref(g), float(dt), int(works.shape[1]), _p64(f["uvel"]), _p64(f["vvel"]),
+                               _p64(f["HTE"]), _p64(f["HTN"]), _p64(f["tarea"]), _p64(works))
+    del keep
 
 
 def halo_r8(d, a: np.ndarray, loc: int, kind: int, fill: float = 0.0):

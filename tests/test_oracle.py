@@ -234,6 +234,69 @@ def test_halo_tripole_rules():
                 assert u[n, b.jhi, i] == -G2[ny - 1, src]
 
 
+def test_halo_tripole_face_rules():
+    """E-face and N-face vectors across the u-fold (serial/ice_boundary.F90:826-846, copy-out :866-885): the halo updates
+    of the edge velocities of transport_upwind (ice_transport_driver.F90:703-708)."""
+    nx, ny = 16, 6
+    d = blocks.create_distrb_cart(nx, ny, 8, 3, ns_boundary_type="tripole")
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((ny + 2, nx + 2))
+    mk = lambda: blocks.to_blocks(d, lambda I, J: G[np.clip(J, 0, ny + 1), (I - 1) % nx + 1] + 0.0 * (I * J))
+    # E face (ioffset 1, joffset 0): ghost(i, ny+1) = -F(nx-i, ny) with 0 -> nx; the top physical row stays
+    e = mk(); ref = e.copy()
+    orc.halo_r8(d, e, C.LOC_EFACE, C.KIND_VECTOR, 0.0)
+    for n, b in enumerate(d.local_blocks):
+        if not b.tripole:
+            continue
+        assert np.array_equal(e[n, b.jhi - 1, b.ilo - 1:b.ihi], ref[n, b.jhi - 1, b.ilo - 1:b.ihi])
+        for i in range(b.ilo - 1, b.ihi):
+            gi = b.iglob_lo + (i + 1 - b.ilo)
+            src = nx - gi if nx - gi >= 1 else nx
+            assert e[n, b.jhi, i] == -G[ny, src]
+    # N face (ioffset 0, joffset 1): top row symmetrised over the pairs (i, nx+1-i), then top(i) = -sym(nx+1-i), ghost(i, ny+1) = -F(nx+1-i, ny-1)
+    v = mk()
+    orc.halo_r8(d, v, C.LOC_NFACE, C.KIND_VECTOR, 0.0)
+    top = blocks.gather_global(d, v)[ny - 1]
+    for i in range(1, nx // 2 + 1):
+        xavg = 0.5 * (G[ny, i] - G[ny, nx + 1 - i])
+        assert top[i - 1] == xavg and top[nx - i] == -xavg         # F(i) <- -(-xavg) = xavg, F(nx+1-i) <- -xavg
+    for n, b in enumerate(d.local_blocks):
+        if b.tripole:
+            for i in range(b.ilo - 1, b.ihi):
+                gi = b.iglob_lo + (i + 1 - b.ilo)
+                assert v[n, b.jhi, i] == -G[ny - 1, nx + 1 - gi]
+    v2 = v.copy()
+    orc.halo_r8(d, v2, C.LOC_NFACE, C.KIND_VECTOR, 0.0)
+    assert np.array_equal(v, v2)
+
+
+def test_transport_upwind_conserves_and_preserves_constants():
+    """upwind_field (ice_transport_driver.F90:1614-1689) is in flux form: with cyclic E-W and land rows at the N/S edges
+    (no flux through them) the area integral of every advected array is conserved; a uniform field in a non-divergent
+    (here: uniform zonal, on a grid whose HTE does not vary along x) flow stays uniform; donor-cell fluxes keep 0 <= phi."""
+    case, d, f = util.make_case(48, 40, 12, 10, land="rows")
+    rng = np.random.default_rng(3)
+    I, J = blocks.block_index_windows(d)
+    for n in range(d.nblocks):
+        Ig = (I[n] - 1) % 48 + 1
+        f["uvel"][n] = 0.2 * np.sin(2 * np.pi * Ig / 48.0)[None, :] * np.cos(np.pi * (J[n] - 20.5) / 40.0)[:, None] * f["umask"][n]
+        f["vvel"][n] = 0.1 * np.cos(4 * np.pi * Ig / 48.0)[None, :] * np.sin(np.pi * J[n] / 40.0)[:, None] * f["umask"][n]
+    phi = blocks.to_blocks(d, lambda I_, J_: 0.5 + 0.4 * np.sin(0.37 * ((I_ - 1) % 48 + 1)) * np.cos(0.23 * J_)) * f["tmask"]
+    works = np.ascontiguousarray(np.stack([phi, 2.0 * phi], axis=1))
+    for k in range(2):
+        w = np.ascontiguousarray(works[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); works[:, k] = w
+    phys = util.cell_mask(d, "phys")
+    before = [(works[:, k] * f["tarea"])[phys].sum() for k in range(2)]
+    w1 = works.copy()
+    orc.transport_upwind(d, 6000.0, f, w1)
+    for k in range(2):
+        after = (w1[:, k] * f["tarea"])[phys].sum()
+        assert abs(after - before[k]) <= 1e-12 * abs(before[k])
+    assert np.array_equal(w1[:, 1], 2.0 * w1[:, 0]) and w1[:, 0][phys].min() >= 0.0 and np.abs(w1 - works).max() > 1e-4
+    assert np.array_equal(w1[:, :, ~phys[0]] if d.nblocks == 1 else w1[~np.broadcast_to(phys[:, None], w1.shape)],
+                          works[:, :, ~phys[0]] if d.nblocks == 1 else works[~np.broadcast_to(phys[:, None], works.shape)])
+
+
 def test_principal_stress():
     import ctypes as ct
     nx = ny = 4

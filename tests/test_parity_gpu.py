@@ -754,6 +754,42 @@ def test_resident_state_sparse_transfers(ns):
     s.close()
 
 
+@pytest.mark.parametrize("ns,bs", [("open", (100, 116)), ("open", (25, 29)), ("tripole", (24, 16)), ("tripole", (48, 32))])
+def test_transport_upwind_on_the_resident_velocities(ns, bs):
+    """SURVEY S8 row f-3, first step: transport_upwind (ice_transport_driver.F90:634-772) -- edge velocities from the
+    uvel / vvel the evp left on the device, their E-face / N-face halo updates (tripole: the fold rules of those field
+    locations, serial/ice_boundary.F90:826-846) and upwind_field on every array of the work array -- against the oracle's
+    restatement, bit for bit, on BASELINE config 1's shape and on tripole grids, one and many blocks."""
+    nx, ny = (100, 116) if ns == "open" else (96, 64)
+    case, d, f = util.make_case(nx, ny, *bs, ns=ns, land="continents")
+    synth.add_thickness_distribution(f)
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    orc.evp(d, orc.make_params(3600.0, 30, xmin), fo)
+    s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    assert not util.compare(d, fg, fo, names=["uvel", "vvel"])
+    # the work array of state_to_work (:1432-1448): aice0, then per category aicen, vicen, vsnon (+ one aicen-weighted tracer)
+    ncat = f["aicen"].shape[1]
+    planes = [f["aice0"]]
+    for n in range(ncat):
+        a, v = f["aicen"][:, n], f["vicen"][:, n]
+        planes += [a, v, 0.2 * v, a * (0.3 + 0.1 * n)]
+    works = np.ascontiguousarray(np.stack(planes, axis=1))              # (nblocks, narr, ny_block, nx_block)
+    for k in range(works.shape[1]):                                      # ghost cells current, as after bound_state
+        w = np.ascontiguousarray(works[:, k])
+        orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+        works[:, k] = w
+    wo, wg = works.copy(), works.copy()
+    orc.transport_upwind(d, 3600.0, fo, wo)
+    s.ctx.transport_upwind(3600.0, wg)
+    s.close()
+    phys = util.cell_mask(d, "phys")
+    assert np.abs(wo - works)[:, :, phys[0]].max() > 1e-6 if d.nblocks == 1 else np.abs(wo - works).max() > 1e-6
+    assert np.array_equal(wg, wo)                                       # physical cells advected alike, ghost cells untouched by both
+
+
 def test_caller_arrays_in_device_memory():
     """A host model whose fields already live on the GPU passes device pointers in place of host arrays (same block
     layout): the library reads and writes them in place.  Here the arrays are torch tensors on the device."""
