@@ -1360,8 +1360,7 @@ static int tune_R2(evpk_ctx *c) {
         const unsigned int nt = cnt[ncand + k];
         if (nt == 0) continue;
         const int nw = tcand[k] + 3;
-        const double util = (double)((16 / nw) * nw) / 16.0;          // 16 waves per CU at 128 VGPRs: whole workgroups only
-        const double per_simd = std::max((double)((nw + 3) / 4), (double)nt * nw / (double)c->nsimd / util * (nw > 8 ? 1.25 : 1.0));
+        const double per_simd = std::max((double)((nw + 3) / 4), (double)nt * nw / (double)c->nsimd * (nw > 8 ? 1.35 : 1.0));
         const double cost = 3.6 * per_simd + 6.0;
         if (cost < bestT * 0.999) { bestT = cost; bestH = tcand[k]; }
     }
@@ -1602,10 +1601,13 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
-        const bool pair_inside = c->use_double && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
+        // (a small slab on a one-rank tripole grid: the band sequence of a pair -- two band launches, two folds, two hand-overs
+        // between the streams, ~45 us -- costs more than two one-row-per-wave launches with their folds on one stream)
+        const bool pairs = c->use_double && !(c->band_mode && c->tile_mode && c->nranks == 1 && !c->force_exchange);
+        const bool pair_inside = pairs && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
         // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
         // the LAST variant of k_subcycle)
-        const bool pair_ends_evp = c->use_double && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte);
+        const bool pair_ends_evp = pairs && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte);
         if (pair_inside || pair_ends_evp) {
             a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
@@ -1707,8 +1709,18 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         const bool last = (c->ksub == c->p.ndte);
         if (c->nstrips > 0) {
             const dim3 g((((c->nstrips + 3) / 4 + 7) / 8) * 8), b(256);   // multiple of 8: see the XCD remap in k_subcycle
+            // small slab: one row per wave (k_subcycle_t) instead of R + 1 march steps per wave
+            const bool t1 = c->R <= 7 && (long long)c->nstrips * (c->R + 1) <= 8LL * c->nsimd && c->tile_force != 0;
+            const dim3 gt(c->nstrips), bt((c->R + 1) * 64);
+            const size_t lds = (size_t)(c->R + 1) * 2048;
             if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
-            if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, c->stream, a);
+            if (t1) {
+                if (last && revp) hipLaunchKernelGGL((k_subcycle_t<true, true>), gt, bt, lds, c->stream, a);
+                else if (last) hipLaunchKernelGGL((k_subcycle_t<true, false>), gt, bt, lds, c->stream, a);
+                else if (revp) hipLaunchKernelGGL((k_subcycle_t<false, true>), gt, bt, lds, c->stream, a);
+                else hipLaunchKernelGGL((k_subcycle_t<false, false>), gt, bt, lds, c->stream, a);
+            }
+            else if (last && revp) hipLaunchKernelGGL((k_subcycle<true, true>), g, b, 0, c->stream, a);
             else if (last) hipLaunchKernelGGL((k_subcycle<true, false>), g, b, 0, c->stream, a);
             else if (revp) hipLaunchKernelGGL((k_subcycle<false, true>), g, b, 0, c->stream, a);
             else hipLaunchKernelGGL((k_subcycle<false, false>), g, b, 0, c->stream, a);

@@ -220,7 +220,9 @@ def test_forced_exchange_path(ns, monkeypatch):
 
 def test_two_subcycle_kernel_equals_single(monkeypatch):
     """k_subcycle2 (two subcycles per launch) vs k_subcycle only: bit-identical, including odd ndte,
-    subcycles issued in odd pieces, revised EVP, and a non-cyclic E-W boundary."""
+    subcycles issued in odd pieces, revised EVP, and a non-cyclic E-W boundary.  (EVPK_TILE=0: the marching kernels; on a
+    one-rank tripole grid this small the tuner would otherwise drop the pairs for one-row-per-wave single launches.)"""
+    monkeypatch.setenv("EVPK_TILE", "0")
     for kw, ndte, pieces in [(dict(land="continents"), 31, [31]), (dict(land="continents"), 40, [7, 12, 21]),
                              (dict(ice="full"), 24, [24]), (dict(land="continents", ns="tripole"), 33, [33]),
                              (dict(ice="full", ns="tripole"), 26, [9, 17])]:
