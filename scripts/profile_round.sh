@@ -40,6 +40,8 @@ rm -rf "$out"/pmc_sq
 bash scripts/configs.sh > "$out/configs.txt" 2>&1
 python3 scripts/pcie_run.py > "$out/pcie.txt" 2>&1
 bash scripts/zone_sweep.sh > "$out/zone_sweep.txt" 2>&1
+bash scripts/xp_compare.sh > "$out/xp_compare.txt" 2>&1
+bash scripts/tile_ab.sh > "$out/tile_ab.txt" 2>&1
 fi
 cp profiles/traffic.json "$out/traffic.json" 2>/dev/null
 ls -la "$out"
