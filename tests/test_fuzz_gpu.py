@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH": "0"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_ZONE_M": "2"},
          {"EVPK_COMPACT_METRICS": "0"}, {"EVPK_STRIP_ROWS": "3"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_OVERLAP": "0"},
-         {"EVPK_FORCE_EXCHANGE": "2"}, {"EVPK_FORCE_EXCHANGE": "2", "EVPK_ZONE_M": "1"}]
+         {"EVPK_FORCE_EXCHANGE": "2"}, {"EVPK_FORCE_EXCHANGE": "2", "EVPK_ZONE_M": "1"},
+         {"EVPK_TILE": "1"}, {"EVPK_TILE": "1", "EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_TILE": "1", "EVPK_STRIP_ROWS": "2"}, {"EVPK_TILE": "0"}]
 
 
 def _config(seed):
@@ -39,7 +40,7 @@ def _config(seed):
     return dict(nx=nx, ny=ny, bsx=bsx, bsy=bsy, ns=ns, ew=ew, ndte=int(rng.choice([1, 2, 5, 8, 13, 20])),
                 revised=bool(rng.random() < 0.3), turn=bool(rng.random() < 0.3), ice=str(rng.choice(["polar", "full", "patches", "dots"])),
                 land=str(rng.choice(["rows", "continents"])), mode=MODES[int(rng.integers(len(MODES)))], ncalls=int(rng.choice([1, 2, 3])),
-                resident=bool(rng.random() < 0.5), pin=bool(rng.random() < 0.2),
+                resident=bool(rng.random() < 0.5), pin=bool(rng.random() < 0.2), sparse=bool(rng.random() < 0.25),
                 tilt=bool(rng.random() < 0.2), ugrid_wind=bool(rng.random() < 0.2), dt=float(rng.choice([3600.0, 900.0, 7200.0])),
                 strength=(None if rng.random() < 0.6 else dict(kstrength=int(rng.integers(0, 2)), krdg_partic=int(rng.integers(0, 2)),
                                                                  krdg_redist=int(rng.integers(0, 2)))), rng=rng)
@@ -48,6 +49,8 @@ def _config(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_N", "40"))))
 def test_random_configuration(seed, monkeypatch):
     k = _config(seed)
+    k["sparse"] = k["sparse"] and k["resident"] and not k["ugrid_wind"]      # sparse transfers: resident state, page-locked arrays
+    k["pin"] = k["pin"] or k["sparse"]
     for name, v in k["mode"].items():
         monkeypatch.setenv(name, v)
     case = synth.SynthCase(nx=k["nx"], ny=k["ny"], ns_boundary=C.BND_NAMES[k["ns"]], ew_boundary=C.BND_NAMES[k["ew"]],
@@ -63,7 +66,8 @@ def test_random_configuration(seed, monkeypatch):
     p = orc.make_params(dt, k["ndte"], xmin, revised_evp=k["revised"], cosw=cosw, sinw=sinw, tilt_from_slope=k["tilt"],
                         wind_on_ugrid=k["ugrid_wind"], **skw)
     s = dyn.EvpDynamics(d, fg, ndte=k["ndte"], revised_evp=k["revised"], xmin=xmin, cosw=cosw, sinw=sinw,
-                        tilt_from_slope=k["tilt"], wind_on_ugrid=k["ugrid_wind"], device_strength=k["strength"], pin_host=k["pin"])
+                        tilt_from_slope=k["tilt"], wind_on_ugrid=k["ugrid_wind"], device_strength=k["strength"], pin_host=k["pin"],
+                        sparse_io=k["sparse"])
     s.init_evp(dt)
     I, J = blocks.block_index_windows(d)
     nxg, nyg = d.nx_global, d.ny_global
@@ -92,6 +96,10 @@ def test_random_configuration(seed, monkeypatch):
         if k["strength"]:
             for ff in (fo, fg):
                 synth.add_thickness_distribution(ff)
+        if k["sparse"]:                        # its precondition: no T-grid forcing where there is no ice
+            for ff in (fo, fg):
+                for name in ("strairxT", "strairyT"):
+                    ff[name][...] = np.where(ff["aice"] > 0.0, base[name], 0.0)
         nt, nu, _ = orc.evp(d, p, fo)
         if k["resident"] and call:             # the state stays on the device: inputs only, then the staged calls
             s.ctx.upload_inputs(fg)

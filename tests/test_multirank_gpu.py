@@ -86,6 +86,22 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
                 for name in util.ALL_CELLS + util.NE_CELLS + util.PHYS_CELLS:
                     ref.setdefault(name, np.zeros_like(f[name]))[n] = f1[name][n1]
             bad += [(call,) + x for x in util.compare(d, f, ref)]
+        if env.get("TEST_UPWIND"):
+            # transport_upwind (row f-3) on the slab's resident velocities: its edge-velocity halos go through the same
+            # exchange machinery (E-W ring, tripole fold of E-face / N-face fields with the mirror ranks)
+            synth.add_thickness_distribution(f1)
+            planes = [f1["aice0"]] + [a for n in range(f1["aicen"].shape[1]) for a in (f1["aicen"][:, n], f1["vicen"][:, n])]
+            w1 = np.ascontiguousarray(np.stack(planes, axis=1))
+            for k in range(w1.shape[1]):
+                w = np.ascontiguousarray(w1[:, k]); orc.halo_r8(d1, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); w1[:, k] = w
+            loc = [next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id) for b in d.local_blocks]
+            wl = np.ascontiguousarray(w1[loc])
+            orc.transport_upwind(d1, 3600.0, f1, w1)
+            s.ctx.transport_upwind(3600.0, wl)
+            if not np.array_equal(wl, w1[loc]):
+                bad.append(("transport_upwind", int((wl != w1[loc]).sum())))
+            if not np.abs(w1[loc] - np.stack(planes, axis=1)[loc]).max() > 0:
+                bad.append(("transport_upwind did nothing", 0))
         st = s.ctx.stats()
         s.close()
         if int(st.transport) != {"shm": 2, "ipc": 3}[xp]:
@@ -181,6 +197,11 @@ def test_x_slabs_tripole(xp):
     _run(2, "tripole", 240, 64, 20, 32, ndte=24, xp=xp)
     _run(4, "tripole", 240, 64, 30, 16, ndte=13, xp=xp)
     _run(3, "tripole", 240, 64, 20, 32, ndte=10, xp=xp)          # uneven mirror: 3 slabs
+
+
+@pytest.mark.parametrize("ns,world", [("open", 3), ("tripole", 2), ("tripole", 4)])
+def test_transport_upwind_across_slabs(ns, world):
+    _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_UPWIND": "1"}, xp="ipc")
 
 
 def test_x_slabs_one_subcycle_kernel_and_serial_exchange():
