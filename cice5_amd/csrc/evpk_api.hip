@@ -1045,11 +1045,17 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking,
                                               (g->nranks > 1 && g->ns_boundary != EVPK_BND_TRIPOLE) ? least : greatest));
     }
-    HIPCHK(c, hipEventCreateWithFlags(&c->evB0, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->evB1, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->evI, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->evE, hipEventDisableTiming));
+    {   // hand-over events between the two streams of THIS device: a device-scope release is all they need (the system-scope
+        // fence of a default event costs ~4 us per hand-over; EVPK_EVENT_SCOPE=0 restores it)
+        unsigned fl = hipEventDisableTiming | hipEventReleaseToDevice;
+        const char *e = getenv("EVPK_EVENT_SCOPE");
+        if (e && atoi(e) == 0) fl = hipEventDisableTiming;
+        HIPCHK(c, hipEventCreateWithFlags(&c->evB0, fl));
+        HIPCHK(c, hipEventCreateWithFlags(&c->evB1, fl));
+        HIPCHK(c, hipEventCreateWithFlags(&c->evI, fl));
+        HIPCHK(c, hipEventCreateWithFlags(&c->evX, fl));
+        HIPCHK(c, hipEventCreateWithFlags(&c->evE, fl));
+    }
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
     const size_t nd = slab_doubles(s), nm = mask_elems(s);
