@@ -270,6 +270,21 @@ def make_block_fields(case: SynthCase, d: Decomp) -> Dict[str, np.ndarray]:
     return f
 
 
+def add_remap_grid(case: SynthCase, d: Decomp, f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """the grid arrays horizontal_remap reads beyond those of evp (ice_transport_remap.F90:340-343): dxu, dyu, hm (real land mask)"""
+    from .blocks import block_index_windows
+    shp = (d.nblocks, d.ny_block, d.nx_block)
+    for n in ("dxu", "dyu", "hm"):
+        f[n] = np.zeros(shp, dtype=np.float64)
+    Iw, Jw = block_index_windows(d)
+    for b in range(d.nblocks):
+        I, J = np.broadcast_arrays(Iw[b][None, :], Jw[b][:, None])
+        f["dxu"][b] = case.field("dxu", I, J)
+        f["dyu"][b] = case.field("dyu", I, J)
+        f["hm"][b] = case.hm(I, J)
+    return f
+
+
 def global_min_dx(case: SynthCase) -> float:
     """min(global_minval(dxt, tmask), global_minval(dyt, tmask)) of ice_dyn_shared.F90:221-223."""
     I = np.arange(1, case.nx + 1)[None, :]

@@ -176,6 +176,16 @@ void orc_halo_stress(const orc_geom *g, double *a1, const double *a2);
 void orc_transport_upwind(const orc_geom *g, double dt, int narr, const double *uvel, const double *vvel,
                           const double *HTE, const double *HTN, const double *tarea, double *works);
 
+/* horizontal_remap (source/ice_transport_remap.F90:309-850), the incremental remapping transport: oracle/remap_oracle.c.
+ * mm (nblocks, ncat+1, ny, nx) [plane 0 = open water], tm (nblocks, ncat, ntrace, ny, nx), both in place on physical cells, ghost
+ * cells current on entry; tracer_type / depend (1-based, 0 = none) / has_dependents as init_transport builds them
+ * (ice_transport_driver.F90:66-183); l_fixed_area must be 0.  Returns 0, 1 (departure points out of bounds), 2 (negative
+ * area) or 3 (unsupported option). */
+int orc_horizontal_remap(const orc_geom *g, double dt, int ncat, int ntrace, const double *uvel, const double *vvel, double *mm, double *tm,
+                         int l_fixed_area, const int32_t *tracer_type, const int32_t *depend, const int32_t *has_dependents,
+                         int integral_order, int l_dp_midpt, const double *HTE, const double *HTN, const double *dxu, const double *dyu,
+                         const double *tarear, const double *hm);
+
 void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_override,
              int64_t counts[2], double *loop_seconds /* [0] wall time of the subcycle loop, [1] the halo updates' share of it; may be NULL */);
 

@@ -66,7 +66,7 @@ HALO_CB = ct.CFUNCTYPE(None, c_f64p, ct.c_int, ct.c_int, ct.c_double, ct.c_int, 
 
 def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "evp_oracle.c")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, n)) for n in ("evp_oracle.c", "remap_oracle.c", "evp_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libevp_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -104,6 +104,9 @@ def lib():
         _lib.orc_halo_r8.argtypes = [ct.POINTER(OrcGeom), c_f64p, ct.c_int, ct.c_int, ct.c_double]
         _lib.orc_halo_i4.argtypes = [ct.POINTER(OrcGeom), c_i32p, ct.c_int32]
         _lib.orc_transport_upwind.argtypes = [ct.POINTER(OrcGeom), ct.c_double, ct.c_int] + [c_f64p] * 6
+        _lib.orc_horizontal_remap.argtypes = ([ct.POINTER(OrcGeom), ct.c_double, ct.c_int, ct.c_int] + [c_f64p] * 4 + [ct.c_int] +
+                                              [c_i32p] * 3 + [ct.c_int, ct.c_int] + [c_f64p] * 6)
+        _lib.orc_horizontal_remap.restype = ct.c_int
         _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
         _lib.orc_principal_stress.argtypes = [ct.c_int, ct.c_int] + [c_f64p] * 6
         _lib.orc_set_halo_callback.argtypes = [HALO_CB, ct.c_void_p]
@@ -185,6 +188,41 @@ def transport_upwind(d, dt: float, f: Dict[str, np.ndarray], works: np.ndarray):
     lib().orc_transport_upwind(ct.byref(g), float(dt), int(works.shape[1]), _p64(f["uvel"]), _p64(f["vvel"]),
                                _p64(f["HTE"]), _p64(f["HTN"]), _p64(f["tarea"]), _p64(works))
     del keep
+
+
+def remap_tables(trcr_depend):
+    """tracer_type / depend / has_dependents of init_transport (ice_transport_driver.F90:88-125) for hice, hsno and the
+    tracers whose `trcr_depend` (0 area, 1 ice volume, 2 snow volume, 2 + nt: tracer nt) is given"""
+    ntrace = 2 + len(trcr_depend)
+    depend = np.zeros(ntrace, dtype=np.int32)
+    ttype = np.ones(ntrace, dtype=np.int32)
+    for nt, dep in enumerate(trcr_depend, start=1):
+        depend[2 + nt - 1] = dep
+        ttype[2 + nt - 1] = 2
+        if dep == 0:
+            ttype[2 + nt - 1] = 1
+        elif dep > 2 and trcr_depend[dep - 2 - 1] > 0:
+            ttype[2 + nt - 1] = 3
+    has = np.zeros(ntrace, dtype=np.int32)
+    for nt in range(ntrace):
+        if depend[nt] > 0:
+            assert depend[nt] - 1 < nt, "a tracer must come after the tracer it depends on"
+            has[depend[nt] - 1] = 1
+    return ttype, depend, has
+
+
+def horizontal_remap(d, dt: float, f: Dict[str, np.ndarray], mm: np.ndarray, tm: np.ndarray, tracer_type, depend, has_dependents,
+                     integral_order: int = 3, l_dp_midpt: bool = True, l_fixed_area: bool = False) -> int:
+    """orc_horizontal_remap: mm (nblocks, ncat+1, ny, nx), tm (nblocks, ncat, ntrace, ny, nx) in place; velocities and grid from f"""
+    g, keep = make_geom(d)
+    ncat, ntrace = mm.shape[1] - 1, tm.shape[2]
+    rc = lib().orc_horizontal_remap(ct.byref(g), float(dt), ncat, ntrace, _p64(f["uvel"]), _p64(f["vvel"]), _p64(mm), _p64(tm),
+                                    int(l_fixed_area), _p32(np.ascontiguousarray(tracer_type, dtype=np.int32)),
+                                    _p32(np.ascontiguousarray(depend, dtype=np.int32)),
+                                    _p32(np.ascontiguousarray(has_dependents, dtype=np.int32)), int(integral_order), int(l_dp_midpt),
+                                    _p64(f["HTE"]), _p64(f["HTN"]), _p64(f["dxu"]), _p64(f["dyu"]), _p64(f["tarear"]), _p64(f["hm"]))
+    del keep
+    return int(rc)
 
 
 def halo_r8(d, a: np.ndarray, loc: int, kind: int, fill: float = 0.0):

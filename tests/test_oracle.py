@@ -297,6 +297,128 @@ def test_transport_upwind_conserves_and_preserves_constants():
                           works[:, :, ~phys[0]] if d.nblocks == 1 else works[~np.broadcast_to(phys[:, None], works.shape)])
 
 
+def _remap_case(nx, ny, bsx, bsy, ns="open", ncat=3, seed=4, dt=3600.0, trcr_depend=(0, 1, 2 + 1)):
+    """a state for horizontal_remap: areas aim(0:ncat) summing to 1 over ocean, hice / hsno (type 1), a surface tracer on
+    the area (depend 0), one on the ice volume (depend 1: type 2 on hice) and one on the first tracer (type 2 / 3), and a
+    smooth velocity field that vanishes on land; ghost cells current (halo updates of the oracle)"""
+    case, d, f = util.make_case(nx, ny, bsx, bsy, ns=ns, land="continents")
+    synth.add_remap_grid(case, d, f)
+    I, J = blocks.block_index_windows(d)
+    ttype, depend, has = orc.remap_tables(list(trcr_depend))
+    ntrace = len(ttype)
+    mm = np.zeros((d.nblocks, ncat + 1, d.ny_block, d.nx_block))
+    tm = np.zeros((d.nblocks, ncat, ntrace, d.ny_block, d.nx_block))
+    for b in range(d.nblocks):
+        Ig = ((I[b] - 1) % nx + 1)[None, :] + 0 * J[b][:, None]
+        Jg = J[b][:, None] + 0 * I[b][None, :]
+        x, y = 2 * np.pi * Ig / nx, np.pi * Jg / ny
+        ocean = f["tmask"][b] > 0
+        ice = ocean & (np.sin(3 * x + 0.5) * np.cos(2 * y) > -0.3)
+        tot = np.zeros_like(x)
+        for n in range(1, ncat + 1):
+            a = np.where(ice, 0.25 * (1 + 0.8 * np.sin(n * x + y)) / ncat * 2.0, 0.0)
+            a = np.where(np.sin(5 * x * n + 2 * y) > 0.7, 0.0, a)          # holes: categories without ice
+            mm[b, n] = a
+            tot += a
+            tm[b, n - 1, 0] = np.where(a > 0, n * (0.5 + 0.3 * np.cos(2 * x - y)), 0.0)        # hice
+            tm[b, n - 1, 1] = np.where(a > 0, 0.1 * (1 + 0.5 * np.sin(x + 3 * y)), 0.0)        # hsno
+            for k in range(2, ntrace):
+                tm[b, n - 1, k] = np.where(a > 0, -2.0 - k + np.sin(k * x) * np.cos(y + n), 0.0)
+        mm[b, 0] = np.where(ocean, 1.0 - tot, 0.0)
+        f["uvel"][b] = 0.3 * np.sin(2 * x) * np.cos(y) * f["umask"][b]
+        f["vvel"][b] = 0.2 * np.cos(3 * x + 1.0) * np.sin(2 * y) * f["umask"][b]
+    for arr in (mm.reshape(d.nblocks, -1, d.ny_block, d.nx_block), tm.reshape(d.nblocks, -1, d.ny_block, d.nx_block)):
+        for k in range(arr.shape[1]):
+            w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
+    for n in ("uvel", "vvel"):
+        orc.halo_r8(d, f[n], C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+    return case, d, f, mm, tm, (ttype, depend, has)
+
+
+def test_remap_conserves_and_keeps_tracers_monotone():
+    """horizontal_remap (ice_transport_remap.F90:309-850): area, area*tracer and area*tracer*tracer integrals are conserved
+    (flux form; no flux through land or the closed N/S rows), no tracer leaves the range of its 3x3 neighbourhood
+    (limited gradients), nothing moves without velocity, uniform tracers stay uniform."""
+    case, d, f, mm, tm, (ttype, depend, has) = _remap_case(48, 40, 48, 40)
+    phys = util.cell_mask(d, "phys")[0]
+    ta = f["tarea"][0]
+    m0, t0 = mm.copy(), tm.copy()
+    assert orc.horizontal_remap(d, 3600.0, f, mm, tm, ttype, depend, has) == 0
+    assert np.abs(mm - m0)[0][:, phys].max() > 1e-3
+    ncat, ntrace = tm.shape[1], tm.shape[2]
+    for n in range(ncat + 1):
+        a0, a1 = (m0[0, n] * ta)[phys].sum(), (mm[0, n] * ta)[phys].sum()
+        assert abs(a1 - a0) <= 1e-12 * abs(a0), n
+    def amount(m, t, n, k):
+        q = m[0, n] * t[0, n - 1, k]
+        dep = depend[k]
+        while dep > 0:
+            q = q * t[0, n - 1, dep - 1]
+            dep = depend[dep - 1]
+        return (q * ta)[phys].sum()
+    for n in range(1, ncat + 1):
+        for k in range(ntrace):
+            q0, q1 = amount(m0, t0, n, k), amount(mm, tm, n, k)
+            assert abs(q1 - q0) <= 1e-11 * max(abs(q0), 1e-30), (n, k)
+    # monotonicity of the type-1 tracers: within the quasi-local bounds of check_monotonicity (ice_transport_driver.F90:
+    # 1084-1235: min / max over the 3x3 neighbourhood with ice, extended to the neighbours' neighbourhoods)
+    for n in range(1, ncat + 1):
+        for k in range(ntrace):
+            if ttype[k] != 1:
+                continue
+            old, a_old = t0[0, n - 1, k], m0[0, n] > 1e-11
+            lo = np.full(old.shape, np.inf); hi = np.full(old.shape, -np.inf)
+            for dj in (-2, -1, 0, 1, 2):
+                for di in (-2, -1, 0, 1, 2):
+                    sh = np.roll(np.roll(np.where(a_old, old, np.nan), dj, 0), di, 1)
+                    lo = np.fmin(lo, sh); hi = np.fmax(hi, sh)
+            new = tm[0, n - 1, k]
+            chk = phys & (mm[0, n] > 1e-9) & np.isfinite(lo)
+            chk[[0, 1, -2, -1], :] = False; chk[:, [0, 1, -2, -1]] = False
+            assert (new[chk] >= lo[chk] - 1e-9 * np.abs(lo[chk])).all() and (new[chk] <= hi[chk] + 1e-9 * np.abs(hi[chk])).all(), (n, k)
+    # nothing moves without velocity
+    m2, t2 = m0.copy(), t0.copy()
+    f2 = dict(f); f2["uvel"] = np.zeros_like(f["uvel"]); f2["vvel"] = np.zeros_like(f["vvel"])
+    assert orc.horizontal_remap(d, 3600.0, f2, m2, t2, ttype, depend, has) == 0
+    assert np.array_equal(m2[0][:, phys], m0[0][:, phys])
+    keep = m0[0, 1:][:, None] > 0
+    # (the tracers go through (m*T)/m: equal to rounding)
+    assert np.allclose(np.where(keep, t2[0], 0.0)[:, :, phys], np.where(keep, t0[0], 0.0)[:, :, phys], rtol=4e-16, atol=0)
+    # uniform tracers stay uniform where ice is
+    t3 = np.where(m0[:, 1:, None] > 0, 2.5, 0.0) * np.ones_like(t0)
+    m3 = m0.copy()
+    for k in range(t3.shape[2]):
+        for n in range(t3.shape[1]):
+            w = np.ascontiguousarray(t3[:, n, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); t3[:, n, k] = w
+    assert orc.horizontal_remap(d, 3600.0, f, m3, t3, ttype, depend, has) == 0
+    ice = (m3[0, 1:] > 1e-9)[:, None] & phys[None, None] & np.ones_like(t3[0], dtype=bool)
+    assert np.abs(t3[0][ice] - 2.5).max() < 1e-11
+    # the departure points must stay within the neighbouring cells (:1583-1589)
+    assert orc.horizontal_remap(d, 3.0e6, f, m0.copy(), t0.copy(), ttype, depend, has) == 1
+
+
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_remap_decomposition_invariance(ns):
+    """1 block == N blocks bit for bit (ghost-cell updates of dpx, dpy, mc, mx, my, tc, tx, ty, :564-613), both integral
+    orders 2 and 3 and both departure-point rules"""
+    ref = None
+    for bs in [(48, 40), (12, 10), (24, 20)]:
+        case, d, f, mm, tm, (ttype, depend, has) = _remap_case(48, 40, *bs, ns=ns)
+        out = []
+        for order, midpt in ((3, True), (2, False), (1, True)):
+            m, t = mm.copy(), tm.copy()
+            assert orc.horizontal_remap(d, 3600.0, f, m, t, ttype, depend, has, integral_order=order, l_dp_midpt=midpt) == 0
+            out.append([blocks.gather_global(d, np.ascontiguousarray(m[:, n])) for n in range(m.shape[1])] +
+                       [blocks.gather_global(d, np.ascontiguousarray(t[:, n, k])) for n in range(t.shape[1]) for k in range(t.shape[2])])
+        if ref is None:
+            ref = out
+            assert np.abs(out[0][1] - out[1][1]).max() > 0          # the options do change the result
+        else:
+            for a, b in zip(ref, out):
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y), bs
+
+
 def test_principal_stress():
     import ctypes as ct
     nx = ny = 4
