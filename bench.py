@@ -57,9 +57,9 @@ def parse():
 
 
 def source_sha():
-    """identifies the kernel build a PMC pass was made with: the three sources libevpk.so is compiled from"""
+    """identifies the kernel build a PMC pass was made with: the sources libevpk.so is compiled from"""
     h = hashlib.sha256()
-    for n in ("evpk_kernels.hip", "evpk_api.hip", "evpk_internal.h"):
+    for n in ("evpk_kernels.hip", "evpk_api.hip", "evpk_internal.h", "evpk_remap.hip"):
         h.update(open(os.path.join(ROOT, "cice5_amd", "csrc", n), "rb").read())
     return h.hexdigest()[:16]
 

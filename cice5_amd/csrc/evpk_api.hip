@@ -28,6 +28,7 @@
 
 // single translation unit: the kernels are compiled together with the host API
 #include "evpk_kernels.hip"
+#include "evpk_remap.hip"
 
 using namespace evpk;
 
@@ -264,6 +265,12 @@ struct evpk_ctx {
     int nsimd = 1024;                // SIMDs of the chip (4 per CU)
     double *tp_a = nullptr, *tp_b = nullptr, *tp_stage = nullptr;   // transport_upwind: two scratch planes, staging of the work array
     size_t tp_stage_n = 0;
+    // transport_remap: grid planes (dxu, dyu, hm), the plane pool of one call shape, its pointer tables, the error word
+    double *rm_grid = nullptr, *rm_pool = nullptr, *rm_stage = nullptr;
+    double **rm_tab = nullptr;
+    signed char *rm_sgn = nullptr;
+    unsigned *rm_bad = nullptr;
+    size_t rm_pool_n = 0, rm_stage_n = 0, rm_tab_n = 0;
     bool have_lengths = false;       // HTN / HTE were given in evpk_geom
     unsigned char *io_raw = nullptr, *io_act = nullptr;   // sparse I/O: tiles whose inputs are uploaded this step
     long long evp_count = 0;         // evpk_prep calls so far
@@ -794,7 +801,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -2021,6 +2028,174 @@ extern "C" int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, doubl
     if (staged) HIPCHK(c, hipMemcpyAsync(works, c->tp_stage, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return xp_check(c);
+}
+
+// ---- transport_remap's horizontal_remap (source/ice_transport_remap.F90:309-850) on the resident velocities ----
+// grid arrays the EVP path does not hold: dxu, dyu (ice_grid) and hm (the land mask as a real); block arrays, ghost cells current
+extern "C" int evpk_remap_init(evpk_ctx *c, const double *dxu, const double *dyu, const double *hm) {
+    if (!c || !dxu || !dyu || !hm) return 1;
+    if (!c->connected) FAIL(c, "evpk_remap_init: the context is not connected yet (evpk_connect)");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t np = mask_elems(s), nblk = (size_t)c->nyb * c->nxb, n = (size_t)c->nblocks * nblk;
+    if (!c->rm_grid) HIPCHK(c, hipMalloc(&c->rm_grid, sizeof(double) * 3 * np));
+    if (!c->rm_bad) HIPCHK(c, hipMalloc(&c->rm_bad, sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(c->rm_grid, 0, sizeof(double) * 3 * np, c->stream));
+    if (c->stage_n < n) FAIL(c, "evpk_remap_init: staging buffer too small");
+    const double *src[3] = {dxu, dyu, hm};
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    for (int q = 0; q < 3; q++) {
+        const double *dev = (const double *)mapped_alias(src[q]);
+        if (!dev) {
+            HIPCHK(c, hipMemcpyAsync(c->stage, src[q], sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+            dev = c->stage;
+        }
+        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, dev, nblk, c->rm_grid + (size_t)q * np);
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // (the staging buffer is reused by the next array)
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// ghost ring of a list of plain planes (centre location; scalars or vectors): one launch on one rank, else through the
+// scratch state planes and the general update, max_nf planes at a time
+static int planes_halo(evpk_ctx *c, double **d_list, const signed char *d_sgn, int n, bool vector) {
+    Slab &s = c->s;
+    if (n <= 0) return 0;
+    if (c->ns == EVPK_BND_CYCLIC) FAIL(c, "ns_boundary_type cyclic is not supported");
+    const int tx = 128;
+    if (c->nranks == 1 && !c->force_exchange) {
+        hipLaunchKernelGGL(k_planes_halo, dim3((s.nxl + s.nyl + 2 + tx - 1) / tx, n), dim3(tx), 0, c->stream, s, (double *const *)d_list, d_sgn,
+                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    const int nt = 4 * (s.nxl + 2) + 4 * (s.nyl + 2);
+    for (int q = 0; q < n; q += c->max_nf) {
+        const int nf = std::min(c->max_nf, n - q);
+        hipLaunchKernelGGL(k_planes_frame, dim3((nt + tx - 1) / tx), dim3(tx), 0, c->stream, s, (double *const *)(d_list + q), (int)F_STATE2, nf, 0);
+        if (halo(c, F_STATE2, nf, false, vector, 0.0)) return 1;
+        hipLaunchKernelGGL(k_planes_frame, dim3((nt + tx - 1) / tx), dim3(tx), 0, c->stream, s, (double *const *)(d_list + q), (int)F_STATE2, nf, 1);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, double *mm, double *tm, const int32_t *tracer_type,
+                                    const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
+                                    int32_t l_fixed_area) {
+    if (!c || !mm || ncat < 1 || ntrace < 0 || (ntrace > 0 && (!tm || !tracer_type || !depend || !has_dependents))) return 1;
+    if (!c->uploaded) FAIL(c, "evpk_transport_remap: no velocities on the device (run evp first)");
+    if (!c->have_lengths) FAIL(c, "evpk_transport_remap needs HTN and HTE in evpk_geom");
+    if (!c->rm_grid) FAIL(c, "evpk_transport_remap: evpk_remap_init has not been called");
+    if (l_fixed_area) FAIL(c, "evpk_transport_remap: l_fixed_area = .true. is not supported");
+    if (ntrace > RM_MAXT) FAIL(c, "evpk_transport_remap: ntrace = %d exceeds %d", ntrace, RM_MAXT);
+    if (integral_order < 1 || integral_order > 3) FAIL(c, "evpk_transport_remap: integral_order = %d", integral_order);
+    RemapTab tb{};
+    tb.ncat = ncat; tb.ntrace = ntrace; tb.order = integral_order; tb.midpt = l_dp_midpt ? 1 : 0;
+    for (int nt = 0; nt < ntrace; nt++) {
+        if (tracer_type[nt] < 1 || tracer_type[nt] > 3) FAIL(c, "evpk_transport_remap: tracer_type(%d) = %d", nt + 1, tracer_type[nt]);
+        // a dependent tracer follows the one it depends on (ice_transport_driver.F90:init_transport orders them so); type 3 hangs on a type 2
+        if (tracer_type[nt] > 1 && (depend[nt] < 1 || depend[nt] > nt)) FAIL(c, "evpk_transport_remap: depend(%d) = %d", nt + 1, depend[nt]);
+        if (tracer_type[nt] == 3 && (tracer_type[depend[nt] - 1] != 2)) FAIL(c, "evpk_transport_remap: tracer %d (type 3) must depend on a type 2 tracer", nt + 1);
+        tb.type[nt] = (signed char)tracer_type[nt]; tb.dep[nt] = (signed char)depend[nt]; tb.has[nt] = has_dependents[nt] ? 1 : 0;
+    }
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ncp = ncat + 1, ntp = ncat * ntrace;
+    const size_t np = mask_elems(s), nblk = (size_t)c->nyb * c->nxb;
+    const size_t nplanes = (size_t)5 * ncp + (size_t)6 * ntp;
+    if (c->rm_pool_n < nplanes * np) {
+        if (c->rm_pool) (void)hipFree(c->rm_pool);
+        c->rm_pool = nullptr; c->rm_pool_n = 0;
+        if (hipMalloc(&c->rm_pool, sizeof(double) * nplanes * np) != hipSuccess)
+            FAIL(c, "evpk_transport_remap: %zu planes of %zu cells do not fit on the device", nplanes, np);
+        c->rm_pool_n = nplanes * np;
+        HIPCHK(c, hipMemsetAsync(c->rm_pool, 0, sizeof(double) * nplanes * np, c->stream));
+    }
+    // pointer tables: [0, nplanes) the planes in RemapPlanes order; then the two halo lists
+    //   A (before construct_fields): mm, tm -- scalars;   B: tc -- scalars, then mx, my, tx, ty -- vectors
+    std::vector<double *> tab(nplanes);
+    for (size_t q = 0; q < nplanes; q++) tab[q] = c->rm_pool + q * np;
+    const size_t o_tm = 5 * ncp, o_tc = o_tm + ntp, o_tx = o_tc + ntp, o_ty = o_tx + ntp;
+    std::vector<double *> lst;
+    std::vector<signed char> sg;
+    for (int q = 0; q < ncp; q++) { lst.push_back(tab[q]); sg.push_back(1); }
+    for (int q = 0; q < ntp; q++) { lst.push_back(tab[o_tm + q]); sg.push_back(1); }
+    const size_t nA = lst.size();
+    for (int q = 0; q < ntp; q++) { lst.push_back(tab[o_tc + q]); sg.push_back(1); }
+    const size_t nBs = lst.size() - nA;
+    for (int q = 0; q < 2 * ncp; q++) { lst.push_back(tab[ncp + q]); sg.push_back(-1); }
+    for (int q = 0; q < ntp; q++) { lst.push_back(tab[o_tx + q]); sg.push_back(-1); }
+    for (int q = 0; q < ntp; q++) { lst.push_back(tab[o_ty + q]); sg.push_back(-1); }
+    const size_t nBv = lst.size() - nA - nBs, nall = nplanes + lst.size();
+    if (c->rm_tab_n < nall) {
+        if (c->rm_tab) (void)hipFree(c->rm_tab);
+        if (c->rm_sgn) (void)hipFree(c->rm_sgn);
+        c->rm_tab = nullptr; c->rm_sgn = nullptr; c->rm_tab_n = 0;
+        HIPCHK(c, hipMalloc(&c->rm_tab, sizeof(double *) * nall));
+        HIPCHK(c, hipMalloc(&c->rm_sgn, nall));
+        c->rm_tab_n = nall;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->rm_tab, tab.data(), sizeof(double *) * nplanes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rm_tab + nplanes, lst.data(), sizeof(double *) * lst.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rm_sgn, sg.data(), sg.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->rm_bad, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab, lst, sg are pageable host vectors)
+    RemapPlanes P{(double *const *)c->rm_tab, ncp, ntp};
+    // the caller's arrays: in place where their memory is visible to the device, else through a staging copy
+    const size_t n_mm = (size_t)c->nblocks * ncp * nblk, n_tm = (size_t)c->nblocks * ntp * nblk;
+    double *dmm = (double *)mapped_alias(mm), *dtm = ntp ? (double *)mapped_alias(tm) : nullptr;
+    const bool st_mm = !dmm, st_tm = ntp && !dtm;
+    if (st_mm || st_tm) {
+        const size_t need = (st_mm ? n_mm : 0) + (st_tm ? n_tm : 0);
+        if (c->rm_stage_n < need) {
+            if (c->rm_stage) (void)hipFree(c->rm_stage);
+            c->rm_stage = nullptr; c->rm_stage_n = 0;
+            HIPCHK(c, hipMalloc(&c->rm_stage, sizeof(double) * need));
+            c->rm_stage_n = need;
+        }
+        double *q = c->rm_stage;
+        if (st_mm) { HIPCHK(c, hipMemcpyAsync(q, mm, sizeof(double) * n_mm, hipMemcpyHostToDevice, c->stream)); dmm = q; q += n_mm; }
+        if (st_tm) { HIPCHK(c, hipMemcpyAsync(q, tm, sizeof(double) * n_tm, hipMemcpyHostToDevice, c->stream)); dtm = q; }
+    }
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    for (int n = 0; n < ncp; n++)        // mm(nx_block, ny_block, 0:ncat, max_blocks), tm(nx_block, ny_block, ntrace, ncat, max_blocks)
+        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dmm + (size_t)n * nblk), (size_t)ncp * nblk, tab[n]);
+    for (int q = 0; q < ntp; q++)
+        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dtm + (size_t)q * nblk), (size_t)ntp * nblk, tab[o_tm + q]);
+    HIPCHK(c, hipGetLastError());
+    double **dl = c->rm_tab + nplanes;
+    if (planes_halo(c, dl, c->rm_sgn, (int)nA, false)) return 1;
+    const double *dxu = c->rm_grid, *dyu = c->rm_grid + np, *hm = c->rm_grid + 2 * np;
+    const dim3 g2 = grid2d(s, B2D);
+    hipLaunchKernelGGL(k_remap_construct, dim3(g2.x, g2.y, ncp), B2D, 0, c->stream, s, tb, P, hm);
+    if (planes_halo(c, dl + nA, c->rm_sgn + nA, (int)nBs, false)) return 1;
+    if (planes_halo(c, dl + nA + nBs, c->rm_sgn + nA + nBs, (int)nBv, true)) return 1;
+    // departure points in the sig1 / sig2 planes (scratch between calls of evpk_principal_stress), NE-corner vectors (:564-570)
+    const int SB = c->cur ? F_STATE1 : F_STATE0;
+    hipLaunchKernelGGL(k_remap_dp, g2, B2D, 0, c->stream, s, SB, dt, dxu, dyu, tb.midpt, (int)F_SIG1, (int)F_SIG2, c->rm_bad);
+    if (halo(c, F_SIG1, 2, true, true, 0.0)) return 1;
+    hipLaunchKernelGGL(k_remap_flux<false>, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 3) / 4), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
+    hipLaunchKernelGGL(k_remap_flux<true>, dim3((s.nxl + 63) / 64, (s.nyl + 1 + 3) / 4), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
+    hipLaunchKernelGGL(k_remap_update, dim3((s.nxl + 63) / 64, (s.nyl + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, c->rm_bad);
+    HIPCHK(c, hipGetLastError());
+    unsigned bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, c->rm_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (xp_check(c)) return 1;
+    // (ranks decide alone, as the reference's l_stop is per task: the caller aborts the run, abort_ice)
+    if (bad & 1u) { c->err = "evpk_transport_remap: departure points out of bounds (ice_transport_remap.F90:1583-1607)"; return EVPK_REMAP_BAD_DEPARTURE; }
+    if (bad & 2u) { c->err = "evpk_transport_remap: negative area / mass after the update (ice_transport_remap.F90:3622-3640)"; return EVPK_REMAP_NEGATIVE_MASS; }
+    for (int n = 0; n < ncp; n++)
+        hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)tab[n], dmm + (size_t)n * nblk, (size_t)ncp * nblk);
+    for (int q = 0; q < ntp; q++)
+        hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)tab[o_tm + q], dtm + (size_t)q * nblk, (size_t)ntp * nblk);
+    HIPCHK(c, hipGetLastError());
+    if (st_mm) HIPCHK(c, hipMemcpyAsync(mm, dmm, sizeof(double) * n_mm, hipMemcpyDeviceToHost, c->stream));
+    if (st_tm) HIPCHK(c, hipMemcpyAsync(tm, dtm, sizeof(double) * n_tm, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {

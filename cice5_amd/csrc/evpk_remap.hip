@@ -1,0 +1,468 @@
+// evpk_remap.hip -- incremental remapping transport (source/ice_transport_remap.F90: horizontal_remap, :309-850) on the
+// velocities resident on the device.  SURVEY.md S8 row f-3.  Included by evpk_api.hip (one translation unit).
+//
+// Layout: every advected or derived field is a plain plane indexed like the mask planes (mcell), one per (field, category
+// [, tracer]); the planes of one call live in a pool addressed through a table of pointers in device memory.
+//   mm[n], n = 0..ncat            mean mass (area) per category, 0 = open water     (in / out)
+//   tm[n-1][nt]                   mean tracers                                        (in / out)
+//   mx, my[n]; tc, tx, ty[n-1][nt]   limited gradients / centre values (construct_fields), ghost ring by k_planes_halo
+//   fe, fn[n]; tfe, tfn[n-1][nt]  mass and mass*tracer transports across the east / north edges
+// mc (the mass at the cell centre) is mm where mm > puny and 0 elsewhere (:1190, xav = yav = 0), on ghost cells too -- it needs no
+// plane.  Kernels: k_remap_dp (departure_points) -> halo -> k_remap_construct (make_masks + construct_fields + limited_gradient,
+// one thread per cell and category) -> k_planes_halo -> k_remap_flux (locate_triangles + triangle_coordinates +
+// transport_integrals, one thread per edge, all categories and tracers from one set of triangles) -> k_remap_update.
+// Same operation order as the Fortran, -ffp-contract=off: bit-comparable with the CPU restatement.
+#pragma once
+
+namespace evpk {
+
+constexpr int RM_MAXT = 32;          // tracers per category
+constexpr int RM_GROUPS = 6, RM_VERT = 3;
+
+struct RemapTab {
+    int ncat, ntrace, order, midpt;
+    signed char type[RM_MAXT], dep[RM_MAXT], has[RM_MAXT];     // tracer_type, depend (1-based, 0 none), has_dependents
+};
+// pointer table: [0 .. ncat] mm, then mx, my, fe, fn (ncat+1 each); then per (n-1)*ntrace+nt: tm, tc, tx, ty, tfe, tfn
+struct RemapPlanes {
+    double *const *tab;
+    int ncp, ntp;
+    __device__ double *mm(int n) const { return tab[n]; }
+    __device__ double *mx(int n) const { return tab[ncp + n]; }
+    __device__ double *my(int n) const { return tab[2 * ncp + n]; }
+    __device__ double *fe(int n) const { return tab[3 * ncp + n]; }
+    __device__ double *fn(int n) const { return tab[4 * ncp + n]; }
+    __device__ double *tm(int p) const { return tab[5 * ncp + p]; }
+    __device__ double *tc(int p) const { return tab[5 * ncp + ntp + p]; }
+    __device__ double *tx(int p) const { return tab[5 * ncp + 2 * ntp + p]; }
+    __device__ double *ty(int p) const { return tab[5 * ncp + 3 * ntp + p]; }
+    __device__ double *tfe(int p) const { return tab[5 * ncp + 4 * ntp + p]; }
+    __device__ double *tfn(int p) const { return tab[5 * ncp + 5 * ntp + p]; }
+};
+
+#define RM_PUNY 1.0e-11
+#define RM_EPS16 1.0e-16
+
+// ---- departure_points (:1493-1670): dpx, dpy into two F planes (their halo is the NE-corner vector update of evp) ----
+__global__ void k_remap_dp(Slab s, int SB, double dt, const double *dxu, const double *dyu, int midpt, int fdx, int fdy, unsigned *bad) {
+    SLAB_IJ_ALL
+    double px = 0.0, py = 0.0;
+    if (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl) {
+        const double u = FD(s, SB + S_U, k), v = FD(s, SB + S_V, k);
+        px = -dt * u;
+        py = -dt * v;
+        if (px < -FD(s, F_HTN, k) || px > FD(s, F_HTN, cell(s, i + 1, j)) || py < -FD(s, F_HTE, k) || py > FD(s, F_HTE, cell(s, i, j + 1)))
+            atomicOr(bad, 1u);                                                        // :1583-1589
+        if (midpt && (u != 0.0 || v != 0.0)) {                                        // :1611-1667
+            px = px / dxu[km];
+            py = py / dyu[km];
+            const double mpx = 0.5 * px, mpy = 0.5 * py;
+            int i2, j2;
+            double mpxt, mpyt;
+            if (mpx >= 0.0 && mpy >= 0.0) { i2 = i + 1; j2 = j + 1; mpxt = mpx - 0.5; mpyt = mpy - 0.5; }
+            else if (mpx < 0.0 && mpy < 0.0) { i2 = i; j2 = j; mpxt = mpx + 0.5; mpyt = mpy + 0.5; }
+            else if (mpx >= 0.0 && mpy < 0.0) { i2 = i + 1; j2 = j; mpxt = mpx - 0.5; mpyt = mpy + 0.5; }
+            else { i2 = i; j2 = j + 1; mpxt = mpx + 0.5; mpyt = mpy - 0.5; }
+            const size_t kmm = cell(s, i2 - 1, j2 - 1), kpm = cell(s, i2, j2 - 1), kpp = cell(s, i2, j2), kmp = cell(s, i2 - 1, j2);
+            const double ump = FD(s, SB + S_U, kmm) * (mpxt - 0.5) * (mpyt - 0.5) - FD(s, SB + S_U, kpm) * (mpxt + 0.5) * (mpyt - 0.5)
+                             + FD(s, SB + S_U, kpp) * (mpxt + 0.5) * (mpyt + 0.5) - FD(s, SB + S_U, kmp) * (mpxt - 0.5) * (mpyt + 0.5);
+            const double vmp = FD(s, SB + S_V, kmm) * (mpxt - 0.5) * (mpyt - 0.5) - FD(s, SB + S_V, kpm) * (mpxt + 0.5) * (mpyt - 0.5)
+                             + FD(s, SB + S_V, kpp) * (mpxt + 0.5) * (mpyt + 0.5) - FD(s, SB + S_V, kmp) * (mpxt - 0.5) * (mpyt + 0.5);
+            px = -dt * ump;
+            py = -dt * vmp;
+        }
+    }
+    FD(s, fdx, k) = px;
+    FD(s, fdy, k) = py;
+}
+
+// ---- limited_gradient (:1344-1484) at one cell; MASK(ii,jj), PHI(ii,jj) functors ----
+template <typename FM, typename FP>
+__device__ __forceinline__ void rm_limited_gradient(int i, int j, FM mask, FP phi, double cx, double cy, double &gx, double &gy) {
+    const double ph = phi(i, j);
+    auto nb = [&](int ii, int jj) { const double m = mask(ii, jj); return m * phi(ii, jj) + (1.0 - m) * ph; };
+    const double phi_nw = nb(i - 1, j + 1), phi_n = nb(i, j + 1), phi_ne = nb(i + 1, j + 1);
+    const double phi_w = nb(i - 1, j), phi_e = nb(i + 1, j);
+    const double phi_sw = nb(i - 1, j - 1), phi_s = nb(i, j - 1), phi_se = nb(i + 1, j - 1);
+    const double gxtmp = (phi_e - phi_w) * 0.5, gytmp = (phi_n - phi_s) * 0.5;
+    double pmn = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(phi_nw, phi_n), phi_ne), phi_w), ph), phi_e), phi_sw), phi_s), phi_se);
+    double pmx = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(phi_nw, phi_n), phi_ne), phi_w), ph), phi_e), phi_sw), phi_s), phi_se);
+    pmn = pmn - ph;
+    pmx = pmx - ph;
+    double w1 = (0.5 - cx) * gxtmp + (0.5 - cy) * gytmp;
+    double w2 = (0.5 - cx) * gxtmp - (0.5 + cy) * gytmp;
+    const double w3 = -(0.5 + cx) * gxtmp - (0.5 + cy) * gytmp;
+    const double w4 = (0.5 - cy) * gytmp - (0.5 + cx) * gxtmp;
+    const double qmn = fmin(fmin(fmin(w1, w2), w3), w4), qmx = fmax(fmax(fmax(w1, w2), w3), w4);
+    if (fabs(qmn) > fabs(pmn)) w1 = fmax(0.0, pmn / qmn); else w1 = 1.0;           // :1459-1468
+    if (fabs(qmx) > fabs(pmx)) w2 = fmax(0.0, pmx / qmx); else w2 = 1.0;
+    w1 = fmin(w1, w2);
+    gx = w1 * gxtmp;
+    gy = w1 * gytmp;
+}
+
+// ---- make_masks (:867-1015) + construct_fields (:1024-1331): one thread per cell, blockIdx.z = category ----
+__global__ void k_remap_construct(Slab s, RemapTab t, RemapPlanes P, const double *hm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, n = blockIdx.z;
+    if (i > s.nxl + 1 || j > s.nyl + 1) return;
+    const size_t km = mcell(s, i, j);
+    const double xxav = 1.0 / 12.0, yyav = 1.0 / 12.0, xav = 0.0, yav = 0.0;          // init_remap, :249-289
+    const double *mm = P.mm(n);
+    const bool phys = (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl);
+    const bool ice = phys && mm[km] > RM_PUNY;                                        // the cell list of construct_fields
+    double mx = 0.0, my = 0.0;
+    if (phys && hm[km] > RM_PUNY)                                                     // limited_gradient(mm, hm, xav, yav)
+        rm_limited_gradient(i, j, [&](int ii, int jj) { return hm[mcell(s, ii, jj)]; }, [&](int ii, int jj) { return mm[mcell(s, ii, jj)]; },
+                            xav, yav, mx, my);
+    P.mx(n)[km] = mx;
+    P.my(n)[km] = my;
+    if (n == 0) return;
+    const double mc = ice ? mm[km] : 0.0;
+    double mxav = 0.0, myav = 0.0;
+    if (ice) {
+        mxav = (mx * xxav + mc * xav) / mm[km];                                       // :1212-1215
+        myav = (my * yyav + mc * yav) / mm[km];
+    }
+    double mtxav[RM_MAXT], mtyav[RM_MAXT];
+    for (int nt = 0; nt < t.ntrace; nt++) { mtxav[nt] = 0.0; mtyav[nt] = 0.0; }
+    auto mmask = [&](int ii, int jj) { return mm[mcell(s, ii, jj)] > RM_PUNY ? 1.0 : 0.0; };
+    for (int nt = 0; nt < t.ntrace; nt++) {
+        const int p = (n - 1) * t.ntrace + nt;
+        const double *tm = P.tm(p);
+        double tx = 0.0, ty = 0.0, tc = 0.0;
+        auto phi = [&](int ii, int jj) { return tm[mcell(s, ii, jj)]; };
+        if (t.type[nt] == 1) {                                                        // :1219-1273
+            if (phys && mm[km] > RM_PUNY) rm_limited_gradient(i, j, mmask, phi, mxav, myav, tx, ty);
+            if (ice) {
+                tc = tm[km] - tx * mxav - ty * myav;
+                if (t.has[nt] && fabs(tm[km]) > RM_PUNY) {                            // tmask (:971-981)
+                    const double w1 = mc * tc, w2 = mc * tx + mx * tc, w3 = mc * ty + my * tc;
+                    const double w7 = 1.0 / (mm[km] * tm[km]);
+                    mtxav[nt] = (w1 * xav + w2 * xxav) * w7;
+                    mtyav[nt] = (w1 * yav + w3 * yyav) * w7;
+                }
+            }
+        } else if (t.type[nt] == 2) {                                                 // :1275-1293
+            const int nt1 = t.dep[nt] - 1;
+            const double *tm1 = P.tm((n - 1) * t.ntrace + nt1);
+            auto tmask1 = [&](int ii, int jj) { const size_t q = mcell(s, ii, jj); return (t.has[nt1] && mm[q] > RM_PUNY && fabs(tm1[q]) > RM_PUNY) ? 1.0 : 0.0; };
+            if (phys && tmask1(i, j) > RM_PUNY) rm_limited_gradient(i, j, tmask1, phi, mtxav[nt1], mtyav[nt1], tx, ty);
+            if (ice) tc = tm[km] - tx * mtxav[nt1] - ty * mtyav[nt1];
+        } else if (t.type[nt] == 3) {                                                 // :1295-1303
+            if (ice) tc = tm[km];
+        }
+        P.tc(p)[km] = tc;
+        P.tx(p)[km] = tx;
+        P.ty(p)[km] = ty;
+    }
+}
+
+// ---- ghost ring of a list of plain planes, one rank: centre fields, scalar (sgn +1) or vector (-1) ----
+// blockIdx.y = plane.  N-S: south fill, north fill or the centre u-fold ghost(i, ny+1) = sgn * P(nx-i+1, ny); then E-W over all
+// rows (cyclic wrap or fill).  One launch does both: a thread owning a ghost-row cell of a ghost column computes it from the source.
+__global__ void k_planes_halo(Slab s, double *const *planes, const signed char *sgn, int cyclic, int tripole) {
+    double *P = planes[blockIdx.y];
+    const double sg = (double)sgn[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = s.nxl + 2, nrow = s.nyl + 2;
+    const int nx = s.nxl;                                      // one rank: nxl == nx_global
+    auto north = [&](int g) -> double {                         // value of the north ghost row at global column g (1..nx)
+        return tripole ? sg * P[mcell(s, nx - g + 1, s.nyl)] : 0.0;
+    };
+    if (t < ncol) {                                             // south and north ghost rows, all columns
+        const int i = t;
+        int g = i; if (g < 1) g += nx; if (g > nx) g -= nx;
+        const bool inside = (i >= 1 && i <= nx) || cyclic;
+        P[mcell(s, i, 0)] = 0.0;
+        P[mcell(s, i, s.nyl + 1)] = inside ? north(g) : 0.0;
+    } else if (t < ncol + nrow - 2) {                           // west and east ghost columns, physical rows
+        const int j = t - ncol + 1;
+        P[mcell(s, 0, j)] = cyclic ? P[mcell(s, nx, j)] : 0.0;
+        P[mcell(s, nx + 1, j)] = cyclic ? P[mcell(s, 1, j)] : 0.0;
+    }
+}
+
+// ---- locate_triangles (:1680-3047) + triangle_coordinates (:3078-3187) for one edge; l_fixed_area = .false. ----
+struct RmTri { double xp[RM_GROUPS][RM_VERT + 1], yp[RM_GROUPS][RM_VERT + 1], area[RM_GROUPS]; int di[RM_GROUPS], dj[RM_GROUPS]; };
+
+template <bool NORTH, typename FDP>
+__device__ __forceinline__ void rm_edge_triangles(int i, int j, FDP dxy /* (ii, jj, &dx, &dy): scaled departure point */,
+                                                  double areafac_l, double areafac_r, int order, RmTri &t) {
+    // source cells relative to the edge: TL, BL, TR, BR, TC, BC (:1823-1876)
+    const int tl0 = NORTH ? -1 : 1, tl1 = 1, bl0 = NORTH ? -1 : 0, bl1 = NORTH ? 0 : 1, tr0 = 1, tr1 = NORTH ? 1 : -1;
+    const int br0 = NORTH ? 1 : 0, br1 = NORTH ? 0 : -1, tc0 = NORTH ? 0 : 1, tc1 = NORTH ? 1 : 0, bc0 = 0, bc1 = 0;
+    const double areafac_c = 0.5 * (areafac_l + areafac_r);
+    double fact[RM_GROUPS];
+#pragma unroll
+    for (int g = 0; g < RM_GROUPS; g++) {
+        fact[g] = 0.0; t.area[g] = 0.0; t.di[g] = 0; t.dj[g] = 0;
+#pragma unroll
+        for (int v = 0; v <= RM_VERT; v++) { t.xp[g][v] = 0.0; t.yp[g][v] = 0.0; }
+    }
+#define RM_TRI(NG, X1, Y1, X2, Y2, X3, Y3, S0, S1, FAC) do { t.xp[NG - 1][1] = X1; t.yp[NG - 1][1] = Y1; t.xp[NG - 1][2] = X2; t.yp[NG - 1][2] = Y2; \
+        t.xp[NG - 1][3] = X3; t.yp[NG - 1][3] = Y3; t.di[NG - 1] = S0; t.dj[NG - 1] = S1; fact[NG - 1] = FAC; } while (0)
+    const double xcl = -0.5, ycl = 0.0, xcr = 0.5, ycr = 0.0;
+    double xdl, ydl, xdr, ydr, ax, ay, bx, by;
+    if (NORTH) { dxy(i - 1, j, ax, ay); dxy(i, j, bx, by); xdl = xcl + ax; ydl = ycl + ay; xdr = xcr + bx; ydr = ycr + by; }      // :1958-1963
+    else { dxy(i, j, ax, ay); dxy(i, j - 1, bx, by); xdl = xcl - ay; ydl = ycl + ax; xdr = xcr - by; ydr = ycr + bx; }           // :1965-1968
+    const double xdm = 0.5 * (xdr + xdl), ydm = 0.5 * (ydr + ydl);
+    const double xil = xcl, yil = (xcl * (ydm - ydl) + xdm * ydl - xdl * ydm) / (xdm - xdl);
+    const double xir = xcr, yir = (xcr * (ydr - ydm) - xdm * ydr + xdr * ydm) / (xdr - xdm);
+    const double md = (ydr - ydl) / (xdr - xdl);
+    const double xic = fabs(md) > RM_PUNY ? xdl - ydl / md : 0.0, yic = 0.0;
+    const double xicl = xic, yicl = yic, xicr = xic, yicr = yic;
+    // TL and BL triangles (:2013-2100)
+    if (yil > 0.0 && xdl < xcl && ydl >= 0.0) RM_TRI(1, xcl, ycl, xil, yil, xdl, ydl, tl0, tl1, -areafac_l);
+    else if (yil < 0.0 && xdl < xcl && ydl < 0.0) RM_TRI(1, xcl, ycl, xdl, ydl, xil, yil, bl0, bl1, areafac_l);
+    else if (yil < 0.0 && xdl < xcl && ydl >= 0.0) {
+        RM_TRI(1, xcl, ycl, xdl, ydl, xic, yic, tl0, tl1, areafac_l);
+        RM_TRI(3, xcl, ycl, xic, yic, xil, yil, bl0, bl1, areafac_l);
+    } else if (yil > 0.0 && xdl < xcl && ydl < 0.0) {
+        RM_TRI(3, xcl, ycl, xil, yil, xic, yic, tl0, tl1, -areafac_l);
+        RM_TRI(1, xcl, ycl, xic, yic, xdl, ydl, bl0, bl1, -areafac_l);
+    }
+    // TR and BR triangles (:2106-2196)
+    if (yir > 0.0 && xdr >= xcr && ydr >= 0.0) RM_TRI(2, xcr, ycr, xdr, ydr, xir, yir, tr0, tr1, -areafac_r);
+    else if (yir < 0.0 && xdr >= xcr && ydr < 0.0) RM_TRI(2, xcr, ycr, xir, yir, xdr, ydr, br0, br1, areafac_r);
+    else if (yir < 0.0 && xdr >= xcr && ydr >= 0.0) {
+        RM_TRI(2, xcr, ycr, xic, yic, xdr, ydr, tr0, tr1, areafac_r);
+        RM_TRI(3, xcr, ycr, xir, yir, xic, yic, br0, br1, areafac_r);
+    } else if (yir > 0.0 && xdr >= xcr && ydr < 0.0) {
+        RM_TRI(3, xcr, ycr, xic, yic, xir, yir, tr0, tr1, -areafac_r);
+        RM_TRI(2, xcr, ycr, xdr, ydr, xic, yic, br0, br1, -areafac_r);
+    }
+    if (xdl < xcl) { xdl = xil; ydl = yil; }                                          // :2202-2210
+    if (xdr > xcr) { xdr = xir; ydr = yir; }
+    // TC and BC triangles (:2378-2836)
+    if (ydl >= 0.0 && ydr >= 0.0 && ydm >= 0.0) {
+        RM_TRI(4, xcl, ycl, xcr, ycr, xdl, ydl, tc0, tc1, -areafac_c);
+        RM_TRI(5, xcr, ycr, xdr, ydr, xdl, ydl, tc0, tc1, -areafac_c);
+        RM_TRI(6, xdl, ydl, xdr, ydr, xdm, ydm, tc0, tc1, -areafac_c);
+    } else if (ydl >= 0.0 && ydr >= 0.0 && ydm < 0.0) {
+        RM_TRI(4, xcl, ycl, xicl, yicl, xdl, ydl, tc0, tc1, -areafac_c);
+        RM_TRI(5, xcr, ycr, xdr, ydr, xicr, yicr, tc0, tc1, -areafac_c);
+        RM_TRI(6, xicr, yicr, xicl, yicl, xdm, ydm, bc0, bc1, areafac_c);
+    } else if (ydl < 0.0 && ydr < 0.0 && ydm < 0.0) {
+        RM_TRI(4, xcl, ycl, xdl, ydl, xcr, ycr, bc0, bc1, areafac_c);
+        RM_TRI(5, xcr, ycr, xdl, ydl, xdr, ydr, bc0, bc1, areafac_c);
+        RM_TRI(6, xdl, ydl, xdm, ydm, xdr, ydr, bc0, bc1, areafac_c);
+    } else if (ydl < 0.0 && ydr < 0.0 && ydm >= 0.0) {
+        RM_TRI(4, xcl, ycl, xdl, ydl, xicl, yicl, bc0, bc1, areafac_c);
+        RM_TRI(5, xcr, ycr, xicr, yicr, xdr, ydr, bc0, bc1, areafac_c);
+        RM_TRI(6, xicl, yicl, xicr, yicr, xdm, ydm, tc0, tc1, -areafac_c);
+    } else if (ydl >= 0.0 && ydr < 0.0 && xic >= 0.0 && ydm >= 0.0) {
+        RM_TRI(4, xcl, ycl, xicr, yicr, xdl, ydl, tc0, tc1, -areafac_c);
+        RM_TRI(5, xcr, ycr, xicr, yicr, xdr, ydr, bc0, bc1, areafac_r);
+        RM_TRI(6, xdl, ydl, xicr, yicr, xdm, ydm, tc0, tc1, -areafac_c);
+    } else if (ydl >= 0.0 && ydr < 0.0 && xic >= 0.0 && ydm < 0.0) {
+        RM_TRI(4, xcl, ycl, xicl, yicl, xdl, ydl, tc0, tc1, -areafac_c);
+        RM_TRI(5, xcr, ycr, xicr, yicr, xdr, ydr, bc0, bc1, areafac_r);
+        RM_TRI(6, xicr, yicr, xicl, yicl, xdm, ydm, bc0, bc1, areafac_c);
+    } else if (ydl >= 0.0 && ydr < 0.0 && xic < 0.0 && ydm < 0.0) {
+        RM_TRI(4, xcl, ycl, xicl, yicl, xdl, ydl, tc0, tc1, -areafac_l);
+        RM_TRI(5, xcr, ycr, xicl, yicl, xdr, ydr, bc0, bc1, areafac_c);
+        RM_TRI(6, xdr, ydr, xicl, yicl, xdm, ydm, bc0, bc1, areafac_c);
+    } else if (ydl >= 0.0 && ydr < 0.0 && xic < 0.0 && ydm >= 0.0) {
+        RM_TRI(4, xcl, ycl, xicl, yicl, xdl, ydl, tc0, tc1, -areafac_l);
+        RM_TRI(5, xcr, ycr, xicr, yicr, xdr, ydr, bc0, bc1, areafac_c);
+        RM_TRI(6, xicl, yicl, xicr, yicr, xdm, ydm, tc0, tc1, -areafac_c);
+    } else if (ydl < 0.0 && ydr >= 0.0 && xic < 0.0 && ydm >= 0.0) {
+        RM_TRI(4, xcl, ycl, xdl, ydl, xicl, yicl, bc0, bc1, areafac_l);
+        RM_TRI(5, xcr, ycr, xdr, ydr, xicl, yicl, tc0, tc1, -areafac_c);
+        RM_TRI(6, xicl, yicl, xdr, ydr, xdm, ydm, tc0, tc1, -areafac_c);
+    } else if (ydl < 0.0 && ydr >= 0.0 && xic < 0.0 && ydm < 0.0) {
+        RM_TRI(4, xcl, ycl, xdl, ydl, xicl, yicl, bc0, bc1, areafac_l);
+        RM_TRI(5, xcr, ycr, xdr, ydr, xicr, yicr, tc0, tc1, -areafac_c);
+        RM_TRI(6, xicr, yicr, xicl, yicl, xdm, ydm, bc0, bc1, areafac_c);
+    } else if (ydl < 0.0 && ydr >= 0.0 && xic >= 0.0 && ydm < 0.0) {
+        RM_TRI(4, xcl, ycl, xdl, ydl, xicr, yicr, bc0, bc1, areafac_c);
+        RM_TRI(5, xcr, ycr, xdr, ydr, xicr, yicr, tc0, tc1, -areafac_r);
+        RM_TRI(6, xicr, yicr, xdl, ydl, xdm, ydm, bc0, bc1, areafac_c);
+    } else if (ydl < 0.0 && ydr >= 0.0 && xic >= 0.0 && ydm >= 0.0) {
+        RM_TRI(4, xcl, ycl, xdl, ydl, xicl, yicl, bc0, bc1, areafac_c);
+        RM_TRI(5, xcr, ycr, xdr, ydr, xicr, yicr, tc0, tc1, -areafac_r);
+        RM_TRI(6, xicl, yicl, xicr, yicr, xdm, ydm, tc0, tc1, -areafac_c);
+    }
+#undef RM_TRI
+#pragma unroll
+    for (int g = 0; g < RM_GROUPS; g++) {
+        double a = 0.5 * ((t.xp[g][2] - t.xp[g][1]) * (t.yp[g][3] - t.yp[g][1]) - (t.yp[g][2] - t.yp[g][1]) * (t.xp[g][3] - t.xp[g][1])) * fact[g];
+        if (fabs(a) < RM_EPS16 * areafac_c) a = 0.0;                                   // :2890-2893
+        t.area[g] = a;
+        if (a == 0.0) continue;
+#pragma unroll
+        for (int v = 1; v <= RM_VERT; v++) {                                          // coordinates relative to the source cell (:2943-2975)
+            if (NORTH) {
+                t.xp[g][v] = t.xp[g][v] - 1.0 * t.di[g];
+                t.yp[g][v] = t.yp[g][v] + 0.5 - 1.0 * t.dj[g];
+            } else {
+                const double w1 = t.xp[g][v];
+                t.xp[g][v] = t.yp[g][v] + 0.5 - 1.0 * t.di[g];
+                t.yp[g][v] = -w1 - 1.0 * t.dj[g];
+            }
+        }
+        t.xp[g][0] = (1.0 / 3.0) * (t.xp[g][1] + t.xp[g][2] + t.xp[g][3]);            // triangle_coordinates (:3078-3187)
+        t.yp[g][0] = (1.0 / 3.0) * (t.yp[g][1] + t.yp[g][2] + t.yp[g][3]);
+        if (order == 2) {
+#pragma unroll
+            for (int v = 1; v <= RM_VERT; v++) { t.xp[g][v] = 0.5 * t.xp[g][v] + 0.5 * t.xp[g][0]; t.yp[g][v] = 0.5 * t.yp[g][v] + 0.5 * t.yp[g][0]; }
+        } else if (order != 1) {
+#pragma unroll
+            for (int v = 1; v <= RM_VERT; v++) { t.xp[g][v] = 0.4 * t.xp[g][v] + 0.6 * t.xp[g][0]; t.yp[g][v] = 0.4 * t.yp[g][v] + 0.6 * t.yp[g][0]; }
+        }
+    }
+}
+
+// ---- transport_integrals (:3199-3509): one thread per edge, every category and tracer from one set of triangles ----
+template <bool NORTH>
+__global__ void k_remap_flux(Slab s, RemapTab tb, RemapPlanes P, const double *dxu, const double *dyu, int fdx, int fdy) {
+    // east edges: i = 0 .. nxl, j = 1 .. nyl;  north edges: i = 1 .. nxl, j = 0 .. nyl   (:1823-1826, :1849-1852)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + (NORTH ? 1 : 0);
+    const int j = blockIdx.y * blockDim.y + threadIdx.y + (NORTH ? 0 : 1);
+    if (i > s.nxl || j > s.nyl) return;
+    const size_t km = mcell(s, i, j);
+    const size_t ka = cell(s, i, j), kb = NORTH ? cell(s, i - 1, j) : cell(s, i, j - 1);
+    const bool moving = FD(s, fdx, kb) != 0.0 || FD(s, fdy, kb) != 0.0 || FD(s, fdx, ka) != 0.0 || FD(s, fdy, ka) != 0.0;   // :1911-1929
+    RmTri t;
+    if (moving) {
+        auto dxy = [&](int ii, int jj, double &dx, double &dy) {
+            const size_t q = cell(s, ii, jj), qm = mcell(s, ii, jj);
+            dx = FD(s, fdx, q) / dxu[qm];                                             // :1932-1937
+            dy = FD(s, fdy, q) / dyu[qm];
+        };
+        const size_t kl = NORTH ? mcell(s, i - 1, j) : mcell(s, i, j), kr = NORTH ? mcell(s, i, j) : mcell(s, i, j - 1);
+        rm_edge_triangles<NORTH>(i, j, dxy, dxu[kl] * dyu[kl], dxu[kr] * dyu[kr], tb.order, t);
+    }
+    const double p5625m = -9.0 / 16.0, p52083 = 25.0 / 48.0, p333 = 1.0 / 3.0;
+    for (int n = 0; n <= tb.ncat; n++) {
+        double mflx = 0.0;
+        double mtflx[RM_MAXT], mtsum[RM_MAXT], mtxsum[RM_MAXT], mtysum[RM_MAXT];
+        for (int nt = 0; nt < tb.ntrace; nt++) mtflx[nt] = 0.0;
+        if (moving) {
+            const double *mm = P.mm(n), *mxp = P.mx(n), *myp = P.my(n);
+            for (int g = 0; g < RM_GROUPS; g++) {
+                if (t.area[g] == 0.0) continue;
+                const size_t k2 = mcell(s, i + t.di[g], j + t.dj[g]);
+                const double mc = mm[k2] > RM_PUNY ? mm[k2] : 0.0, mx = mxp[k2], my = myp[k2];
+                const double *xp = t.xp[g], *yp = t.yp[g];
+                double msum, mxsum, mxxsum, mxysum, mysum, myysum;
+                if (tb.order == 1) {
+                    const double m0 = mc + xp[0] * mx + yp[0] * my;
+                    msum = m0;
+                    mxsum = m0 * xp[0]; mxxsum = mxsum * xp[0]; mxysum = mxsum * yp[0];
+                    mysum = m0 * yp[0]; myysum = mysum * yp[0];
+                } else if (tb.order == 2) {
+                    const double m1 = p333 * (mc + xp[1] * mx + yp[1] * my), m2 = p333 * (mc + xp[2] * mx + yp[2] * my),
+                                 m3 = p333 * (mc + xp[3] * mx + yp[3] * my);
+                    msum = m1 + m2 + m3;
+                    double w1 = m1 * xp[1], w2 = m2 * xp[2], w3 = m3 * xp[3];
+                    mxsum = w1 + w2 + w3;
+                    mxxsum = w1 * xp[1] + w2 * xp[2] + w3 * xp[3];
+                    mxysum = w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+                    w1 = m1 * yp[1]; w2 = m2 * yp[2]; w3 = m3 * yp[3];
+                    mysum = w1 + w2 + w3;
+                    myysum = w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+                } else {
+                    const double m0 = p5625m * (mc + xp[0] * mx + yp[0] * my), m1 = p52083 * (mc + xp[1] * mx + yp[1] * my),
+                                 m2 = p52083 * (mc + xp[2] * mx + yp[2] * my), m3 = p52083 * (mc + xp[3] * mx + yp[3] * my);
+                    msum = m0 + m1 + m2 + m3;
+                    double w0 = m0 * xp[0], w1 = m1 * xp[1], w2 = m2 * xp[2], w3 = m3 * xp[3];
+                    mxsum = w0 + w1 + w2 + w3;
+                    mxxsum = w0 * xp[0] + w1 * xp[1] + w2 * xp[2] + w3 * xp[3];
+                    mxysum = w0 * yp[0] + w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+                    w0 = m0 * yp[0]; w1 = m1 * yp[1]; w2 = m2 * yp[2]; w3 = m3 * yp[3];
+                    mysum = w0 + w1 + w2 + w3;
+                    myysum = w0 * yp[0] + w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+                }
+                mflx = mflx + t.area[g] * msum;
+                if (n == 0) continue;
+                for (int nt = 0; nt < tb.ntrace; nt++) {
+                    const int p = (n - 1) * tb.ntrace + nt;
+                    const double tc = P.tc(p)[k2];
+                    if (tb.type[nt] == 1) {                                           // :3449-3468
+                        const double tx = P.tx(p)[k2], ty = P.ty(p)[k2];
+                        mtsum[nt] = msum * tc + mxsum * tx + mysum * ty;
+                        mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
+                        mtxsum[nt] = mxsum * tc + mxxsum * tx + mxysum * ty;
+                        mtysum[nt] = mysum * tc + mxysum * tx + myysum * ty;
+                    } else if (tb.type[nt] == 2) {                                    // :3470-3483
+                        const int nt1 = tb.dep[nt] - 1;
+                        const double tx = P.tx(p)[k2], ty = P.ty(p)[k2];
+                        mtsum[nt] = mtsum[nt1] * tc + mtxsum[nt1] * tx + mtysum[nt1] * ty;
+                        mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
+                    } else if (tb.type[nt] == 3) {                                    // :3485-3497
+                        const int nt1 = tb.dep[nt] - 1;
+                        mtsum[nt] = mtsum[nt1] * tc;
+                        mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
+                    }
+                }
+            }
+        }
+        (NORTH ? P.fn(n) : P.fe(n))[km] = mflx;
+        if (n >= 1)
+            for (int nt = 0; nt < tb.ntrace; nt++) {
+                const int p = (n - 1) * tb.ntrace + nt;
+                (NORTH ? P.tfn(p) : P.tfe(p))[km] = mtflx[nt];
+            }
+    }
+}
+
+// ---- update_fields (:3517-3729): one thread per physical cell, blockIdx.z = category ----
+__global__ void k_remap_update(Slab s, RemapTab tb, RemapPlanes P, unsigned *bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y * blockDim.y + threadIdx.y + 1, n = blockIdx.z;
+    if (i > s.nxl || j > s.nyl) return;
+    const size_t k = mcell(s, i, j), kw = mcell(s, i - 1, j), ks = mcell(s, i, j - 1);
+    const double tarear = FD(s, F_TAREAR, cell(s, i, j));
+    double *mmp = P.mm(n);
+    const double mold = mmp[k];
+    double told[RM_MAXT], tnew[RM_MAXT], mtold[RM_MAXT];
+    if (n >= 1)
+        for (int nt = 0; nt < tb.ntrace; nt++) {                                      // :3574-3598
+            told[nt] = P.tm((n - 1) * tb.ntrace + nt)[k];
+            if (tb.type[nt] == 1) mtold[nt] = mold * told[nt];
+            else if (tb.type[nt] == 2) mtold[nt] = mold * told[tb.dep[nt] - 1] * told[nt];
+            else { const int nt1 = tb.dep[nt] - 1, nt2 = tb.dep[nt1] - 1; mtold[nt] = mold * told[nt2] * told[nt1] * told[nt]; }
+        }
+    double w1 = P.fe(n)[k] - P.fe(n)[kw] + P.fn(n)[k] - P.fn(n)[ks];                  // :3605-3620
+    double mnew = mold - w1 * tarear;
+    if (mnew < -RM_PUNY) atomicOr(bad, 2u);
+    else if (mnew < 0.0) mnew = 0.0;
+    mmp[k] = mnew;
+    if (n == 0) return;
+    for (int nt = 0; nt < tb.ntrace; nt++) {
+        const int p = (n - 1) * tb.ntrace + nt;
+        double v = 0.0;                                                               // :3658-3662
+        if (mnew > 0.0) {
+            w1 = P.tfe(p)[k] - P.tfe(p)[kw] + P.tfn(p)[k] - P.tfn(p)[ks];
+            if (tb.type[nt] == 1) v = (mtold[nt] - w1 * tarear) / mnew;
+            else if (tb.type[nt] == 2) {
+                const int nt1 = tb.dep[nt] - 1;
+                if (fabs(tnew[nt1]) > 0.0) v = (mtold[nt] - w1 * tarear) / (mnew * tnew[nt1]);
+            } else {
+                const int nt1 = tb.dep[nt] - 1, nt2 = tb.dep[nt1] - 1;
+                if (fabs(tnew[nt1]) > 0.0 && fabs(tnew[nt2]) > 0.0) v = (mtold[nt] - w1 * tarear) / (mnew * tnew[nt2] * tnew[nt1]);
+            }
+        }
+        tnew[nt] = v;
+        P.tm(p)[k] = v;
+    }
+}
+
+// ---- frame (two outermost rows / columns) of a list of planes <-> consecutive planes of the pair-interleaved slab, where
+// the general halo update works (several ranks, forced exchange); back: the ghost ring only ----
+__global__ void k_planes_frame(Slab s, double *const *planes, int f0, int nf, int back) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = s.nxl + 2, nrow = s.nyl + 2;
+    int i, j;
+    if (t < 4 * ncol) { const int r = t / ncol; i = t % ncol; j = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? s.nyl : s.nyl + 1; }
+    else if (t < 4 * ncol + 4 * nrow) { const int u = t - 4 * ncol, q = u / nrow; j = u % nrow; i = q == 0 ? 0 : q == 1 ? 1 : q == 2 ? s.nxl : s.nxl + 1; }
+    else return;
+    if (back && !(i == 0 || i == s.nxl + 1 || j == 0 || j == s.nyl + 1)) return;
+    const size_t k = cell(s, i, j), km = mcell(s, i, j);
+    for (int q = 0; q < nf; q++) {
+        if (back) planes[q][km] = FD(s, f0 + q, k);
+        else FD(s, f0 + q, k) = planes[q][km];
+    }
+}
+
+}  // namespace evpk

@@ -82,7 +82,9 @@ EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "
            "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
            "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
            "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
-           "evpk_transport_upwind"]
+           "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap"]
+
+REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS = 11, 12        # include/evpk.h
 
 _lib = None
 
@@ -122,6 +124,9 @@ def lib():
         L.evpk_connect.argtypes = [ctxp, ct.c_void_p]
         L.evpk_device_check.argtypes = [ct.c_int32]
         L.evpk_transport_upwind.argtypes = [ctxp, ct.c_double, ct.c_int32, c_f64p]
+        L.evpk_remap_init.argtypes = [ctxp, c_f64p, c_f64p, c_f64p]
+        L.evpk_transport_remap.argtypes = [ctxp, ct.c_double, ct.c_int32, ct.c_int32, c_f64p, c_f64p, c_i32p, c_i32p, c_i32p,
+                                           ct.c_int32, ct.c_int32, ct.c_int32]
         L.evpk_restart_write.argtypes = [ctxp, ct.c_char_p, ct.c_int32, ct.c_int32]
         L.evpk_restart_read.argtypes = [ctxp, ct.c_char_p, ct.c_int64, ct.c_int32]
         for n in EXPORTS:
@@ -284,6 +289,27 @@ class Context:
         """evpk_transport_upwind: works is (nblocks, narr, ny_block, nx_block), advected in place"""
         assert works.ndim == 4
         self._chk(self._L.evpk_transport_upwind(self._ctx, float(dt), int(works.shape[1]), _p64(works)), "evpk_transport_upwind")
+
+    def remap_init(self, dxu: np.ndarray, dyu: np.ndarray, hm: np.ndarray):
+        """evpk_remap_init: the grid arrays of horizontal_remap beyond the geometry's (block arrays)"""
+        self._chk(self._L.evpk_remap_init(self._ctx, _p64(dxu), _p64(dyu), _p64(hm)), "evpk_remap_init")
+
+    def transport_remap(self, dt: float, mm: np.ndarray, tm: Optional[np.ndarray], tracer_type, depend, has_dependents,
+                        integral_order: int = 3, l_dp_midpt: bool = True, l_fixed_area: bool = False) -> int:
+        """evpk_transport_remap: mm (nblocks, ncat+1, ny_block, nx_block), tm (nblocks, ncat, ntrace, ny_block, nx_block) in
+        place.  Returns 0, REMAP_BAD_DEPARTURE or REMAP_NEGATIVE_MASS (the reference's two l_stop cases); raises otherwise."""
+        assert mm.ndim == 4 and mm.flags["C_CONTIGUOUS"]
+        ncat = mm.shape[1] - 1
+        ntrace = 0 if tm is None else int(tm.shape[2])
+        if ntrace:
+            assert tm.ndim == 5 and tm.shape[1] == ncat and tm.flags["C_CONTIGUOUS"]
+        tt, dp, hd = (np.ascontiguousarray(a, dtype=np.int32) for a in (tracer_type, depend, has_dependents))
+        rc = self._L.evpk_transport_remap(self._ctx, float(dt), ncat, ntrace, _p64(mm), _p64(tm) if ntrace else None,
+                                          _p32(tt) if ntrace else None, _p32(dp) if ntrace else None, _p32(hd) if ntrace else None,
+                                          int(integral_order), int(l_dp_midpt), int(l_fixed_area))
+        if rc not in (0, REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS):
+            self._chk(rc, "evpk_transport_remap")
+        return int(rc)
 
     def restart_write(self, path: str, append: bool = False, big_endian: bool = True):
         self._chk(self._L.evpk_restart_write(self._ctx, path.encode(), int(append), int(big_endian)), "evpk_restart_write")

@@ -207,6 +207,35 @@ int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
  * compute_tracers stay with the host's tracer bookkeeping.  Needs HTN and HTE in evpk_geom. */
 int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, double *works);
 
+/* SURVEY S8 row f-3, second step: horizontal_remap (source/ice_transport_remap.F90:309-850), the incremental remapping of
+ * transport_remap (ice_transport_driver.F90:258-626), on the velocities the last evp left on the device.
+ *
+ * evpk_remap_init (once, after evpk_create / evpk_connect): the grid arrays this path reads beyond evpk_geom's -- dxu, dyu
+ * (ice_grid.F90) and hm (the land mask as a real, ice_grid.F90) -- block arrays, ghost cells current.
+ *
+ * evpk_transport_remap replaces the call at ice_transport_driver.F90:513-517 with the same arguments minus uvel, vvel:
+ *   mm  real(8) (nx_block, ny_block, 0:ncat, max_blocks): mean mass (aim; category 0 = open water)      in / out
+ *   tm  real(8) (nx_block, ny_block, ntrace, ncat, max_blocks): mean tracers (trm); NULL if ntrace = 0   in / out
+ *   tracer_type, depend (1-based, 0 = none), has_dependents: (ntrace), as init_transport sets them (:117-187); a tracer
+ *   follows the one it depends on
+ *   integral_order 1..3, l_dp_midpt: the module parameters of ice_transport_remap.F90:252-262
+ *   l_fixed_area: must be 0 (.false., the reference's setting for the B grid, :489-492)
+ * Physical cells of mm and tm are advanced in place; ghost cells are read (they are refreshed on the device first, so they
+ * need not be current) and left alone -- the reference calls bound_state afterwards (:573).  Up to EVPK_REMAP_MAX_TRACERS
+ * tracers.  make_masks, construct_fields, limited_gradient, departure_points, locate_triangles, triangle_coordinates,
+ * transport_integrals and update_fields run on the GPU in the Fortran's operation order; state_to_tracers /
+ * tracers_to_state and the conservation / monotonicity diagnostics stay with the host's tracer bookkeeping.
+ * Returns 0, EVPK_REMAP_BAD_DEPARTURE (a departure point left the neighbouring cells, :1583-1607: the time step is too
+ * long), EVPK_REMAP_NEGATIVE_MASS (:3622-3640) -- mm, tm untouched in both cases, the reference aborts there -- or 1 with
+ * evpk_last_error.  Needs HTN and HTE in evpk_geom. */
+#define EVPK_REMAP_MAX_TRACERS 32
+#define EVPK_REMAP_BAD_DEPARTURE 11
+#define EVPK_REMAP_NEGATIVE_MASS 12
+int evpk_remap_init(evpk_ctx *c, const double *dxu, const double *dyu, const double *hm);
+int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, double *mm, double *tm, const int32_t *tracer_type,
+                         const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
+                         int32_t l_fixed_area);
+
 /* The dynamics records of the reference's binary restart (source/ice_restart_driver.F90:122-176 dumpfile, :295-412
  * restartfile; io_binary/ice_restart.F90:641-684): uvel, vvel, strocnxT, strocnyT, stressp_1,3,2,4, stressm_1,3,2,4,
  * stress12_1,3,2,4, iceumask as real 0/1 -- 17 Fortran sequential unformatted records of the (nx_global, ny_global)

@@ -297,49 +297,11 @@ def test_transport_upwind_conserves_and_preserves_constants():
                           works[:, :, ~phys[0]] if d.nblocks == 1 else works[~np.broadcast_to(phys[:, None], works.shape)])
 
 
-def _remap_case(nx, ny, bsx, bsy, ns="open", ncat=3, seed=4, dt=3600.0, trcr_depend=(0, 1, 2 + 1)):
-    """a state for horizontal_remap: areas aim(0:ncat) summing to 1 over ocean, hice / hsno (type 1), a surface tracer on
-    the area (depend 0), one on the ice volume (depend 1: type 2 on hice) and one on the first tracer (type 2 / 3), and a
-    smooth velocity field that vanishes on land; ghost cells current (halo updates of the oracle)"""
-    case, d, f = util.make_case(nx, ny, bsx, bsy, ns=ns, land="continents")
-    synth.add_remap_grid(case, d, f)
-    I, J = blocks.block_index_windows(d)
-    ttype, depend, has = orc.remap_tables(list(trcr_depend))
-    ntrace = len(ttype)
-    mm = np.zeros((d.nblocks, ncat + 1, d.ny_block, d.nx_block))
-    tm = np.zeros((d.nblocks, ncat, ntrace, d.ny_block, d.nx_block))
-    for b in range(d.nblocks):
-        Ig = ((I[b] - 1) % nx + 1)[None, :] + 0 * J[b][:, None]
-        Jg = J[b][:, None] + 0 * I[b][None, :]
-        x, y = 2 * np.pi * Ig / nx, np.pi * Jg / ny
-        ocean = f["tmask"][b] > 0
-        ice = ocean & (np.sin(3 * x + 0.5) * np.cos(2 * y) > -0.3)
-        tot = np.zeros_like(x)
-        for n in range(1, ncat + 1):
-            a = np.where(ice, 0.25 * (1 + 0.8 * np.sin(n * x + y)) / ncat * 2.0, 0.0)
-            a = np.where(np.sin(5 * x * n + 2 * y) > 0.7, 0.0, a)          # holes: categories without ice
-            mm[b, n] = a
-            tot += a
-            tm[b, n - 1, 0] = np.where(a > 0, n * (0.5 + 0.3 * np.cos(2 * x - y)), 0.0)        # hice
-            tm[b, n - 1, 1] = np.where(a > 0, 0.1 * (1 + 0.5 * np.sin(x + 3 * y)), 0.0)        # hsno
-            for k in range(2, ntrace):
-                tm[b, n - 1, k] = np.where(a > 0, -2.0 - k + np.sin(k * x) * np.cos(y + n), 0.0)
-        mm[b, 0] = np.where(ocean, 1.0 - tot, 0.0)
-        f["uvel"][b] = 0.3 * np.sin(2 * x) * np.cos(y) * f["umask"][b]
-        f["vvel"][b] = 0.2 * np.cos(3 * x + 1.0) * np.sin(2 * y) * f["umask"][b]
-    for arr in (mm.reshape(d.nblocks, -1, d.ny_block, d.nx_block), tm.reshape(d.nblocks, -1, d.ny_block, d.nx_block)):
-        for k in range(arr.shape[1]):
-            w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
-    for n in ("uvel", "vvel"):
-        orc.halo_r8(d, f[n], C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
-    return case, d, f, mm, tm, (ttype, depend, has)
-
-
 def test_remap_conserves_and_keeps_tracers_monotone():
     """horizontal_remap (ice_transport_remap.F90:309-850): area, area*tracer and area*tracer*tracer integrals are conserved
     (flux form; no flux through land or the closed N/S rows), no tracer leaves the range of its 3x3 neighbourhood
     (limited gradients), nothing moves without velocity, uniform tracers stay uniform."""
-    case, d, f, mm, tm, (ttype, depend, has) = _remap_case(48, 40, 48, 40)
+    case, d, f, mm, tm, (ttype, depend, has) = util.remap_case(48, 40, 48, 40)
     phys = util.cell_mask(d, "phys")[0]
     ta = f["tarea"][0]
     m0, t0 = mm.copy(), tm.copy()
@@ -403,7 +365,7 @@ def test_remap_decomposition_invariance(ns):
     orders 2 and 3 and both departure-point rules"""
     ref = None
     for bs in [(48, 40), (12, 10), (24, 20)]:
-        case, d, f, mm, tm, (ttype, depend, has) = _remap_case(48, 40, *bs, ns=ns)
+        case, d, f, mm, tm, (ttype, depend, has) = util.remap_case(48, 40, *bs, ns=ns)
         out = []
         for order, midpt in ((3, True), (2, False), (1, True)):
             m, t = mm.copy(), tm.copy()

@@ -792,6 +792,126 @@ def test_transport_upwind_on_the_resident_velocities(ns, bs):
     assert np.array_equal(wg, wo)                                       # physical cells advected alike, ghost cells untouched by both
 
 
+def _remap_on_device(d, f, mm, tm, tables, dt, order, midpt, env=None, monkeypatch=None):
+    """horizontal_remap through the C ABI on synthetic velocities uploaded as the resident state"""
+    ttype, depend, has = tables
+    if env:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+    s = dyn.EvpDynamics(d, f, ndte=10, xmin=1.0e4)
+    s.set_evp_parameters(3600.0)
+    s.ctx.upload(f)                                                      # uvel, vvel resident, as after an evp
+    s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+    rc = s.ctx.transport_remap(dt, mm, tm, ttype, depend, has, integral_order=order, l_dp_midpt=midpt)
+    s.close()
+    return rc
+
+
+@pytest.mark.parametrize("ns,bs,order,midpt", [("open", (48, 40), 3, True), ("open", (12, 10), 2, False), ("open", (24, 20), 1, True),
+                                              ("tripole", (48, 40), 3, True), ("tripole", (12, 10), 3, False),
+                                              ("tripole", (24, 20), 2, True), ("tripole", (16, 8), 1, False)])
+def test_transport_remap_matches_the_oracle(ns, bs, order, midpt):
+    """SURVEY S8 row f-3, second step: horizontal_remap (ice_transport_remap.F90:309-850) -- masks, limited gradients,
+    departure points (both rules), the triangles of every edge and their integrals (all three quadrature orders), the
+    flux-form update of areas and of tracers of all three types -- against the oracle's restatement, bit for bit, open and
+    tripole grids, one and many blocks."""
+    case, d, f, mm, tm, tables = util.remap_case(48, 40, *bs, ns=ns, trcr_depend=(0, 1, 2 + 1, 2 + 2))     # types 1, 1, 1, 2, 2, 3
+    assert list(tables[0]) == [1, 1, 1, 2, 2, 3]
+    mo, to, mg, tg = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    assert orc.horizontal_remap(d, 3600.0, f, mo, to, *tables, integral_order=order, l_dp_midpt=midpt) == 0
+    assert _remap_on_device(d, f, mg, tg, tables, 3600.0, order, midpt) == 0
+    assert np.abs(mo - mm).max() > 1e-3 and np.abs(to - tm).max() > 1e-3
+    assert np.array_equal(mg, mo)            # physical cells advanced alike, ghost cells left alone by both
+    assert np.array_equal(tg, to)
+
+
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_transport_remap_through_the_general_halo_path(ns, monkeypatch):
+    """the ghost-cell updates of mm, tm, mx, my, tc, tx, ty through the pack / exchange / unpack path several ranks take
+    (EVPK_FORCE_EXCHANGE=1), fourteen planes at a time through the scratch state planes; and ghost cells of the caller's
+    arrays that are not current do not matter (the device refreshes them first)"""
+    case, d, f, mm, tm, tables = util.remap_case(48, 40, 24, 20, ns=ns, ncat=5)
+    mo, to, mg, tg = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    assert orc.horizontal_remap(d, 3600.0, f, mo, to, *tables) == 0
+    if d.nblocks == 1:
+        ghost = ~util.cell_mask(d, "phys")[0]
+        mg[0][:, ghost] = 7.0; tg[0][:, :, ghost] = -3.0
+    assert _remap_on_device(d, f, mg, tg, tables, 3600.0, 3, True, {"EVPK_FORCE_EXCHANGE": "1"}, monkeypatch) == 0
+    if d.nblocks == 1:
+        mg[0][:, ghost] = mm[0][:, ghost]; tg[0][:, :, ghost] = tm[0][:, :, ghost]
+    assert np.array_equal(mg, mo) and np.array_equal(tg, to)
+
+
+def test_transport_remap_stale_ghost_cells_and_no_tracers():
+    case, d, f, mm, tm, tables = util.remap_case(48, 40, 48, 40, ns="tripole")
+    ghost = ~util.cell_mask(d, "phys")[0]
+    mo, to, mg, tg = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    assert orc.horizontal_remap(d, 3600.0, f, mo, to, *tables) == 0
+    mg[0][:, ghost] = 7.0; tg[0][:, :, ghost] = -3.0
+    assert _remap_on_device(d, f, mg, tg, tables, 3600.0, 3, True) == 0
+    assert np.array_equal(mg[0][:, ~ghost], mo[0][:, ~ghost]) and np.array_equal(tg[0][:, :, ~ghost], to[0][:, :, ~ghost])
+    assert (mg[0][:, ghost] == 7.0).all() and (tg[0][:, :, ghost] == -3.0).all()
+    # areas alone (ntrace = 0)
+    m1 = mm.copy()
+    assert _remap_on_device(d, f, m1, None, ([], [], []), 3600.0, 3, True) == 0
+    assert np.array_equal(m1, mo)
+
+
+def test_transport_remap_reports_the_two_abort_cases():
+    """departure points outside the neighbouring cells (:1583-1607) and a negative area after the update (:3622-3640):
+    the reference aborts; the library returns the case and leaves the arrays alone"""
+    case, d, f, mm, tm, tables = util.remap_case(48, 40, 24, 20)
+    mo, to, mg, tg = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    dt = 3600.0 * 400
+    assert orc.horizontal_remap(d, dt, f, mo, to, *tables) == 1
+    assert _remap_on_device(d, f, mg, tg, tables, dt, 3, True) == evpk.REMAP_BAD_DEPARTURE
+    assert np.array_equal(mg, mm) and np.array_equal(tg, tm)
+    with pytest.raises(evpk.EvpkError):
+        _remap_on_device(d, f, mg, tg, tables, 3600.0, 4, True)
+    with pytest.raises(evpk.EvpkError):
+        _remap_on_device(d, f, mg, tg, (tables[0], [0] * len(tables[0]), tables[2]), 3600.0, 3, True)
+
+
+def test_transport_remap_after_an_evp():
+    """the production order: evp leaves uvel, vvel on the device, transport_remap advects the ice state with them
+    (ice_step_mod.F90:step_dynamics); BASELINE config 1's shape in 25 x 29 blocks, five categories"""
+    case, d, f = util.make_case(100, 116, 25, 29, ns="open", land="continents")
+    synth.add_thickness_distribution(f)
+    synth.add_remap_grid(case, d, f)
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    orc.evp(d, orc.make_params(3600.0, 30, xmin), fo)
+    s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    assert not util.compare(d, fg, fo, names=["uvel", "vvel"])
+    ncat = f["aicen"].shape[1]
+    tables = orc.remap_tables([0, 1, 2, 2 + 1, 2 + 2])                   # hice, hsno; Tsfc (area), qice (hice), qsno (hsno), one on Tsfc, one on qice (type 3)
+    ntrace = len(tables[0])
+    mm = np.zeros((d.nblocks, ncat + 1) + f["aice0"].shape[1:])
+    tm = np.zeros((d.nblocks, ncat, ntrace) + f["aice0"].shape[1:])
+    mm[:, 0] = f["aice0"]
+    for n in range(ncat):
+        a, v = f["aicen"][:, n], f["vicen"][:, n]
+        mm[:, n + 1] = a
+        h = np.where(a > 1e-11, v / np.where(a > 1e-11, a, 1.0), 0.0)
+        tm[:, n, 0], tm[:, n, 1] = h, 0.2 * h
+        for k in range(2, ntrace):
+            tm[:, n, k] = np.where(a > 1e-11, (-5.0 - n) * 10.0 ** (k - 2) * (1.0 + 0.2 * np.sin(0.1 * k * np.arange(a.shape[-1]))), 0.0)
+    for arr in (mm.reshape(d.nblocks, -1, *mm.shape[2:]), tm.reshape(d.nblocks, -1, *mm.shape[2:])):
+        for k in range(arr.shape[1]):
+            w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
+    umax = max(np.abs(fo["uvel"]).max(), np.abs(fo["vvel"]).max())
+    dt = 0.4 * xmin / umax                                                # departure points up to 0.4 cells away
+    mo, to, mg, tg = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+    assert orc.horizontal_remap(d, dt, fo, mo, to, *tables) == 0
+    assert s.ctx.transport_remap(dt, mg, tg, *tables) == 0
+    s.close()
+    assert np.abs(mo - mm).max() > 1e-3
+    assert np.array_equal(mg, mo) and np.array_equal(tg, to)
+
+
 def test_caller_arrays_in_device_memory():
     """A host model whose fields already live on the GPU passes device pointers in place of host arrays (same block
     layout): the library reads and writes them in place.  Here the arrays are torch tensors on the device."""

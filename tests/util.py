@@ -56,3 +56,42 @@ def compare(d, got: Dict[str, np.ndarray], ref: Dict[str, np.ndarray], names: Op
                 diff = np.abs(a[neq].astype(np.float64) - b[neq].astype(np.float64))
                 bad.append((n, int(neq.sum()), float(np.nanmax(diff))))
     return bad
+
+
+def remap_case(nx, ny, bsx, bsy, ns="open", ncat=3, seed=4, dt=3600.0, trcr_depend=(0, 1, 2 + 1)):
+    """a state for horizontal_remap: areas aim(0:ncat) summing to 1 over ocean, hice / hsno (type 1), a surface tracer on
+    the area (depend 0), one on the ice volume (depend 1: type 2 on hice) and one on the first tracer (type 2 / 3), and a
+    smooth velocity field that vanishes on land; ghost cells current (halo updates of the oracle)"""
+    from oracle import orc
+    case, d, f = make_case(nx, ny, bsx, bsy, ns=ns, land="continents")
+    synth.add_remap_grid(case, d, f)
+    I, J = blocks.block_index_windows(d)
+    ttype, depend, has = orc.remap_tables(list(trcr_depend))
+    ntrace = len(ttype)
+    mm = np.zeros((d.nblocks, ncat + 1, d.ny_block, d.nx_block))
+    tm = np.zeros((d.nblocks, ncat, ntrace, d.ny_block, d.nx_block))
+    for b in range(d.nblocks):
+        Ig = ((I[b] - 1) % nx + 1)[None, :] + 0 * J[b][:, None]
+        Jg = J[b][:, None] + 0 * I[b][None, :]
+        x, y = 2 * np.pi * Ig / nx, np.pi * Jg / ny
+        ocean = f["tmask"][b] > 0
+        ice = ocean & (np.sin(3 * x + 0.5) * np.cos(2 * y) > -0.3)
+        tot = np.zeros_like(x)
+        for n in range(1, ncat + 1):
+            a = np.where(ice, 0.25 * (1 + 0.8 * np.sin(n * x + y)) / ncat * 2.0, 0.0)
+            a = np.where(np.sin(5 * x * n + 2 * y) > 0.7, 0.0, a)          # holes: categories without ice
+            mm[b, n] = a
+            tot += a
+            tm[b, n - 1, 0] = np.where(a > 0, n * (0.5 + 0.3 * np.cos(2 * x - y)), 0.0)        # hice
+            tm[b, n - 1, 1] = np.where(a > 0, 0.1 * (1 + 0.5 * np.sin(x + 3 * y)), 0.0)        # hsno
+            for k in range(2, ntrace):
+                tm[b, n - 1, k] = np.where(a > 0, -2.0 - k + np.sin(k * x) * np.cos(y + n), 0.0)
+        mm[b, 0] = np.where(ocean, 1.0 - tot, 0.0)
+        f["uvel"][b] = 0.3 * np.sin(2 * x) * np.cos(y) * f["umask"][b]
+        f["vvel"][b] = 0.2 * np.cos(3 * x + 1.0) * np.sin(2 * y) * f["umask"][b]
+    for arr in (mm.reshape(d.nblocks, -1, d.ny_block, d.nx_block), tm.reshape(d.nblocks, -1, d.ny_block, d.nx_block)):
+        for k in range(arr.shape[1]):
+            w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
+    for n in ("uvel", "vvel"):
+        orc.halo_r8(d, f[n], C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+    return case, d, f, mm, tm, (ttype, depend, has)
