@@ -90,7 +90,10 @@
                 evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
                 evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
                 evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read, &
-                evpk_transport_upwind
+                evpk_transport_upwind, evpk_remap_init, evpk_transport_remap, &
+                EVPK_REMAP_BAD_DEPARTURE, EVPK_REMAP_NEGATIVE_MASS
+
+      integer (c_int), parameter :: EVPK_REMAP_BAD_DEPARTURE = 11, EVPK_REMAP_NEGATIVE_MASS = 12     ! include/evpk.h
 
       interface
          integer (c_int) function evpk_get_unique_id (id) bind(C, name='evpk_get_unique_id')
@@ -190,6 +193,21 @@
             real (c_double), value :: dt
             integer (c_int32_t), value :: narr
             type (c_ptr), value :: works
+         end function
+         ! horizontal_remap (ice_transport_remap.F90:309-850) on the resident velocities: dxu, dyu, hm once, then
+         ! mm(nx_block,ny_block,0:ncat,max_blocks), tm(nx_block,ny_block,ntrace,ncat,max_blocks) advanced in place
+         integer (c_int) function evpk_remap_init (ctx, dxu, dyu, hm) bind(C, name='evpk_remap_init')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ctx, dxu, dyu, hm
+         end function
+         integer (c_int) function evpk_transport_remap (ctx, dt, ncat, ntrace, mm, tm, tracer_type, depend, has_dependents, &
+                                                        integral_order, l_dp_midpt, l_fixed_area) bind(C, name='evpk_transport_remap')
+            import :: c_int, c_ptr, c_double, c_int32_t
+            type (c_ptr), value :: ctx
+            real (c_double), value :: dt
+            integer (c_int32_t), value :: ncat, ntrace
+            type (c_ptr), value :: mm, tm, tracer_type, depend, has_dependents
+            integer (c_int32_t), value :: integral_order, l_dp_midpt, l_fixed_area
          end function
          integer (c_int) function evpk_destroy (ctx) bind(C, name='evpk_destroy')
             import :: c_int, c_ptr

@@ -40,6 +40,7 @@
       public :: evpk_resident_state, evpk_state_changed_on_host, evpk_device_strength
       public :: evpk_bound_seconds, evpk_loop_seconds
       public :: evpk_download_all, evpk_sparse_io
+      public :: evpk_horizontal_remap
       save
 
       ! .true. (default): every array the reference's evp leaves modified comes back every call.  .false. (with
@@ -458,6 +459,64 @@
          end function tmask_l
 
       end subroutine evp
+
+!=======================================================================
+! horizontal_remap (reference: ice_transport_remap.F90:309-850) on the velocities the last evp left on the device: same
+! argument list, so that ice_transport_driver.F90:216
+!     use ice_transport_remap, only: horizontal_remap, make_masks
+! becomes
+!     use ice_transport_remap, only: make_masks
+!     use ice_dyn_evp, only: horizontal_remap => evpk_horizontal_remap
+! and the call at :475-481 stays as it is.  uvel, vvel are accepted for that reason only: the library advects with the
+! device copies (bit-identical to the host arrays after evp).  SURVEY.md S8 row f-3.
+
+      subroutine evpk_horizontal_remap (dt,                ntrace,     &
+                                        uvel,              vvel,       &
+                                        mm,                tm,         &
+                                        l_fixed_area,                  &
+                                        tracer_type,       depend,     &
+                                        has_dependents,                &
+                                        integral_order,                &
+                                        l_dp_midpt)
+
+      use ice_blocks, only: nx_block, ny_block
+      use ice_domain_size, only: ncat, max_blocks
+      use ice_grid, only: dxu, dyu, hm
+      use ice_exit, only: abort_ice
+
+      real (kind=dbl_kind), intent(in) :: dt
+      integer (kind=int_kind), intent(in) :: ntrace
+      real (kind=dbl_kind), intent(in), dimension(nx_block,ny_block,max_blocks) :: uvel, vvel
+      real (kind=dbl_kind), intent(inout), target, dimension (nx_block,ny_block,0:ncat,max_blocks) :: mm
+      real (kind=dbl_kind), intent(inout), target, dimension (nx_block,ny_block,ntrace,ncat,max_blocks) :: tm
+      logical, intent(in) :: l_fixed_area
+      integer (kind=int_kind), dimension (ntrace), intent(in) :: tracer_type, depend
+      logical (kind=log_kind), dimension (ntrace), intent(in) :: has_dependents
+      integer (kind=int_kind), intent(in) :: integral_order
+      logical (kind=log_kind), intent(in) :: l_dp_midpt
+
+      integer (c_int32_t), dimension (max(ntrace,1)), target :: ttype, dep, has
+      integer (c_int) :: rc
+      logical (kind=log_kind), save :: first = .true.
+
+      if (.not. c_associated(ctx)) call abort_ice('horizontal_remap: no velocities on the device: evp has not run yet')
+      if (first) then
+         rc = evpk_remap_init (ctx, loc_r8(dxu), loc_r8(dyu), loc_r8(hm))
+         if (rc /= 0) call abort_ice('horizontal_remap: evpk_remap_init: '//trim(evpk_error_string(ctx)))
+         first = .false.
+      endif
+      ttype(1:ntrace) = tracer_type(1:ntrace)
+      dep(1:ntrace) = depend(1:ntrace)
+      has(1:ntrace) = merge(1, 0, has_dependents(1:ntrace))
+      rc = evpk_transport_remap (ctx, dt, int(ncat, c_int32_t), int(ntrace, c_int32_t), loc_r8(mm), loc_r8(tm), &
+                                 c_loc(ttype), c_loc(dep), c_loc(has), int(integral_order, c_int32_t), &
+                                 merge(1_c_int32_t, 0_c_int32_t, l_dp_midpt), merge(1_c_int32_t, 0_c_int32_t, l_fixed_area))
+      ! the reference's two l_stop cases (:498-503 departure_points, :822-839 update_fields) and everything else
+      if (rc == EVPK_REMAP_BAD_DEPARTURE) call abort_ice('remap transport: bad departure points')
+      if (rc == EVPK_REMAP_NEGATIVE_MASS) call abort_ice('remap transport: negative area')
+      if (rc /= 0) call abort_ice('horizontal_remap: evpk_transport_remap: '//trim(evpk_error_string(ctx)))
+
+      end subroutine evpk_horizontal_remap
 
 !=======================================================================
 

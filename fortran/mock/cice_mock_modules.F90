@@ -148,7 +148,8 @@
       use ice_kinds_mod
       implicit none
       real (kind=dbl_kind), dimension(:,:,:), allocatable :: &
-         dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, uarear, tinyarea, tarea, uarea, HTN, HTE
+         dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, uarear, tinyarea, tarea, uarea, HTN, HTE, &
+         dxu, dyu, hm
       logical (kind=log_kind), dimension(:,:,:), allocatable :: tmask, umask
       character (char_len) :: grid_type = 'rectangular'
       end module ice_grid

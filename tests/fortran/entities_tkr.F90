@@ -34,7 +34,7 @@
           ss_tltx, ss_tlty, iceumask, fm, strtltx, strtlty, strocnx, strocny, strintx, strinty, strocnxT, strocnyT, &
           strax, stray, stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
           stress12_1, stress12_2, stress12_3, stress12_4
-      use ice_grid, only: tmask, umask, dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, uarear, tinyarea, tarea, uarea, HTN, HTE
+      use ice_grid, only: tmask, umask, dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, uarear, tinyarea, tarea, uarea, HTN, HTE, dxu, dyu, hm
       use ice_mechred, only: ice_strength, kstrength, krdg_partic, krdg_redist, mu_rdg, Cf
       use ice_state, only: aice, vice, vsno, uvel, vvel, divu, shear, aice_init, aice0, aicen, vicen, strength
       use ice_timers, only: timer_dynamics, timer_bound, ice_timer_start, ice_timer_stop
@@ -73,6 +73,7 @@
       call l_3 (tmask);  call l_3 (umask)
       call r8_3 (dxt);  call r8_3 (dyt);  call r8_3 (dxhy);  call r8_3 (dyhx);  call r8_3 (cxp);  call r8_3 (cyp);  call r8_3 (cxm);  call r8_3 (cym)
       call r8_3 (tarear);  call r8_3 (uarear);  call r8_3 (tinyarea);  call r8_3 (tarea);  call r8_3 (uarea);  call r8_3 (HTN);  call r8_3 (HTE)
+      call r8_3 (dxu);  call r8_3 (dyu);  call r8_3 (hm)
       call i4_0 (kstrength);  call i4_0 (krdg_partic);  call i4_0 (krdg_redist);  call r8_0 (mu_rdg);  call r8_0 (Cf)
       call r8_3 (aice);  call r8_3 (vice);  call r8_3 (vsno);  call r8_3 (uvel);  call r8_3 (vvel);  call r8_3 (divu);  call r8_3 (shear)
       call r8_3 (aice_init);  call r8_3 (aice0);  call r8_4 (aicen);  call r8_4 (vicen);  call r8_3 (strength)

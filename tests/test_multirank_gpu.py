@@ -102,6 +102,41 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
                 bad.append(("transport_upwind", int((wl != w1[loc]).sum())))
             if not np.abs(w1[loc] - np.stack(planes, axis=1)[loc]).max() > 0:
                 bad.append(("transport_upwind did nothing", 0))
+        if env.get("TEST_REMAP"):
+            # transport_remap (row f-3): the ghost-cell updates of its centre fields go through the exchange machinery in
+            # groups of planes (E-W ring, tripole fold with the mirror ranks), dpx / dpy as NE-corner vectors
+            synth.add_thickness_distribution(f1)
+            synth.add_remap_grid(case, d1, f1)
+            synth.add_remap_grid(case, d, f)
+            ncat = f1["aicen"].shape[1]
+            tables = orc.remap_tables([0, 1, 2 + 1, 2 + 2])
+            ntrace = len(tables[0])
+            m1 = np.zeros((d1.nblocks, ncat + 1) + f1["aice0"].shape[1:])
+            t1 = np.zeros((d1.nblocks, ncat, ntrace) + f1["aice0"].shape[1:])
+            m1[:, 0] = f1["aice0"]
+            for n in range(ncat):
+                a, v = f1["aicen"][:, n], f1["vicen"][:, n]
+                m1[:, n + 1] = a
+                h = np.where(a > 1e-11, v / np.where(a > 1e-11, a, 1.0), 0.0)
+                t1[:, n, 0], t1[:, n, 1] = h, 0.2 * h
+                for k in range(2, ntrace):
+                    t1[:, n, k] = np.where(a > 1e-11, -3.0 - n - 0.5 * k + 0.1 * h, 0.0)
+            for arr in (m1.reshape(d1.nblocks, -1, *m1.shape[2:]), t1.reshape(d1.nblocks, -1, *m1.shape[2:])):
+                for k in range(arr.shape[1]):
+                    w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d1, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
+            loc = [next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id) for b in d.local_blocks]
+            ml, tl = np.ascontiguousarray(m1[loc]), np.ascontiguousarray(t1[loc])
+            m0 = m1.copy()
+            dtr = 0.4 * xmin / max(np.abs(f1["uvel"]).max(), np.abs(f1["vvel"]).max())
+            s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+            rc1 = orc.horizontal_remap(d1, dtr, f1, m1, t1, *tables)
+            rc = s.ctx.transport_remap(dtr, ml, tl, *tables)
+            if rc1 or rc:
+                bad.append(("transport_remap rc", rc1 * 100 + rc))
+            if not (np.array_equal(ml, m1[loc]) and np.array_equal(tl, t1[loc])):
+                bad.append(("transport_remap", int((ml != m1[loc]).sum() + (tl != t1[loc]).sum())))
+            if not np.abs(m1 - m0).max() > 1e-4:
+                bad.append(("transport_remap did nothing", 0))
         st = s.ctx.stats()
         s.close()
         if int(st.transport) != {"shm": 2, "ipc": 3}[xp]:
@@ -202,6 +237,11 @@ def test_x_slabs_tripole(xp):
 @pytest.mark.parametrize("ns,world", [("open", 3), ("tripole", 2), ("tripole", 4)])
 def test_transport_upwind_across_slabs(ns, world):
     _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_UPWIND": "1"}, xp="ipc")
+
+
+@pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 2, "ipc"), ("tripole", 4, "shm"), ("tripole", 3, "ipc")])
+def test_transport_remap_across_slabs(ns, world, xp):
+    _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_REMAP": "1"}, xp=xp)
 
 
 def test_x_slabs_one_subcycle_kernel_and_serial_exchange():

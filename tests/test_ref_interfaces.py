@@ -47,3 +47,24 @@ def test_mock_modules_declare_every_imported_entity_as_the_reference_does(tmp_pa
         r = subprocess.run([R.FC, "-cpp", "-fsyntax-only", "-DAusCOM"] + extra + ["-module-dir", str(mock), "-I", str(mock), f],
                            capture_output=True, text=True)
         assert r.returncode == 0, f + "\n" + r.stderr[-3000:]
+
+
+def test_transport_driver_compiles_against_the_shims_horizontal_remap(tmp_path):
+    """source/ice_transport_driver.F90 with ONE line changed -- :216 `use ice_transport_remap, only: horizontal_remap,
+    make_masks` -> make_masks from there, horizontal_remap => evpk_horizontal_remap from our ice_dyn_evp -- compiles: the call
+    at :475-481 (aim, trm, tracer_type, depend, has_dependents, integral_order, l_dp_midpt as the driver declares them)
+    matches the shim's argument list.  The edited text exists in the scratch directory only."""
+    rc = R.RefCompile(str(tmp_path), [])
+    rc.need("ice_dyn_evp", include_top=False)
+    rc.compile(os.path.join(ROOT, "fortran", "evpk_mod.F90"), True)
+    rc.compile(os.path.join(ROOT, "fortran", "ice_dyn_evp.F90"), True)
+    rc.need("ice_transport_driver", include_top=False, skip={"ice_dyn_evp"})
+    src = open(os.path.join(R.REF, "source", "ice_transport_driver.F90")).read()
+    old = "      use ice_transport_remap, only: horizontal_remap, make_masks\n"
+    assert src.count(old) == 1
+    edited = tmp_path / "ice_transport_driver_edited.F90"
+    edited.write_text(src.replace(old, "      use ice_transport_remap, only: make_masks\n"
+                                       "      use ice_dyn_evp, only: horizontal_remap => evpk_horizontal_remap\n"))
+    rc.compile(str(edited), True)
+    assert os.path.exists(os.path.join(rc.mods, "ice_transport_driver.mod"))
+
