@@ -2095,10 +2095,30 @@ extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_
     tb.ncat = ncat; tb.ntrace = ntrace; tb.order = integral_order; tb.midpt = l_dp_midpt ? 1 : 0;
     for (int nt = 0; nt < ntrace; nt++) {
         if (tracer_type[nt] < 1 || tracer_type[nt] > 3) FAIL(c, "evpk_transport_remap: tracer_type(%d) = %d", nt + 1, tracer_type[nt]);
-        // a dependent tracer follows the one it depends on (ice_transport_driver.F90:init_transport orders them so); type 3 hangs on a type 2
-        if (tracer_type[nt] > 1 && (depend[nt] < 1 || depend[nt] > nt)) FAIL(c, "evpk_transport_remap: depend(%d) = %d", nt + 1, depend[nt]);
-        if (tracer_type[nt] == 3 && (tracer_type[depend[nt] - 1] != 2)) FAIL(c, "evpk_transport_remap: tracer %d (type 3) must depend on a type 2 tracer", nt + 1);
+        // a dependent tracer follows the one it depends on (init_transport orders them so, ice_transport_driver.F90:88-125); type 2
+        // hangs on a type 1 (hice, hsno or an area tracer), type 3 on a type 2
+        if (tracer_type[nt] > 1) {
+            if (depend[nt] < 1 || depend[nt] > nt) FAIL(c, "evpk_transport_remap: depend(%d) = %d", nt + 1, depend[nt]);
+            const int par = depend[nt] - 1;
+            if (tracer_type[par] != tracer_type[nt] - 1)
+                FAIL(c, "evpk_transport_remap: tracer %d (type %d) must depend on a type %d tracer", nt + 1, tracer_type[nt], tracer_type[nt] - 1);
+            if (tracer_type[nt] == 2 && !has_dependents[par]) FAIL(c, "evpk_transport_remap: has_dependents(%d) is false but tracer %d depends on it", par + 1, nt + 1);
+        }
         tb.type[nt] = (signed char)tracer_type[nt]; tb.dep[nt] = (signed char)depend[nt]; tb.has[nt] = has_dependents[nt] ? 1 : 0;
+    }
+    {   // depth-first order of the dependency forest (RemapTab::ord)
+        int m = 0;
+        for (int a = 0; a < ntrace; a++) {
+            if (tracer_type[a] != 1) continue;
+            tb.ord[m++] = (signed char)a;
+            for (int b2 = a + 1; b2 < ntrace; b2++) {
+                if (tracer_type[b2] != 2 || depend[b2] - 1 != a) continue;
+                tb.ord[m++] = (signed char)b2;
+                for (int b3 = b2 + 1; b3 < ntrace; b3++)
+                    if (tracer_type[b3] == 3 && depend[b3] - 1 == b2) tb.ord[m++] = (signed char)b3;
+            }
+        }
+        if (m != ntrace) FAIL(c, "evpk_transport_remap: the tracer dependencies do not form a forest (%d of %d reached)", m, ntrace);
     }
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2159,11 +2179,15 @@ extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_
         if (st_mm) { HIPCHK(c, hipMemcpyAsync(q, mm, sizeof(double) * n_mm, hipMemcpyHostToDevice, c->stream)); dmm = q; q += n_mm; }
         if (st_tm) { HIPCHK(c, hipMemcpyAsync(q, tm, sizeof(double) * n_tm, hipMemcpyHostToDevice, c->stream)); dtm = q; }
     }
-    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    for (int n = 0; n < ncp; n++)        // mm(nx_block, ny_block, 0:ncat, max_blocks), tm(nx_block, ny_block, ntrace, ncat, max_blocks)
-        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dmm + (size_t)n * nblk), (size_t)ncp * nblk, tab[n]);
-    for (int q = 0; q < ntp; q++)
-        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dtm + (size_t)q * nblk), (size_t)ntp * nblk, tab[o_tm + q]);
+    // mm(nx_block, ny_block, 0:ncat, max_blocks), tm(nx_block, ny_block, ntrace, ncat, max_blocks) -> planes, one launch per array
+    const dim3 b(64, 4);
+    const int nrg = (c->nyb + 3) / 4;
+    if ((long long)nrg * c->nblocks > 65535 || ntp > 65535) FAIL(c, "evpk_transport_remap: too many blocks for one launch");
+    hipLaunchKernelGGL(k_gather_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dmm,
+                       nblk, (size_t)ncp * nblk, (double *const *)c->rm_tab, nrg);
+    if (ntp)
+        hipLaunchKernelGGL(k_gather_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ntp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dtm,
+                           nblk, (size_t)ntp * nblk, (double *const *)(c->rm_tab + o_tm), nrg);
     HIPCHK(c, hipGetLastError());
     double **dl = c->rm_tab + nplanes;
     if (planes_halo(c, dl, c->rm_sgn, (int)nA, false)) return 1;
@@ -2176,8 +2200,8 @@ extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_
     const int SB = c->cur ? F_STATE1 : F_STATE0;
     hipLaunchKernelGGL(k_remap_dp, g2, B2D, 0, c->stream, s, SB, dt, dxu, dyu, tb.midpt, (int)F_SIG1, (int)F_SIG2, c->rm_bad);
     if (halo(c, F_SIG1, 2, true, true, 0.0)) return 1;
-    hipLaunchKernelGGL(k_remap_flux<false>, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 3) / 4), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
-    hipLaunchKernelGGL(k_remap_flux<true>, dim3((s.nxl + 63) / 64, (s.nyl + 1 + 3) / 4), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
+    hipLaunchKernelGGL(k_remap_flux<false>, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
+    hipLaunchKernelGGL(k_remap_flux<true>, dim3((s.nxl + 63) / 64, (s.nyl + 1 + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
     hipLaunchKernelGGL(k_remap_update, dim3((s.nxl + 63) / 64, (s.nyl + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, c->rm_bad);
     HIPCHK(c, hipGetLastError());
     unsigned bad = 0;
@@ -2187,10 +2211,11 @@ extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_
     // (ranks decide alone, as the reference's l_stop is per task: the caller aborts the run, abort_ice)
     if (bad & 1u) { c->err = "evpk_transport_remap: departure points out of bounds (ice_transport_remap.F90:1583-1607)"; return EVPK_REMAP_BAD_DEPARTURE; }
     if (bad & 2u) { c->err = "evpk_transport_remap: negative area / mass after the update (ice_transport_remap.F90:3622-3640)"; return EVPK_REMAP_NEGATIVE_MASS; }
-    for (int n = 0; n < ncp; n++)
-        hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)tab[n], dmm + (size_t)n * nblk, (size_t)ncp * nblk);
-    for (int q = 0; q < ntp; q++)
-        hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)tab[o_tm + q], dtm + (size_t)q * nblk, (size_t)ntp * nblk);
+    hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
+                       (double *const *)c->rm_tab, dmm, nblk, (size_t)ncp * nblk, nrg);
+    if (ntp)
+        hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ntp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
+                           (double *const *)(c->rm_tab + o_tm), dtm, nblk, (size_t)ntp * nblk, nrg);
     HIPCHK(c, hipGetLastError());
     if (st_mm) HIPCHK(c, hipMemcpyAsync(mm, dmm, sizeof(double) * n_mm, hipMemcpyDeviceToHost, c->stream));
     if (st_tm) HIPCHK(c, hipMemcpyAsync(tm, dtm, sizeof(double) * n_tm, hipMemcpyDeviceToHost, c->stream));

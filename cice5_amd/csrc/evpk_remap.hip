@@ -18,10 +18,18 @@ namespace evpk {
 
 constexpr int RM_MAXT = 32;          // tracers per category
 constexpr int RM_GROUPS = 6, RM_VERT = 3;
+#ifndef RM_FLUX_WAVES
+#define RM_FLUX_WAVES 3          // waves per SIMD the flux kernels are compiled for (register budget 512 / waves)
+#endif
 
 struct RemapTab {
     int ncat, ntrace, order, midpt;
     signed char type[RM_MAXT], dep[RM_MAXT], has[RM_MAXT];     // tracer_type, depend (1-based, 0 none), has_dependents
+    // the tracers in depth-first order of the dependency forest: a type-1 tracer, then each tracer that hangs on it (type 2),
+    // each followed by its own dependents (type 3).  Tracers are independent of each other apart from what they read of their
+    // parents, so the order of processing is free; in THIS order the parent of a type-2 tracer is always the last type-1 tracer
+    // seen and that of a type-3 tracer the last type-2 one: their values are two scalars per thread instead of arrays.
+    signed char ord[RM_MAXT];
 };
 // pointer table: [0 .. ncat] mm, then mx, my, fe, fn (ncat+1 each); then per (n-1)*ntrace+nt: tm, tc, tx, ty, tfe, tfn
 struct RemapPlanes {
@@ -76,14 +84,14 @@ __global__ void k_remap_dp(Slab s, int SB, double dt, const double *dxu, const d
     FD(s, fdy, k) = py;
 }
 
-// ---- limited_gradient (:1344-1484) at one cell; MASK(ii,jj), PHI(ii,jj) functors ----
-template <typename FM, typename FP>
-__device__ __forceinline__ void rm_limited_gradient(int i, int j, FM mask, FP phi, double cx, double cy, double &gx, double &gy) {
-    const double ph = phi(i, j);
-    auto nb = [&](int ii, int jj) { const double m = mask(ii, jj); return m * phi(ii, jj) + (1.0 - m) * ph; };
-    const double phi_nw = nb(i - 1, j + 1), phi_n = nb(i, j + 1), phi_ne = nb(i + 1, j + 1);
-    const double phi_w = nb(i - 1, j), phi_e = nb(i + 1, j);
-    const double phi_sw = nb(i - 1, j - 1), phi_s = nb(i, j - 1), phi_se = nb(i + 1, j - 1);
+// ---- limited_gradient (:1344-1484) at one cell from the 3x3 values around it (index (dj+1)*3 + (di+1)) ----
+__device__ __forceinline__ void rm_lg9(const double *mk, const double *ph9, double cx, double cy, double &gx, double &gy) {
+    const double ph = ph9[4];
+#define RM_NB(q) (mk[q] * ph9[q] + (1.0 - mk[q]) * ph)
+    const double phi_nw = RM_NB(6), phi_n = RM_NB(7), phi_ne = RM_NB(8);
+    const double phi_w = RM_NB(3), phi_e = RM_NB(5);
+    const double phi_sw = RM_NB(0), phi_s = RM_NB(1), phi_se = RM_NB(2);
+#undef RM_NB
     const double gxtmp = (phi_e - phi_w) * 0.5, gytmp = (phi_n - phi_s) * 0.5;
     double pmn = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(phi_nw, phi_n), phi_ne), phi_w), ph), phi_e), phi_sw), phi_s), phi_se);
     double pmx = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(phi_nw, phi_n), phi_ne), phi_w), ph), phi_e), phi_sw), phi_s), phi_se);
@@ -102,59 +110,88 @@ __device__ __forceinline__ void rm_limited_gradient(int i, int j, FM mask, FP ph
 }
 
 // ---- make_masks (:867-1015) + construct_fields (:1024-1331): one thread per cell, blockIdx.z = category ----
-__global__ void k_remap_construct(Slab s, RemapTab t, RemapPlanes P, const double *hm) {
+// The masks are functions of mm and tm at the nine stencil cells, which the thread holds in registers (mm once per category, the
+// tmask of the current type-1 tracer for the tracers that hang on it).  Cells without ice of the category (every mask 0, tc = tx =
+// ty = 0 in the reference) write NOTHING: the flux kernel takes the zeros from the mass plane's own test (mm <= puny), so most
+// of the 3 ntrace ncat planes are never touched where there is no ice.  The nine values of the next tracer are in flight while
+// the gradient of this one is computed.
+__global__ void __launch_bounds__(256) k_remap_construct(Slab s, RemapTab t, RemapPlanes P, const double *hm) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, n = blockIdx.z;
     if (i > s.nxl + 1 || j > s.nyl + 1) return;
     const size_t km = mcell(s, i, j);
+    const long pitch = s.pitch;
+#define RM_K9(q) (size_t)((long)km + ((q) / 3 - 1) * pitch + ((q) % 3 - 1))          // = mcell(s, i + q%3 - 1, j + q/3 - 1)
     const double xxav = 1.0 / 12.0, yyav = 1.0 / 12.0, xav = 0.0, yav = 0.0;          // init_remap, :249-289
     const double *mm = P.mm(n);
     const bool phys = (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl);
-    const bool ice = phys && mm[km] > RM_PUNY;                                        // the cell list of construct_fields
+    double m9[9], mk[9];
     double mx = 0.0, my = 0.0;
-    if (phys && hm[km] > RM_PUNY)                                                     // limited_gradient(mm, hm, xav, yav)
-        rm_limited_gradient(i, j, [&](int ii, int jj) { return hm[mcell(s, ii, jj)]; }, [&](int ii, int jj) { return mm[mcell(s, ii, jj)]; },
-                            xav, yav, mx, my);
+    const bool ocean = phys && hm[km] > RM_PUNY;
+    const bool ice = phys && mm[km] > RM_PUNY;                                        // the cell list of construct_fields
+    if (ocean || ice) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) m9[q] = mm[RM_K9(q)];
+    }
+    if (ocean) {                                                                      // limited_gradient(mm, hm, xav, yav), :1186-1191
+#pragma unroll
+        for (int q = 0; q < 9; q++) mk[q] = hm[RM_K9(q)];
+        rm_lg9(mk, m9, xav, yav, mx, my);
+    }
     P.mx(n)[km] = mx;
     P.my(n)[km] = my;
-    if (n == 0) return;
-    const double mc = ice ? mm[km] : 0.0;
-    double mxav = 0.0, myav = 0.0;
-    if (ice) {
-        mxav = (mx * xxav + mc * xav) / mm[km];                                       // :1212-1215
-        myav = (my * yyav + mc * yav) / mm[km];
+    if (n == 0 || !ice) return;
+    const double mc = m9[4];                                                          // :1198-1202 (xav = yav = 0)
+    const double mxav = (mx * xxav + mc * xav) / m9[4];                               // :1212-1215
+    const double myav = (my * yyav + mc * yav) / m9[4];
+#pragma unroll
+    for (int q = 0; q < 9; q++) mk[q] = m9[q] > RM_PUNY ? 1.0 : 0.0;                  // mmask
+    double pk[9], t9[9], nx9[9];                                                      // tmask of the parent (type 1); this tracer's and the next one's values
+    double ptx = 0.0, pty = 0.0;                                                      // mtxav, mtyav of the parent
+    bool pmask = false;
+    if (t.ntrace > 0) {
+        const double *tm = P.tm((n - 1) * t.ntrace + t.ord[0]);
+#pragma unroll
+        for (int q = 0; q < 9; q++) nx9[q] = tm[RM_K9(q)];
     }
-    double mtxav[RM_MAXT], mtyav[RM_MAXT];
-    for (int nt = 0; nt < t.ntrace; nt++) { mtxav[nt] = 0.0; mtyav[nt] = 0.0; }
-    auto mmask = [&](int ii, int jj) { return mm[mcell(s, ii, jj)] > RM_PUNY ? 1.0 : 0.0; };
-    for (int nt = 0; nt < t.ntrace; nt++) {
-        const int p = (n - 1) * t.ntrace + nt;
-        const double *tm = P.tm(p);
+    for (int q0 = 0; q0 < t.ntrace; q0++) {
+        const int nt = t.ord[q0], p = (n - 1) * t.ntrace + nt, ty_ = t.type[nt];
+#pragma unroll
+        for (int q = 0; q < 9; q++) t9[q] = nx9[q];
+        if (q0 + 1 < t.ntrace) {
+            const double *tm = P.tm((n - 1) * t.ntrace + t.ord[q0 + 1]);
+#pragma unroll
+            for (int q = 0; q < 9; q++) nx9[q] = tm[RM_K9(q)];
+        }
         double tx = 0.0, ty = 0.0, tc = 0.0;
-        auto phi = [&](int ii, int jj) { return tm[mcell(s, ii, jj)]; };
-        if (t.type[nt] == 1) {                                                        // :1219-1273
-            if (phys && mm[km] > RM_PUNY) rm_limited_gradient(i, j, mmask, phi, mxav, myav, tx, ty);
-            if (ice) {
-                tc = tm[km] - tx * mxav - ty * myav;
-                if (t.has[nt] && fabs(tm[km]) > RM_PUNY) {                            // tmask (:971-981)
+        if (ty_ == 1) {                                                               // :1219-1273
+            rm_lg9(mk, t9, mxav, myav, tx, ty);
+            tc = t9[4] - tx * mxav - ty * myav;
+            pmask = false; ptx = 0.0; pty = 0.0;
+            if (t.has[nt]) {
+#pragma unroll
+                for (int q = 0; q < 9; q++) pk[q] = (m9[q] > RM_PUNY && fabs(t9[q]) > RM_PUNY) ? 1.0 : 0.0;      // tmask (:971-981)
+                pmask = pk[4] > RM_PUNY;
+                if (pmask) {
                     const double w1 = mc * tc, w2 = mc * tx + mx * tc, w3 = mc * ty + my * tc;
-                    const double w7 = 1.0 / (mm[km] * tm[km]);
-                    mtxav[nt] = (w1 * xav + w2 * xxav) * w7;
-                    mtyav[nt] = (w1 * yav + w3 * yyav) * w7;
+                    const double w7 = 1.0 / (m9[4] * t9[4]);
+                    ptx = (w1 * xav + w2 * xxav) * w7;
+                    pty = (w1 * yav + w3 * yyav) * w7;
                 }
             }
-        } else if (t.type[nt] == 2) {                                                 // :1275-1293
-            const int nt1 = t.dep[nt] - 1;
-            const double *tm1 = P.tm((n - 1) * t.ntrace + nt1);
-            auto tmask1 = [&](int ii, int jj) { const size_t q = mcell(s, ii, jj); return (t.has[nt1] && mm[q] > RM_PUNY && fabs(tm1[q]) > RM_PUNY) ? 1.0 : 0.0; };
-            if (phys && tmask1(i, j) > RM_PUNY) rm_limited_gradient(i, j, tmask1, phi, mtxav[nt1], mtyav[nt1], tx, ty);
-            if (ice) tc = tm[km] - tx * mtxav[nt1] - ty * mtyav[nt1];
-        } else if (t.type[nt] == 3) {                                                 // :1295-1303
-            if (ice) tc = tm[km];
+        } else if (ty_ == 2) {                                                        // :1275-1293
+            if (pmask) {
+                rm_lg9(pk, t9, ptx, pty, tx, ty);
+                tc = t9[4] - tx * ptx - ty * pty;
+            } else
+                tc = t9[4];                                                           // (- 0 * mtxav - 0 * mtyav)
+        } else {                                                                      // :1295-1303
+            tc = t9[4];
         }
         P.tc(p)[km] = tc;
         P.tx(p)[km] = tx;
         P.ty(p)[km] = ty;
     }
+#undef RM_K9
 }
 
 // ---- ghost ring of a list of plain planes, one rank: centre fields, scalar (sgn +1) or vector (-1) ----
@@ -313,18 +350,34 @@ __device__ __forceinline__ void rm_edge_triangles(int i, int j, FDP dxy /* (ii, 
     }
 }
 
-// ---- transport_integrals (:3199-3509): one thread per edge, every category and tracer from one set of triangles ----
+// ---- transport_integrals (:3199-3509): one thread per (edge, category); the triangles are rebuilt per category (a few hundred
+// operations against the loads of the integrals), the six mass sums of every triangle stay in registers while the tracers go by
+// in dependency order (RemapTab::ord), so no per-thread array is indexed at run time ----
 template <bool NORTH>
-__global__ void k_remap_flux(Slab s, RemapTab tb, RemapPlanes P, const double *dxu, const double *dyu, int fdx, int fdy) {
+__global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, RemapTab tb, RemapPlanes P, const double *dxu, const double *dyu, int fdx, int fdy) {
     // east edges: i = 0 .. nxl, j = 1 .. nyl;  north edges: i = 1 .. nxl, j = 0 .. nyl   (:1823-1826, :1849-1852)
     const int i = blockIdx.x * blockDim.x + threadIdx.x + (NORTH ? 1 : 0);
     const int j = blockIdx.y * blockDim.y + threadIdx.y + (NORTH ? 0 : 1);
+    const int n = blockIdx.z;
     if (i > s.nxl || j > s.nyl) return;
     const size_t km = mcell(s, i, j);
     const size_t ka = cell(s, i, j), kb = NORTH ? cell(s, i - 1, j) : cell(s, i, j - 1);
     const bool moving = FD(s, fdx, kb) != 0.0 || FD(s, fdy, kb) != 0.0 || FD(s, fdx, ka) != 0.0 || FD(s, fdy, ka) != 0.0;   // :1911-1929
-    RmTri t;
-    if (moving) {
+    double *const fm = NORTH ? P.fn(n) : P.fe(n);
+    if (!moving) {
+        fm[km] = 0.0;
+        if (n >= 1)
+            for (int nt = 0; nt < tb.ntrace; nt++) (NORTH ? P.tfn((n - 1) * tb.ntrace + nt) : P.tfe((n - 1) * tb.ntrace + nt))[km] = 0.0;
+        return;
+    }
+    double area[RM_GROUPS];
+    unsigned k2[RM_GROUPS];              // (a plane has fewer than 2^32 cells: evpk_transport_remap checks)
+    double ms[RM_GROUPS][6];             // msum, mxsum, mxxsum, mxysum, mysum, myysum of each triangle
+    double mflx = 0.0;
+    bool anyice = false;                 // does any triangle of this edge draw on a cell with ice of this category?
+    bool icg[RM_GROUPS];                 // ... per triangle: tc = tx = ty = 0 where there is none (k_remap_construct does not store those zeros)
+    {
+        RmTri t;
         auto dxy = [&](int ii, int jj, double &dx, double &dy) {
             const size_t q = cell(s, ii, jj), qm = mcell(s, ii, jj);
             dx = FD(s, fdx, q) / dxu[qm];                                             // :1932-1937
@@ -332,120 +385,157 @@ __global__ void k_remap_flux(Slab s, RemapTab tb, RemapPlanes P, const double *d
         };
         const size_t kl = NORTH ? mcell(s, i - 1, j) : mcell(s, i, j), kr = NORTH ? mcell(s, i, j) : mcell(s, i, j - 1);
         rm_edge_triangles<NORTH>(i, j, dxy, dxu[kl] * dyu[kl], dxu[kr] * dyu[kr], tb.order, t);
+        const double p5625m = -9.0 / 16.0, p52083 = 25.0 / 48.0, p333 = 1.0 / 3.0;
+        const double *mm = P.mm(n), *mxp = P.mx(n), *myp = P.my(n);
+#pragma unroll
+        for (int g = 0; g < RM_GROUPS; g++) {
+            area[g] = t.area[g];
+            k2[g] = (unsigned)mcell(s, i + t.di[g], j + t.dj[g]);
+            icg[g] = false;
+            if (area[g] == 0.0) continue;
+            const double mmv = mm[k2[g]];
+            icg[g] = mmv > RM_PUNY;
+            anyice = anyice || icg[g];
+            const double mc = mmv > RM_PUNY ? mmv : 0.0, mx = mxp[k2[g]], my = myp[k2[g]];
+            const double *xp = t.xp[g], *yp = t.yp[g];
+            double msum, mxsum, mxxsum, mxysum, mysum, myysum;
+            if (tb.order == 1) {
+                const double m0 = mc + xp[0] * mx + yp[0] * my;
+                msum = m0;
+                mxsum = m0 * xp[0]; mxxsum = mxsum * xp[0]; mxysum = mxsum * yp[0];
+                mysum = m0 * yp[0]; myysum = mysum * yp[0];
+            } else if (tb.order == 2) {
+                const double m1 = p333 * (mc + xp[1] * mx + yp[1] * my), m2 = p333 * (mc + xp[2] * mx + yp[2] * my),
+                             m3 = p333 * (mc + xp[3] * mx + yp[3] * my);
+                msum = m1 + m2 + m3;
+                double w1 = m1 * xp[1], w2 = m2 * xp[2], w3 = m3 * xp[3];
+                mxsum = w1 + w2 + w3;
+                mxxsum = w1 * xp[1] + w2 * xp[2] + w3 * xp[3];
+                mxysum = w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+                w1 = m1 * yp[1]; w2 = m2 * yp[2]; w3 = m3 * yp[3];
+                mysum = w1 + w2 + w3;
+                myysum = w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+            } else {
+                const double m0 = p5625m * (mc + xp[0] * mx + yp[0] * my), m1 = p52083 * (mc + xp[1] * mx + yp[1] * my),
+                             m2 = p52083 * (mc + xp[2] * mx + yp[2] * my), m3 = p52083 * (mc + xp[3] * mx + yp[3] * my);
+                msum = m0 + m1 + m2 + m3;
+                double w0 = m0 * xp[0], w1 = m1 * xp[1], w2 = m2 * xp[2], w3 = m3 * xp[3];
+                mxsum = w0 + w1 + w2 + w3;
+                mxxsum = w0 * xp[0] + w1 * xp[1] + w2 * xp[2] + w3 * xp[3];
+                mxysum = w0 * yp[0] + w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+                w0 = m0 * yp[0]; w1 = m1 * yp[1]; w2 = m2 * yp[2]; w3 = m3 * yp[3];
+                mysum = w0 + w1 + w2 + w3;
+                myysum = w0 * yp[0] + w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+            }
+            ms[g][0] = msum; ms[g][1] = mxsum; ms[g][2] = mxxsum; ms[g][3] = mxysum; ms[g][4] = mysum; ms[g][5] = myysum;
+            mflx = mflx + area[g] * msum;
+        }
     }
-    const double p5625m = -9.0 / 16.0, p52083 = 25.0 / 48.0, p333 = 1.0 / 3.0;
-    for (int n = 0; n <= tb.ncat; n++) {
-        double mflx = 0.0;
-        double mtflx[RM_MAXT], mtsum[RM_MAXT], mtxsum[RM_MAXT], mtysum[RM_MAXT];
-        for (int nt = 0; nt < tb.ntrace; nt++) mtflx[nt] = 0.0;
-        if (moving) {
-            const double *mm = P.mm(n), *mxp = P.mx(n), *myp = P.my(n);
+    fm[km] = mflx;
+    if (n == 0) return;
+    if (!anyice) {
+        // tc = tx = ty = 0 where mm <= puny (construct_fields): every mtsum is a sum of (finite) * 0 and every flux 0 + (+-0) = +0
+        for (int nt = 0; nt < tb.ntrace; nt++) (NORTH ? P.tfn((n - 1) * tb.ntrace + nt) : P.tfe((n - 1) * tb.ntrace + nt))[km] = 0.0;
+        return;
+    }
+    double p1s[RM_GROUPS], p1x[RM_GROUPS], p1y[RM_GROUPS], p2s[RM_GROUPS];        // mtsum, mtxsum, mtysum of the last type-1 tracer; mtsum of the last type-2
+#pragma unroll
+    for (int g = 0; g < RM_GROUPS; g++) { p1s[g] = 0.0; p1x[g] = 0.0; p1y[g] = 0.0; p2s[g] = 0.0; }
+    for (int q0 = 0; q0 < tb.ntrace; q0++) {
+        const int nt = tb.ord[q0], p = (n - 1) * tb.ntrace + nt, ty_ = tb.type[nt];
+        const double *tcp = P.tc(p), *txp = P.tx(p), *typ = P.ty(p);
+        double flx = 0.0;
+        if (ty_ == 1) {                                                               // :3449-3468
+            const bool keep = tb.has[nt] != 0;
+#pragma unroll
             for (int g = 0; g < RM_GROUPS; g++) {
-                if (t.area[g] == 0.0) continue;
-                const size_t k2 = mcell(s, i + t.di[g], j + t.dj[g]);
-                const double mc = mm[k2] > RM_PUNY ? mm[k2] : 0.0, mx = mxp[k2], my = myp[k2];
-                const double *xp = t.xp[g], *yp = t.yp[g];
-                double msum, mxsum, mxxsum, mxysum, mysum, myysum;
-                if (tb.order == 1) {
-                    const double m0 = mc + xp[0] * mx + yp[0] * my;
-                    msum = m0;
-                    mxsum = m0 * xp[0]; mxxsum = mxsum * xp[0]; mxysum = mxsum * yp[0];
-                    mysum = m0 * yp[0]; myysum = mysum * yp[0];
-                } else if (tb.order == 2) {
-                    const double m1 = p333 * (mc + xp[1] * mx + yp[1] * my), m2 = p333 * (mc + xp[2] * mx + yp[2] * my),
-                                 m3 = p333 * (mc + xp[3] * mx + yp[3] * my);
-                    msum = m1 + m2 + m3;
-                    double w1 = m1 * xp[1], w2 = m2 * xp[2], w3 = m3 * xp[3];
-                    mxsum = w1 + w2 + w3;
-                    mxxsum = w1 * xp[1] + w2 * xp[2] + w3 * xp[3];
-                    mxysum = w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
-                    w1 = m1 * yp[1]; w2 = m2 * yp[2]; w3 = m3 * yp[3];
-                    mysum = w1 + w2 + w3;
-                    myysum = w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
-                } else {
-                    const double m0 = p5625m * (mc + xp[0] * mx + yp[0] * my), m1 = p52083 * (mc + xp[1] * mx + yp[1] * my),
-                                 m2 = p52083 * (mc + xp[2] * mx + yp[2] * my), m3 = p52083 * (mc + xp[3] * mx + yp[3] * my);
-                    msum = m0 + m1 + m2 + m3;
-                    double w0 = m0 * xp[0], w1 = m1 * xp[1], w2 = m2 * xp[2], w3 = m3 * xp[3];
-                    mxsum = w0 + w1 + w2 + w3;
-                    mxxsum = w0 * xp[0] + w1 * xp[1] + w2 * xp[2] + w3 * xp[3];
-                    mxysum = w0 * yp[0] + w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
-                    w0 = m0 * yp[0]; w1 = m1 * yp[1]; w2 = m2 * yp[2]; w3 = m3 * yp[3];
-                    mysum = w0 + w1 + w2 + w3;
-                    myysum = w0 * yp[0] + w1 * yp[1] + w2 * yp[2] + w3 * yp[3];
+                if (area[g] == 0.0) continue;
+                const double tc = icg[g] ? tcp[k2[g]] : 0.0, tx = icg[g] ? txp[k2[g]] : 0.0, ty = icg[g] ? typ[k2[g]] : 0.0;
+                const double mts = ms[g][0] * tc + ms[g][1] * tx + ms[g][4] * ty;
+                flx = flx + area[g] * mts;
+                if (keep) {
+                    p1s[g] = mts;
+                    p1x[g] = ms[g][1] * tc + ms[g][2] * tx + ms[g][3] * ty;
+                    p1y[g] = ms[g][4] * tc + ms[g][3] * tx + ms[g][5] * ty;
                 }
-                mflx = mflx + t.area[g] * msum;
-                if (n == 0) continue;
-                for (int nt = 0; nt < tb.ntrace; nt++) {
-                    const int p = (n - 1) * tb.ntrace + nt;
-                    const double tc = P.tc(p)[k2];
-                    if (tb.type[nt] == 1) {                                           // :3449-3468
-                        const double tx = P.tx(p)[k2], ty = P.ty(p)[k2];
-                        mtsum[nt] = msum * tc + mxsum * tx + mysum * ty;
-                        mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
-                        mtxsum[nt] = mxsum * tc + mxxsum * tx + mxysum * ty;
-                        mtysum[nt] = mysum * tc + mxysum * tx + myysum * ty;
-                    } else if (tb.type[nt] == 2) {                                    // :3470-3483
-                        const int nt1 = tb.dep[nt] - 1;
-                        const double tx = P.tx(p)[k2], ty = P.ty(p)[k2];
-                        mtsum[nt] = mtsum[nt1] * tc + mtxsum[nt1] * tx + mtysum[nt1] * ty;
-                        mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
-                    } else if (tb.type[nt] == 3) {                                    // :3485-3497
-                        const int nt1 = tb.dep[nt] - 1;
-                        mtsum[nt] = mtsum[nt1] * tc;
-                        mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
-                    }
-                }
+            }
+        } else if (ty_ == 2) {                                                        // :3470-3483
+#pragma unroll
+            for (int g = 0; g < RM_GROUPS; g++) {
+                if (area[g] == 0.0) continue;
+                const double tc = icg[g] ? tcp[k2[g]] : 0.0, tx = icg[g] ? txp[k2[g]] : 0.0, ty = icg[g] ? typ[k2[g]] : 0.0;
+                const double mts = p1s[g] * tc + p1x[g] * tx + p1y[g] * ty;
+                flx = flx + area[g] * mts;
+                p2s[g] = mts;
+            }
+        } else {                                                                      // :3485-3497
+#pragma unroll
+            for (int g = 0; g < RM_GROUPS; g++) {
+                if (area[g] == 0.0) continue;
+                const double mts = p2s[g] * (icg[g] ? tcp[k2[g]] : 0.0);
+                flx = flx + area[g] * mts;
             }
         }
-        (NORTH ? P.fn(n) : P.fe(n))[km] = mflx;
-        if (n >= 1)
-            for (int nt = 0; nt < tb.ntrace; nt++) {
-                const int p = (n - 1) * tb.ntrace + nt;
-                (NORTH ? P.tfn(p) : P.tfe(p))[km] = mtflx[nt];
-            }
+        (NORTH ? P.tfn(p) : P.tfe(p))[km] = flx;
     }
 }
 
-// ---- update_fields (:3517-3729): one thread per physical cell, blockIdx.z = category ----
-__global__ void k_remap_update(Slab s, RemapTab tb, RemapPlanes P, unsigned *bad) {
+// ---- update_fields (:3517-3729): one thread per physical cell, blockIdx.z = category; tracers in dependency order ----
+__global__ void __launch_bounds__(256) k_remap_update(Slab s, RemapTab tb, RemapPlanes P, unsigned *bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y * blockDim.y + threadIdx.y + 1, n = blockIdx.z;
     if (i > s.nxl || j > s.nyl) return;
     const size_t k = mcell(s, i, j), kw = mcell(s, i - 1, j), ks = mcell(s, i, j - 1);
     const double tarear = FD(s, F_TAREAR, cell(s, i, j));
     double *mmp = P.mm(n);
     const double mold = mmp[k];
-    double told[RM_MAXT], tnew[RM_MAXT], mtold[RM_MAXT];
-    if (n >= 1)
-        for (int nt = 0; nt < tb.ntrace; nt++) {                                      // :3574-3598
-            told[nt] = P.tm((n - 1) * tb.ntrace + nt)[k];
-            if (tb.type[nt] == 1) mtold[nt] = mold * told[nt];
-            else if (tb.type[nt] == 2) mtold[nt] = mold * told[tb.dep[nt] - 1] * told[nt];
-            else { const int nt1 = tb.dep[nt] - 1, nt2 = tb.dep[nt1] - 1; mtold[nt] = mold * told[nt2] * told[nt1] * told[nt]; }
-        }
     double w1 = P.fe(n)[k] - P.fe(n)[kw] + P.fn(n)[k] - P.fn(n)[ks];                  // :3605-3620
     double mnew = mold - w1 * tarear;
     if (mnew < -RM_PUNY) atomicOr(bad, 2u);
     else if (mnew < 0.0) mnew = 0.0;
     mmp[k] = mnew;
     if (n == 0) return;
-    for (int nt = 0; nt < tb.ntrace; nt++) {
-        const int p = (n - 1) * tb.ntrace + nt;
-        double v = 0.0;                                                               // :3658-3662
+    double o1 = 0.0, n1 = 0.0, o2 = 0.0, n2 = 0.0;       // old / new values of the last type-1 and type-2 tracers
+    for (int q0 = 0; q0 < tb.ntrace; q0++) {
+        const int nt = tb.ord[q0], p = (n - 1) * tb.ntrace + nt, ty_ = tb.type[nt];
+        double *tmp = P.tm(p);
+        double v = 0.0, told = 0.0;                                                   // :3658-3662
         if (mnew > 0.0) {
+            told = tmp[k];
             w1 = P.tfe(p)[k] - P.tfe(p)[kw] + P.tfn(p)[k] - P.tfn(p)[ks];
-            if (tb.type[nt] == 1) v = (mtold[nt] - w1 * tarear) / mnew;
-            else if (tb.type[nt] == 2) {
-                const int nt1 = tb.dep[nt] - 1;
-                if (fabs(tnew[nt1]) > 0.0) v = (mtold[nt] - w1 * tarear) / (mnew * tnew[nt1]);
-            } else {
-                const int nt1 = tb.dep[nt] - 1, nt2 = tb.dep[nt1] - 1;
-                if (fabs(tnew[nt1]) > 0.0 && fabs(tnew[nt2]) > 0.0) v = (mtold[nt] - w1 * tarear) / (mnew * tnew[nt2] * tnew[nt1]);
-            }
         }
-        tnew[nt] = v;
-        P.tm(p)[k] = v;
+        if (ty_ == 1) {                                                               // mtold: :3574-3598
+            if (mnew > 0.0) v = (mold * told - w1 * tarear) / mnew;
+            o1 = told; n1 = v;
+        } else if (ty_ == 2) {
+            if (mnew > 0.0 && fabs(n1) > 0.0) v = (mold * o1 * told - w1 * tarear) / (mnew * n1);
+            o2 = told; n2 = v;
+        } else {
+            if (mnew > 0.0 && fabs(n2) > 0.0 && fabs(n1) > 0.0) v = (mold * o1 * o2 * told - w1 * tarear) / (mnew * n1 * n2);
+        }
+        tmp[k] = v;
     }
+}
+
+// ---- the slices of one block array (blocks `bstride` doubles apart, slices `pstride` apart) <-> a list of plain planes, one launch:
+// blockIdx.z = slice, blockIdx.y = (block, group of blockDim.y rows).  k_gather_plane / k_scatter_plane for many planes. ----
+__global__ void k_gather_planes(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, size_t pstride, size_t bstride, double *const *dst, int nrg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int b = blockIdx.y / nrg, j = (blockIdx.y % nrg) * blockDim.y + threadIdx.y + 1;
+    if (i > nxb || j > nyb) return;
+    const BlockDesc d = bd[b];
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
+    const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
+    if (!gather_take(s, d, i, j, si, sj)) return;
+    dst[blockIdx.z][mcell(s, si, sj)] = src[(size_t)blockIdx.z * pstride + (size_t)b * bstride + (size_t)(j - 1) * nxb + (i - 1)];
+}
+__global__ void k_scatter_planes(Slab s, const BlockDesc *bd, int nxb, int nyb, double *const *src, double *dst, size_t pstride, size_t bstride, int nrg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int b = blockIdx.y / nrg, j = (blockIdx.y % nrg) * blockDim.y + threadIdx.y + 1;
+    if (i > nxb || j > nyb) return;
+    int si, sj;
+    if (!scatter_take(s, bd[b], i, j, MODE_PHYS, si, sj)) return;
+    dst[(size_t)blockIdx.z * pstride + (size_t)b * bstride + (size_t)(j - 1) * nxb + (i - 1)] = src[blockIdx.z][mcell(s, si, sj)];
 }
 
 // ---- frame (two outermost rows / columns) of a list of planes <-> consecutive planes of the pair-interleaved slab, where
