@@ -59,7 +59,7 @@ def parse():
 def source_sha():
     """identifies the kernel build a PMC pass was made with: the sources libevpk.so is compiled from"""
     h = hashlib.sha256()
-    for n in ("evpk_kernels.hip", "evpk_api.hip", "evpk_internal.h", "evpk_remap.hip"):
+    for n in ("evpk_kernels.hip", "evpk_api.hip", "evpk_internal.h", "evpk_remap.hip", "evpk_eap.hip", "evpk_fmath.h"):
         h.update(open(os.path.join(ROOT, "cice5_amd", "csrc", n), "rb").read())
     return h.hexdigest()[:16]
 

@@ -29,6 +29,7 @@
 // single translation unit: the kernels are compiled together with the host API
 #include "evpk_kernels.hip"
 #include "evpk_remap.hip"
+#include "evpk_eap.hip"
 
 using namespace evpk;
 
@@ -271,6 +272,10 @@ struct evpk_ctx {
     signed char *rm_sgn = nullptr;
     unsigned *rm_bad = nullptr;
     size_t rm_pool_n = 0, rm_stage_n = 0, rm_tab_n = 0;
+    // EAP (kdyn = 2): set by evpk_eap_init -- the subcycle loop then runs stress_eap / stepu / stepa (evpk_eap.hip)
+    bool eap = false;
+    EapDev E{};
+    double *eap_pool = nullptr, *eap_tab = nullptr;
     bool have_lengths = false;       // HTN / HTE were given in evpk_geom
     unsigned char *io_raw = nullptr, *io_act = nullptr;   // sparse I/O: tiles whose inputs are uploaded this step
     long long evp_count = 0;         // evpk_prep calls so far
@@ -801,7 +806,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->eap_pool, c->eap_tab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1532,11 +1537,130 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     return 0;
 }
 
+// ---- EAP (source/ice_dyn_eap.F90), SURVEY S8 row f-4 -------------------------------------------------------------------------
+extern "C" int evpk_eap_init(evpk_ctx *c, int32_t nx_yield, int32_t ny_yield, int32_t na_yield, const double *s11r, const double *s12r,
+                             const double *s22r, const double *s11s, const double *s12s, const double *s22s) {
+    if (!c || !s11r || !s12r || !s22r || !s11s || !s12s || !s22s) return 1;
+    if (nx_yield < 2 || ny_yield < 2 || na_yield < 2) FAIL(c, "evpk_eap_init: table extents %d x %d x %d", nx_yield, ny_yield, na_yield);
+    if (!c->connected) FAIL(c, "evpk_eap_init: the context is not connected yet (evpk_connect)");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nt = (size_t)nx_yield * ny_yield * na_yield, np = mask_elems(s);
+    if (c->eap_tab) (void)hipFree(c->eap_tab);
+    c->eap_tab = nullptr;
+    HIPCHK(c, hipMalloc(&c->eap_tab, sizeof(double) * 6 * nt));
+    const double *src[6] = {s11r, s12r, s22r, s11s, s12s, s22s};
+    for (int q = 0; q < 6; q++) {
+        HIPCHK(c, hipMemcpy(c->eap_tab + q * nt, src[q], sizeof(double) * nt, hipMemcpyHostToDevice));
+        c->E.tab[q] = c->eap_tab + q * nt;
+    }
+    c->E.nxy = nx_yield; c->E.nyy = ny_yield; c->E.nay = na_yield;
+    if (!c->eap_pool) {
+        HIPCHK(c, hipMalloc(&c->eap_pool, sizeof(double) * EAP_NPLANES * np));
+        HIPCHK(c, hipMemsetAsync(c->eap_pool, 0, sizeof(double) * EAP_NPLANES * np, c->stream));
+        double *q = c->eap_pool;
+        for (int k = 0; k < 4; k++) { c->E.a11[k] = q; q += np; }
+        for (int k = 0; k < 4; k++) { c->E.a12[k] = q; q += np; }
+        for (int k = 0; k < 11; k++) { c->E.hist[k] = q; q += np; }
+        for (int k = 0; k < 8; k++) { c->E.str[k] = q; q += np; }
+        for (int k = 0; k < 4; k++)      // init_eap (:529-551): isotropic structure tensor
+            hipLaunchKernelGGL(k_fill_mplane, grid2d(s, B2D), B2D, 0, c->stream, s, c->E.a11[k], 0.5);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->eap = true;
+    return 0;
+}
+
+static double *eap_member(evpk_ctx *c, int q) {       // the planes in the order of evpk_eap_state's members
+    return q < 4 ? c->E.a11[q] : q < 8 ? c->E.a12[q - 4] : c->E.hist[q - 8];
+}
+
+extern "C" int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st) {
+    if (!c || !st) return 1;
+    if (!c->eap) FAIL(c, "evpk_eap_upload: evpk_eap_init has not been called");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nblk = (size_t)c->nyb * c->nxb, n = (size_t)c->nblocks * nblk;
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    for (int q = 0; q < 8; q++) {
+        const double *h = q < 4 ? st->a11_c[q] : st->a12_c[q - 4];
+        if (!h) continue;
+        const double *dev = (const double *)mapped_alias(h);
+        if (!dev) {
+            HIPCHK(c, hipMemcpyAsync(c->stage, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+            dev = c->stage;
+        }
+        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, dev, nblk, eap_member(c, q));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // (the staging buffer is reused by the next array)
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int evpk_eap_download(evpk_ctx *c, evpk_eap_state *st) {
+    if (!c || !st) return 1;
+    if (!c->eap) FAIL(c, "evpk_eap_download: evpk_eap_init has not been called");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    double *host[19] = {st->a11_c[0], st->a11_c[1], st->a11_c[2], st->a11_c[3], st->a12_c[0], st->a12_c[1], st->a12_c[2], st->a12_c[3],
+                        st->a11, st->a12, st->e11, st->e12, st->e22, st->yieldstress11, st->yieldstress12, st->yieldstress22, st->s11, st->s12, st->s22};
+    for (int q = 0; q < 19; q++) {
+        if (!host[q]) continue;
+        // T-cell fields: the physical cells and the N / E ghost T cells the reference computes too (ice_dyn_shared.F90:528-537)
+        if (double *dst = (double *)mapped_alias(host[q])) {
+            hipLaunchKernelGGL(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), dst, (int)MODE_NE);
+            continue;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->stage, host[q], n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), c->stage, (int)MODE_NE);
+        HIPCHK(c, hipMemcpyAsync(host[q], c->stage, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the subcycle loop of eap(dt) (ice_dyn_eap.F90:345-447): stress_eap, stepu, [stepa], velocity halo -- in place in the current buffer
+static int eap_subcycle(evpk_ctx *c, int32_t nsub) {
+    Slab &s = c->s;
+    const int SB = c->cur ? F_STATE1 : F_STATE0;
+    const dim3 gT((s.nxl + 1 + 63) / 64, (s.nyl + 1 + 3) / 4), gU((s.nxl + 63) / 64, (s.nyl + 3) / 4);
+    const double dte = c->p.dt / (double)c->p.ndte, dtei = 1.0 / dte;        // ice_dyn_shared.F90:209-210
+    c->kernel_ms = c->kernel2_ms = 0.f;
+    c->kernel_launches = c->double_launches = 0;
+    c->kernel_timed = c->kernel2_timed = 0;
+    c->bound_updates = 0; c->bound_timed = 0; c->bound_ms = 0.f;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->ksub == 0) hipLaunchKernelGGL(k_eap_reset, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);
+    for (int n = 0; n < nsub; n++) {
+        const int ksub = c->ksub + 1;
+        if (ksub == c->p.ndte) hipLaunchKernelGGL(k_eap_stress<true>, gT, B2D, 0, c->stream, s, c->E, SB, c->p.arlx1i, c->p.denom1);
+        else hipLaunchKernelGGL(k_eap_stress<false>, gT, B2D, 0, c->stream, s, c->E, SB, c->p.arlx1i, c->p.denom1);
+        hipLaunchKernelGGL(k_eap_stepu, gU, B2D, 0, c->stream, s, c->E, c->p, SB);
+        if (ksub % 10 == 1) hipLaunchKernelGGL(k_eap_stepa, gT, B2D, 0, c->stream, s, c->E, SB, dtei);     // :411-426
+        if (halo(c, SB + S_U, 2, true, true, 0.0)) return 1;                                               // :431-439
+        c->bound_updates++;
+        c->kernel_launches += 2;
+        c->ksub++;
+    }
+    if (c->zone_mode) { c->zone_left = 0; c->inner_ok = true; }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
+    return xp_check(c);
+}
+
 static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     if (!c->prepped) FAIL(c, "evpk_prep has not been called");
     if (nsub < 0) FAIL(c, "nsub < 0");
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->eap) return eap_subcycle(c, nsub);
     const bool wrap = (c->nranks == 1 && c->ew == EVPK_BND_CYCLIC && !c->force_exchange);
     const bool need_halo = (c->nranks > 1) || (c->ns == EVPK_BND_TRIPOLE) || c->force_exchange;
     c->kernel_ms = 0.f;
@@ -1806,7 +1930,7 @@ extern "C" int evpk_finish(evpk_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     const dim3 g2 = grid2d(s, B2D);
     const int SB = c->cur ? F_STATE1 : F_STATE0;
-    if (c->ns == EVPK_BND_TRIPOLE && halo_stress12(c, SB + S_SP)) return 1;        // ice_dyn_evp.F90:454-479
+    if (c->ns == EVPK_BND_TRIPOLE && !c->eap && halo_stress12(c, SB + S_SP)) return 1;        // ice_dyn_evp.F90:454-479 (eap has none)
     hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
     // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)
     if (halo(c, F_WORK3, 2, true, true, 0.0)) return 1;

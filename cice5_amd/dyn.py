@@ -136,6 +136,28 @@ class EvpDynamics:
         f = self.fields if self._outputs is None else {n: self.fields[n] for n in self._outputs}
         self.ctx.download(f)
 
+    # ---- kdyn = 2: the elastic-anisotropic-plastic rheology (source/ice_dyn_eap.F90) ----
+    def init_eap(self, dt: float, tables):
+        """ice_dyn_eap.F90:493-621: init_evp, isotropic structure tensor, the lookup tables (an input here: `tables` as the
+        host's init_eap made them, [na_yield][ny_yield][nx_yield] each).  evp()/eap() of this object then run eap(dt)."""
+        self.init_evp(dt)
+        f = self.fields
+        for c in (1, 2, 3, 4):
+            f[f"a11_{c}"][...] = 0.5
+            f[f"a12_{c}"][...] = 0.0
+        for n in evpk.EAP_HISTORY:
+            if n in f:
+                f[n][...] = 0.0
+        self.ctx.eap_init(tables)
+        self._eap = True
+
+    def eap(self, dt: float):
+        """ice_dyn_eap.F90:66: one call of the EAP dynamics, in place on `fields` (the structure tensor a11_1..4, a12_1..4 is
+        resident on the device between calls and comes back with the history fields every call)"""
+        assert getattr(self, "_eap", False), "init_eap has not been called"
+        self.evp(dt)
+        self.ctx.eap_download(self.fields)
+
     def principal_stress(self):
         """ice_dyn_shared.F90:853: (sig1, sig2) block arrays from the state of the last evp() (physical cells)."""
         shp = self.fields["uvel"].shape

@@ -64,6 +64,13 @@ class State(ct.Structure):
                 [(n, c_f64p) for n in STATE_OUT_F64] + [("icetmask", c_i32p), ("strength", c_f64p)])
 
 
+EAP_HISTORY = ["a11", "a12", "e11", "e12", "e22", "yieldstress11", "yieldstress12", "yieldstress22", "s11", "s12", "s22"]
+
+
+class EapState(ct.Structure):
+    _fields_ = [("a11_c", c_f64p * 4), ("a12_c", c_f64p * 4)] + [(n, c_f64p) for n in EAP_HISTORY]
+
+
 class Stats(ct.Structure):
     _fields_ = [("icellt", ct.c_int64), ("icellu", ct.c_int64), ("ncell_slab", ct.c_int64),
                 ("nstrips", ct.c_int32), ("nstrips_total", ct.c_int32), ("subcycles_done", ct.c_int32),
@@ -82,7 +89,8 @@ EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "
            "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
            "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
            "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
-           "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap"]
+           "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap",
+           "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download"]
 
 REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS = 11, 12        # include/evpk.h
 
@@ -127,6 +135,9 @@ def lib():
         L.evpk_remap_init.argtypes = [ctxp, c_f64p, c_f64p, c_f64p]
         L.evpk_transport_remap.argtypes = [ctxp, ct.c_double, ct.c_int32, ct.c_int32, c_f64p, c_f64p, c_i32p, c_i32p, c_i32p,
                                            ct.c_int32, ct.c_int32, ct.c_int32]
+        L.evpk_eap_init.argtypes = [ctxp, ct.c_int32, ct.c_int32, ct.c_int32] + [c_f64p] * 6
+        L.evpk_eap_upload.argtypes = [ctxp, ct.POINTER(EapState)]
+        L.evpk_eap_download.argtypes = [ctxp, ct.POINTER(EapState)]
         L.evpk_restart_write.argtypes = [ctxp, ct.c_char_p, ct.c_int32, ct.c_int32]
         L.evpk_restart_read.argtypes = [ctxp, ct.c_char_p, ct.c_int64, ct.c_int32]
         for n in EXPORTS:
@@ -310,6 +321,30 @@ class Context:
         if rc not in (0, REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS):
             self._chk(rc, "evpk_transport_remap")
         return int(rc)
+
+    def eap_init(self, tables):
+        """evpk_eap_init: the six lookup tables of init_eap, each [na_yield][ny_yield][nx_yield]; the context then runs eap(dt)"""
+        na, ny, nx = tables[0].shape
+        assert all(t.shape == (na, ny, nx) and t.dtype == np.float64 and t.flags["C_CONTIGUOUS"] for t in tables) and len(tables) == 6
+        self._chk(self._L.evpk_eap_init(self._ctx, nx, ny, na, *[_p64(t) for t in tables]), "evpk_eap_init")
+
+    def _eap_state(self, f, names) -> EapState:
+        st = EapState()
+        st.a11_c = (c_f64p * 4)(*[_p64(f.get(f"a11_{c}") if f"a11_{c}" in names else None) for c in (1, 2, 3, 4)])
+        st.a12_c = (c_f64p * 4)(*[_p64(f.get(f"a12_{c}") if f"a12_{c}" in names else None) for c in (1, 2, 3, 4)])
+        for n in EAP_HISTORY:
+            setattr(st, n, _p64(f.get(n) if n in names else None))
+        return st
+
+    def eap_upload(self, f):
+        """evpk_eap_upload: a11_1..4, a12_1..4 of `f` (those present)"""
+        st = self._eap_state(f, [n for n in f if n[:4] in ("a11_", "a12_")])
+        self._chk(self._L.evpk_eap_upload(self._ctx, ct.byref(st)), "evpk_eap_upload")
+
+    def eap_download(self, f, names=None):
+        """evpk_eap_download: the structure tensor and the EAP history fields present in `f` (or only `names`)"""
+        st = self._eap_state(f, list(f) if names is None else names)
+        self._chk(self._L.evpk_eap_download(self._ctx, ct.byref(st)), "evpk_eap_download")
 
     def restart_write(self, path: str, append: bool = False, big_endian: bool = True):
         self._chk(self._L.evpk_restart_write(self._ctx, path.encode(), int(append), int(big_endian)), "evpk_restart_write")

@@ -317,3 +317,18 @@ def add_thickness_distribution(f: Dict[str, np.ndarray], ncat: int = 5) -> Dict[
     f["vicen"] = np.ascontiguousarray(np.moveaxis(vicen, 0, 1))
     f["aice0"] = np.maximum(1.0 - aice, 0.0)
     return f
+
+
+EAP_STATE = [f"a11_{c}" for c in (1, 2, 3, 4)] + [f"a12_{c}" for c in (1, 2, 3, 4)]
+EAP_HISTORY = ["a11", "a12", "e11", "e12", "e22", "yieldstress11", "yieldstress12", "yieldstress22", "s11", "s12", "s22"]
+
+
+def add_eap_state(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """the module arrays of ice_dyn_eap (source/ice_dyn_eap.F90:36-57) as init_eap leaves them (:529-551): isotropic
+    structure tensor a11 = 1/2, a12 = 0 at the four corners, history fields zero"""
+    shp = f["uvel"].shape
+    for n in EAP_STATE:
+        f[n] = np.full(shp, 0.5 if n.startswith("a11") else 0.0)
+    for n in EAP_HISTORY:
+        f[n] = np.zeros(shp)
+    return f

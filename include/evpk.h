@@ -236,6 +236,32 @@ int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, d
                          const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
                          int32_t l_fixed_area);
 
+/* the elastic-anisotropic-plastic rheology, eap(dt) (source/ice_dyn_eap.F90:66-486; kdyn = 2,
+ * ice_step_mod.F90:1118).  eap is evp with another stress: evp_prep1/2, stepu, the velocity halo, evp_finish are shared
+ * (:79-80), stress_eap (:1052-1467) with update_stress_rdg (:1474-1658) takes the place of stress, stepa (:1664-1787, with
+ * calc_ffrac :1795-1864) evolves the structure tensor every tenth subcycle, and there is no stress fold at the end.
+ *
+ * evpk_eap_init switches the context to EAP: every later evpk_run / evpk_subcycle runs the eap loop.  It takes the six
+ * lookup tables init_eap builds on the host (:555-619; module arrays s11r ... s22s(nx_yield, ny_yield, na_yield), :36-39) and
+ * sets the structure tensor to isotropic (a11 = 1/2, a12 = 0, :529-551) as init_eap does.
+ * evpk_eap_upload moves a11_1..4, a12_1..4 (the prognostic EAP state: restart, read_restart_eap :1908-2010) to the device
+ * (members that are NULL stay as they are); evpk_eap_download brings back any non-NULL member: physical cells and the N / E
+ * ghost T cells, as the reference computes them.
+ * sin, cos and atan2 inside update_stress_rdg / calc_ffrac are fixed algorithms (csrc/evpk_fmath.h, within 1-2 ulp of libm):
+ * the table indices depend on the last bit of an angle, so results agree with another math library except where an index
+ * falls on the other side of a table cell -- as between any two compilers of the reference. */
+typedef struct {
+    double *a11_c[4], *a12_c[4];      /* a11_1..4, a12_1..4: structure tensor at the corners ne, nw, sw, se (ice_dyn_eap.F90:40-41) */
+    double *a11, *a12;                /* out: cell means (history, :55-56) */
+    double *e11, *e12, *e22;          /* out: strain rate tensor (:47-49) */
+    double *yieldstress11, *yieldstress12, *yieldstress22;      /* out (:50-52) */
+    double *s11, *s12, *s22;          /* out: stress tensor (:53-55) */
+} evpk_eap_state;
+int evpk_eap_init(evpk_ctx *c, int32_t nx_yield, int32_t ny_yield, int32_t na_yield, const double *s11r, const double *s12r,
+                  const double *s22r, const double *s11s, const double *s12s, const double *s22s);
+int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st);
+int evpk_eap_download(evpk_ctx *c, evpk_eap_state *st);
+
 /* The dynamics records of the reference's binary restart (source/ice_restart_driver.F90:122-176 dumpfile, :295-412
  * restartfile; io_binary/ice_restart.F90:641-684): uvel, vvel, strocnxT, strocnyT, stressp_1,3,2,4, stressm_1,3,2,4,
  * stress12_1,3,2,4, iceumask as real 0/1 -- 17 Fortran sequential unformatted records of the (nx_global, ny_global)

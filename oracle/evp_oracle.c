@@ -868,8 +868,9 @@ void orc_transport_upwind(const orc_geom *g, double dt, int narr, const double *
 /* ---------------------------------------------------------------------------
  * evp(dt)  (source/ice_dyn_evp.F90:68-510)
  * ------------------------------------------------------------------------- */
-void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_override,
-             int64_t counts[2], double *loop_seconds) {
+/* evp(dt) (ice_dyn_evp.F90:68-510) and, with e != NULL, eap(dt) (ice_dyn_eap.F90:66-486): the same driver around another stress */
+static void dyn_driver(const orc_geom *g, const orc_params *p, orc_fields *f, orc_eap_state *e, int nsub_override,
+                       int64_t counts[2], double *loop_seconds) {
     const int nx = g->nx_block, ny = g->ny_block, nb = g->nblocks;
     const size_t nn = (size_t)nx * ny, tot = nn * nb;
     double *waterx = calloc(tot, 8), *watery = calloc(tot, 8), *forcex = calloc(tot, 8), *forcey = calloc(tot, 8);
@@ -883,6 +884,10 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
         for (size_t k = 0; k < nn; k++) {
             f->rdg_conv[o + k] = c0; f->rdg_shear[o + k] = c0; f->divu[o + k] = c0;
             f->shear[o + k] = c0; f->prs_sig[o + k] = c0;
+            if (e) {                                                      /* ice_dyn_eap.F90:171-180 */
+                e->e11[o + k] = c0; e->e12[o + k] = c0; e->e22[o + k] = c0; e->s11[o + k] = c0; e->s12[o + k] = c0; e->s22[o + k] = c0;
+                e->yieldstress11[o + k] = c0; e->yieldstress12[o + k] = c0; e->yieldstress22[o + k] = c0;
+            }
         }
         orc_evp_prep1(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b],
                       f->aice + o, f->vice + o, f->vsno + o, f->tmask + o,
@@ -922,6 +927,10 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
                       f->strtltx + o, f->strtlty + o, f->strocnx + o, f->strocny + o,
                       f->strintx + o, f->strinty + o, waterx + o, watery + o, forcex + o, forcey + o,
                       sp, sm, s12, f->uvel_init + o, f->vvel_init + o, f->uvel + o, f->vvel + o, p);
+        if (e)                                                            /* structure tensor where there is no ice (ice_dyn_eap.F90:284-298) */
+            for (size_t k = 0; k < nn; k++)
+                if (f->icetmask[o + k] == 0)
+                    for (int c = 0; c < 4; c++) { e->a11[c][o + k] = 0.5; e->a12[c][o + k] = c0; }
         /* ice_strength (:291-301): an input (f->strength already holds it on physical cells) unless strength_mode = 1 */
         if (p->strength_mode)
             orc_ice_strength(nx, ny, g->ilo[b], g->ihi[b], g->jlo[b], g->jhi[b], icellt[b], indxti + o, indxtj + o,
@@ -968,6 +977,12 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
             for (int b = 0; b < nb; b++) {
                 size_t o = (size_t)b * nn;
                 for (int c = 0; c < 4; c++) { tsp[c] = f->stressp[c] + o; tsm[c] = f->stressm[c] + o; ts12[c] = f->stress12[c] + o; }
+                if (e)
+                    orc_eap_stress(nx, ny, ksub, p->ndte, icellt[b], indxti + o, indxtj + o, p->arlx1i, p->denom1,
+                                   f->uvel + o, f->vvel + o, f->dxt + o, f->dyt + o, f->dxhy + o, f->dyhx + o,
+                                   f->cxp + o, f->cyp + o, f->cxm + o, f->cym + o, f->tarear + o, f->strength + o, tsp, tsm, ts12,
+                                   f->shear + o, f->divu + o, f->prs_sig + o, f->rdg_conv + o, f->rdg_shear + o, strtmp, e, o);
+                else
                 orc_stress(nx, ny, ksub, p->ndte, icellt[b], indxti + o, indxtj + o,
                            f->uvel + o, f->vvel + o, f->dxt + o, f->dyt + o, f->dxhy + o, f->dyhx + o,
                            f->cxp + o, f->cyp + o, f->cxm + o, f->cym + o, f->tarear + o, f->tinyarea + o,
@@ -978,6 +993,8 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
                           umassdti + o, f->fm + o, f->uarear + o, f->strocnx + o, f->strocny + o,
                           f->strintx + o, f->strinty + o, f->uvel_init + o, f->vvel_init + o,
                           f->uvel + o, f->vvel + o, p);
+                if (e && ksub % 10 == 1)                                  /* ice_dyn_eap.F90:411-426 */
+                    orc_eap_stepa(nx, ny, p->dtei, icellt[b], indxti + o, indxtj + o, tsp, tsm, ts12, e, o);
             }
         }
         const double th = wall();
@@ -994,7 +1011,7 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
     for (int t = 0; t < nthr; t++) free(strbuf[t]);
     free(strbuf);
 
-    if (g->ns_boundary == ORC_BND_TRIPOLE) {                              /* :416-481 */
+    if (g->ns_boundary == ORC_BND_TRIPOLE && !e) {                        /* :416-481 (eap has no stress fold) */
         double **S[3] = { f->stressp, f->stressm, f->stress12 };
         for (int t = 0; t < 3; t++) {
             orc_halo_stress(g, S[t][0], S[t][2]);
@@ -1022,4 +1039,12 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
 
     free(waterx); free(watery); free(forcex); free(forcey); free(umassdti); free(work1);
     free(indxti); free(indxtj); free(indxui); free(indxuj); free(icellt); free(icellu);
+}
+
+void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_override, int64_t counts[2], double *loop_seconds) {
+    dyn_driver(g, p, f, NULL, nsub_override, counts, loop_seconds);
+}
+
+void orc_eap(const orc_geom *g, const orc_params *p, orc_fields *f, orc_eap_state *e, int nsub_override, int64_t counts[2], double *loop_seconds) {
+    dyn_driver(g, p, f, e, nsub_override, counts, loop_seconds);
 }

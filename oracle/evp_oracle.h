@@ -20,6 +20,7 @@
  */
 #ifndef EVP_ORACLE_H
 #define EVP_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -84,6 +85,16 @@ typedef struct {
     double *aiu, *umass, *uvel_init, *vvel_init;
     int32_t *icetmask;
 } orc_fields;
+
+/* EAP (kdyn = 2, source/ice_dyn_eap.F90): lookup tables of init_eap (:555-619), the structure tensor (restart state) and the
+ * history fields.  Tables: Fortran s11r(nx_yield, ny_yield, na_yield), i.e. C order [na][ny][nx]. */
+typedef struct {
+    int32_t nx_yield, ny_yield, na_yield, pad_;
+    const double *s11r, *s12r, *s22r, *s11s, *s12s, *s22s;
+    double *a11[4], *a12[4];             /* in/out: a11_1..4, a12_1..4 (ne, nw, sw, se) */
+    double *a11m, *a12m;                 /* out: a11, a12 (cell means) */
+    double *e11, *e12, *e22, *yieldstress11, *yieldstress12, *yieldstress22, *s11, *s12, *s22;   /* out */
+} orc_eap_state;
 
 void orc_set_evp_parameters(double dt, int32_t ndte, int32_t revised_evp, double xmin, orc_params *p);
 
@@ -192,4 +203,17 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
 #ifdef __cplusplus
 }
 #endif
+/* eap(dt) (ice_dyn_eap.F90:66-486): evp's driver with stress_eap for stress, stepa every tenth subcycle, no stress fold */
+void orc_eap(const orc_geom *g, const orc_params *p, orc_fields *f, orc_eap_state *e, int nsub_override, int64_t counts[2], double *loop_seconds);
+void orc_eap_stress(int nx, int ny, int ksub, int ndte, int icellt, const int32_t *indxti, const int32_t *indxtj, double arlx1i, double denom1,
+                    const double *uvel, const double *vvel, const double *dxt, const double *dyt, const double *dxhy, const double *dyhx,
+                    const double *cxp, const double *cyp, const double *cxm, const double *cym, const double *tarear, const double *strength,
+                    double *const stressp[4], double *const stressm[4], double *const stress12[4], double *shear, double *divu,
+                    double *prs_sig, double *rdg_conv, double *rdg_shear, double *str, const orc_eap_state *e, size_t off);
+void orc_eap_stepa(int nx, int ny, double dtei, int icellt, const int32_t *indxti, const int32_t *indxtj,
+                   double *const stressp[4], double *const stressm[4], double *const stress12[4], const orc_eap_state *e, size_t off);
+double orc_fm_sin(double x);
+double orc_fm_cos(double x);
+double orc_fm_atan2(double y, double x);
+
 #endif

@@ -61,12 +61,22 @@ class OrcFields(ct.Structure):
                 [(n, c_f64p) for n in _F64_OUT] + [("icetmask", c_i32p)])
 
 
+EAP_OUT = ["e11", "e12", "e22", "yieldstress11", "yieldstress12", "yieldstress22", "s11", "s12", "s22"]
+
+
+class OrcEapState(ct.Structure):
+    _fields_ = ([("nx_yield", ct.c_int32), ("ny_yield", ct.c_int32), ("na_yield", ct.c_int32), ("pad_", ct.c_int32)] +
+                [(n, c_f64p) for n in ("s11r", "s12r", "s22r", "s11s", "s12s", "s22s")] +
+                [("a11", c_f64p * 4), ("a12", c_f64p * 4), ("a11m", c_f64p), ("a12m", c_f64p)] + [(n, c_f64p) for n in EAP_OUT])
+
+
 HALO_CB = ct.CFUNCTYPE(None, c_f64p, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_void_p)
 
 
 def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, n)) for n in ("evp_oracle.c", "remap_oracle.c", "evp_oracle.h")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, n)) for n in ("evp_oracle.c", "remap_oracle.c", "eap_oracle.c", "evp_oracle.h")) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "..", "cice5_amd", "csrc", "evpk_fmath.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libevp_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -101,6 +111,13 @@ def lib():
         _lib.orc_set_evp_parameters.argtypes = [ct.c_double, ct.c_int32, ct.c_int32, ct.c_double, ct.POINTER(OrcParams)]
         _lib.orc_evp.argtypes = [ct.POINTER(OrcGeom), ct.POINTER(OrcParams), ct.POINTER(OrcFields), ct.c_int,
                                  ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double)]      # loop_seconds[2]
+        _lib.orc_eap.argtypes = [ct.POINTER(OrcGeom), ct.POINTER(OrcParams), ct.POINTER(OrcFields), ct.POINTER(OrcEapState), ct.c_int,
+                                 ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double)]
+        for n in ("orc_fm_sin", "orc_fm_cos"):
+            getattr(_lib, n).argtypes = [ct.c_double]
+            getattr(_lib, n).restype = ct.c_double
+        _lib.orc_fm_atan2.argtypes = [ct.c_double, ct.c_double]
+        _lib.orc_fm_atan2.restype = ct.c_double
         _lib.orc_halo_r8.argtypes = [ct.POINTER(OrcGeom), c_f64p, ct.c_int, ct.c_int, ct.c_double]
         _lib.orc_halo_i4.argtypes = [ct.POINTER(OrcGeom), c_i32p, ct.c_int32]
         _lib.orc_transport_upwind.argtypes = [ct.POINTER(OrcGeom), ct.c_double, ct.c_int] + [c_f64p] * 6
@@ -179,6 +196,28 @@ def evp(d, params: OrcParams, f: Dict[str, np.ndarray], nsub: int = 0):
     del keep
     global last_halo_seconds
     last_halo_seconds = float(secs[1])          # the halo updates' share of the loop time returned below
+    return int(counts[0]), int(counts[1]), float(secs[0])
+
+
+def eap(d, params: OrcParams, f: Dict[str, np.ndarray], tables, nsub: int = 0):
+    """orc_eap: eap(dt) (ice_dyn_eap.F90:66-486) in place on `f`, which also holds a11_1..4, a12_1..4 (in/out), a11, a12 and
+    the nine history fields (cice5_amd.synth.add_eap_state); tables = oracle.eap_tables.eap_tables()"""
+    g, keep = make_geom(d)
+    of = make_fields(f)
+    e = OrcEapState()
+    e.na_yield, e.ny_yield, e.nx_yield = tables[0].shape
+    for n, t in zip(("s11r", "s12r", "s22r", "s11s", "s12s", "s22s"), tables):
+        assert t.flags["C_CONTIGUOUS"] and t.dtype == np.float64
+        setattr(e, n, _p64(t))
+    e.a11 = (c_f64p * 4)(*[_p64(f[f"a11_{c}"]) for c in (1, 2, 3, 4)])
+    e.a12 = (c_f64p * 4)(*[_p64(f[f"a12_{c}"]) for c in (1, 2, 3, 4)])
+    e.a11m, e.a12m = _p64(f["a11"]), _p64(f["a12"])
+    for n in EAP_OUT:
+        setattr(e, n, _p64(f[n]))
+    counts = (ct.c_int64 * 2)()
+    secs = (ct.c_double * 2)(0.0, 0.0)
+    lib().orc_eap(ct.byref(g), ct.byref(params), ct.byref(of), ct.byref(e), int(nsub), counts, secs)
+    del keep
     return int(counts[0]), int(counts[1]), float(secs[0])
 
 

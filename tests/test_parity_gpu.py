@@ -912,6 +912,86 @@ def test_transport_remap_after_an_evp():
     assert np.array_equal(mg, mo) and np.array_equal(tg, to)
 
 
+EAP_NE = [f"a11_{c}" for c in (1, 2, 3, 4)] + [f"a12_{c}" for c in (1, 2, 3, 4)] + list(evpk.EAP_HISTORY)
+
+
+def _eap_both(ns, bs, ndte, calls=1, nx=100, ny=116, revised=False):
+    from oracle.eap_tables import eap_tables
+    T = eap_tables()
+    case, d, f = util.make_case(nx, ny, *bs, ns=ns, land="continents")
+    synth.add_eap_state(f)
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, ndte, xmin, revised_evp=revised) if revised else orc.make_params(3600.0, ndte, xmin)
+    s = dyn.EvpDynamics(d, fg, ndte=ndte, xmin=xmin, revised_evp=revised)
+    s.init_eap(3600.0, T)
+    ne = util.cell_mask(d, "ne")
+    bad = []
+    for call in range(calls):
+        if call:
+            for ff in (fo, fg):
+                ff["aice"] *= 0.9; ff["vice"] *= 0.9
+                ff["strairxT"], ff["strairyT"] = ff["strairyT"].copy(), -ff["strairxT"]
+                ff["aice"][:, :, : ff["aice"].shape[2] // 3] = 0.0          # ice disappears from a third of the domain
+                ff["vice"][:, :, : ff["aice"].shape[2] // 3] = 0.0
+                for n in ("aice", "vice"):
+                    orc.halo_r8(d, ff[n], C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+        orc.eap(d, p, fo, T)
+        s.eap(3600.0)
+        bad += [(call,) + x for x in util.compare(d, fg, fo)]
+        for n in EAP_NE:
+            if not np.array_equal(fg[n][ne], fo[n][ne]):
+                bad.append((call, n, int((fg[n][ne] != fo[n][ne]).sum()), float(np.abs(fg[n][ne] - fo[n][ne]).max())))
+    s.close()
+    return fo, fg, bad
+
+
+@pytest.mark.parametrize("ns,bs,ndte", [("open", (100, 116), 120), ("open", (25, 29), 31), ("tripole", (50, 58), 40), ("tripole", (20, 29), 25)])
+def test_eap_matches_the_oracle(ns, bs, ndte):
+    """eap(dt) (ice_dyn_eap.F90:66-486) -- stress_eap with its table lookups, stepu, stepa every tenth
+    subcycle, the velocity halo, no stress fold -- against the oracle's restatement, bit for bit: velocities, the twelve
+    stresses, the structure tensor, the history fields and everything evp_finish leaves; BASELINE config 1's shape"""
+    fo, fg, bad = _eap_both(ns, bs, ndte)
+    assert not bad, bad[:8]
+    assert np.abs(fo["a11_1"] - 0.5).max() > 0.05 and np.abs(fo["uvel"]).max() > 1e-3        # the anisotropy did evolve
+    assert np.abs(fo["yieldstress12"]).max() > 0 and np.abs(fo["rdg_conv"]).max() > 0
+
+
+def test_eap_three_calls_with_ice_that_disappears():
+    """the structure tensor stays on the device between calls and is reset to isotropic where icetmask = 0 (:284-298)"""
+    fo, fg, bad = _eap_both("tripole", (25, 29), 22, calls=3)
+    assert not bad, bad[:8]
+    assert (fo["a11_1"] == 0.5).any() and (fo["a11_1"] != 0.5).any()
+
+
+def test_eap_structure_tensor_from_a_restart():
+    """evpk_eap_upload: a11_1..4, a12_1..4 from the host (read_restart_eap, :1908-2010) before the first call"""
+    from oracle.eap_tables import eap_tables
+    T = eap_tables()
+    case, d, f = util.make_case(100, 116, 50, 58, ns="open", land="continents")
+    synth.add_eap_state(f)
+    rng = np.random.default_rng(3)
+    for c in (1, 2, 3, 4):
+        f[f"a11_{c}"] = rng.uniform(0.3, 0.7, f["uvel"].shape)
+        f[f"a12_{c}"] = rng.uniform(-0.2, 0.2, f["uvel"].shape)
+        for n in (f"a11_{c}", f"a12_{c}"):
+            orc.halo_r8(d, f[n], C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    orc.eap(d, orc.make_params(3600.0, 30, xmin), fo, T)
+    s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+    s.set_evp_parameters(3600.0)
+    s.ctx.eap_init(T)
+    s._eap = True
+    s.ctx.eap_upload(fg)
+    s.eap(3600.0)
+    s.close()
+    ne = util.cell_mask(d, "ne")
+    assert not util.compare(d, fg, fo)
+    for n in EAP_NE:
+        assert np.array_equal(fg[n][ne], fo[n][ne]), n
+
+
 def test_caller_arrays_in_device_memory():
     """A host model whose fields already live on the GPU passes device pointers in place of host arrays (same block
     layout): the library reads and writes them in place.  Here the arrays are torch tensors on the device."""
