@@ -1555,6 +1555,7 @@ extern "C" int evpk_eap_init(evpk_ctx *c, int32_t nx_yield, int32_t ny_yield, in
         c->E.tab[q] = c->eap_tab + q * nt;
     }
     c->E.nxy = nx_yield; c->E.nyy = ny_yield; c->E.nay = na_yield;
+    c->E.invsin = eap_invsin();
     if (!c->eap_pool) {
         HIPCHK(c, hipMalloc(&c->eap_pool, sizeof(double) * EAP_NPLANES * np));
         HIPCHK(c, hipMemsetAsync(c->eap_pool, 0, sizeof(double) * EAP_NPLANES * np, c->stream));

@@ -11,7 +11,7 @@
 // yieldstress11/12/22, s11, s12, s22 (history), str(8) (work).
 // sin / cos / atan2: the fixed algorithms of evpk_fmath.h, shared with the CPU checker (the table indices hang on their last bit).
 #pragma once
-#define EVPK_HD __device__ __forceinline__
+#define EVPK_HD __host__ __device__ __forceinline__
 #include "evpk_fmath.h"
 
 namespace evpk {
@@ -20,6 +20,7 @@ constexpr int EAP_NPLANES = 8 + 11 + 8;
 struct EapDev {
     const double *tab[6];                 // s11r, s12r, s22r, s11s, s12s, s22s: [na][ny][nx]
     int nxy, nyy, nay, pad_;
+    double invsin;                        // c1/sin(pi2/c12) * invstressconviso (:1524-1526), evaluated once on the host with the same evpk_sincos
     double *a11[4], *a12[4];
     double *hist[11];                     // a11, a12, e11, e12, e22, yieldstress11, yieldstress12, yieldstress22, s11, s12, s22
     double *str[8];
@@ -31,15 +32,21 @@ enum { EH_A11 = 0, EH_A12, EH_E11, EH_E12, EH_E22, EH_Y11, EH_Y12, EH_Y22, EH_S1
 #define EAP_PIQ (0.5 * (0.5 * EAP_PI))
 #define EAP_PUNY 1.0e-11
 
+// c1/sin(pi2/c12) * invstressconviso, invstressconviso = c1/(c1 + kfriction*kfriction) (:1521-1526)
+static inline double eap_invsin() {
+    const double kfriction = 0.45;
+    const double invstressconviso = 1.0 / (1.0 + kfriction * kfriction);
+    double sn, cs;
+    evpk_sincos(EAP_PI2 / 12.0, &sn, &cs);
+    return 1.0 / sn * invstressconviso;
+}
+
 // ---- update_stress_rdg (:1474-1658) ----
 template <bool LAST>
 __device__ __forceinline__ void eap_update_stress_rdg(const EapDev &E, double divu, double tension, double shear, double a11, double a12, double strength,
                                                       double &stressp, double &stressm, double &stress12, double &alphar) {
     const double kfriction = 0.45;
-    const double invstressconviso = 1.0 / (1.0 + kfriction * kfriction);
-    double sn, cs;
-    evpk_sincos(EAP_PI2 / 12.0, &sn, &cs);
-    const double invsin = 1.0 / sn * invstressconviso;
+    const double invsin = E.invsin;
     const double a22 = 1.0 - a11;
     const double gamma = 0.5 * evpk_atan2((2.0 * a12), (a11 - a22));
     double Q11, Q12;

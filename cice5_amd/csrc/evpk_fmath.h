@@ -80,7 +80,7 @@ EVPK_HD double evpk_atan2(double y, double x) {
         a = hi + ((u + (u * z) * p) + lo);
         if (swap) a = EVPK_PIO2_HI - (a - EVPK_PIO2_LO);
     }
-    if (signbit(x)) a = EVPK_PI_HI - (a - EVPK_PI_LO);
+    if (ay == 0.0 ? signbit(x) : (x < 0.0)) a = EVPK_PI_HI - (a - EVPK_PI_LO);
     return copysign(a, y);
 }
 

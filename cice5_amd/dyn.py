@@ -137,9 +137,12 @@ class EvpDynamics:
         self.ctx.download(f)
 
     # ---- kdyn = 2: the elastic-anisotropic-plastic rheology (source/ice_dyn_eap.F90) ----
-    def init_eap(self, dt: float, tables):
-        """ice_dyn_eap.F90:493-621: init_evp, isotropic structure tensor, the lookup tables (an input here: `tables` as the
-        host's init_eap made them, [na_yield][ny_yield][nx_yield] each).  evp()/eap() of this object then run eap(dt)."""
+    def init_eap(self, dt: float, tables=None):
+        """ice_dyn_eap.F90:493-621: init_evp, isotropic structure tensor, the lookup tables (eap_tables.py, or `tables` as a
+        host's own init_eap made them, [na_yield][ny_yield][nx_yield] each).  evp()/eap() of this object then run eap(dt)."""
+        if tables is None:
+            from .eap_tables import eap_tables
+            tables = eap_tables()
         self.init_evp(dt)
         f = self.fields
         for c in (1, 2, 3, 4):

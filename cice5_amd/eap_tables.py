@@ -1,7 +1,7 @@
-"""Lookup tables of the EAP rheology as init_eap builds them (source/ice_dyn_eap.F90:555-619, functions w1, w2, s11kr ... s22ks
-:626-1046), restated with numpy for the tests: TEST INFRASTRUCTURE (an input of both the checker and the kernels -- a host
-model passes the tables its own init_eap made).  Returned as C arrays [na_yield][ny_yield][nx_yield], i.e. the memory layout of
-the Fortran s11r(nx_yield, ny_yield, na_yield)."""
+"""Host-side mirror of the table part of init_eap (source/ice_dyn_eap.F90:555-619, functions w1, w2, s11kr ... s22ks :626-1046):
+the six lookup tables of the EAP rheology, with numpy.  They are an INPUT of libevpk (evpk_eap_init) -- a Fortran host passes
+the module arrays its own init_eap filled; this is the same step for the Python mirror (dyn.EvpDynamics.init_eap).  Returned as
+C arrays [na_yield][ny_yield][nx_yield], i.e. the memory layout of the Fortran s11r(nx_yield, ny_yield, na_yield)."""
 import numpy as np
 
 NX_YIELD, NY_YIELD, NA_YIELD = 41, 41, 21        # :31-34

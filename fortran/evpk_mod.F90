@@ -85,13 +85,23 @@
          integer (c_int32_t) :: bound_updates, compact_metrics, transport, reserved_
       end type evpk_stats
 
+      ! evpk_eap_state (include/evpk.h): the structure tensor at the four corners, its cell means, the EAP history fields
+      type, bind(C) :: evpk_eap_state
+         type (c_ptr) :: a11_c(4) = c_null_ptr, a12_c(4) = c_null_ptr
+         type (c_ptr) :: a11 = c_null_ptr, a12 = c_null_ptr
+         type (c_ptr) :: e11 = c_null_ptr, e12 = c_null_ptr, e22 = c_null_ptr
+         type (c_ptr) :: yieldstress11 = c_null_ptr, yieldstress12 = c_null_ptr, yieldstress22 = c_null_ptr
+         type (c_ptr) :: s11 = c_null_ptr, s12 = c_null_ptr, s22 = c_null_ptr
+      end type evpk_eap_state
+
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &
                 evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string, &
                 evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
                 evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
                 evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read, &
                 evpk_transport_upwind, evpk_remap_init, evpk_transport_remap, &
-                EVPK_REMAP_BAD_DEPARTURE, EVPK_REMAP_NEGATIVE_MASS
+                EVPK_REMAP_BAD_DEPARTURE, EVPK_REMAP_NEGATIVE_MASS, &
+                evpk_eap_state, evpk_eap_init, evpk_eap_upload, evpk_eap_download
 
       integer (c_int), parameter :: EVPK_REMAP_BAD_DEPARTURE = 11, EVPK_REMAP_NEGATIVE_MASS = 12     ! include/evpk.h
 
@@ -208,6 +218,24 @@
             integer (c_int32_t), value :: ncat, ntrace
             type (c_ptr), value :: mm, tm, tracer_type, depend, has_dependents
             integer (c_int32_t), value :: integral_order, l_dp_midpt, l_fixed_area
+         end function
+         ! EAP (ice_dyn_eap.F90): tables of init_eap once, then the context runs eap(dt); structure tensor up / everything down
+         integer (c_int) function evpk_eap_init (ctx, nx_yield, ny_yield, na_yield, s11r, s12r, s22r, s11s, s12s, s22s) &
+               bind(C, name='evpk_eap_init')
+            import :: c_int, c_ptr, c_int32_t
+            type (c_ptr), value :: ctx
+            integer (c_int32_t), value :: nx_yield, ny_yield, na_yield
+            type (c_ptr), value :: s11r, s12r, s22r, s11s, s12s, s22s
+         end function
+         integer (c_int) function evpk_eap_upload (ctx, st) bind(C, name='evpk_eap_upload')
+            import :: c_int, c_ptr, evpk_eap_state
+            type (c_ptr), value :: ctx
+            type (evpk_eap_state), intent(in) :: st
+         end function
+         integer (c_int) function evpk_eap_download (ctx, st) bind(C, name='evpk_eap_download')
+            import :: c_int, c_ptr, evpk_eap_state
+            type (c_ptr), value :: ctx
+            type (evpk_eap_state), intent(in) :: st
          end function
          integer (c_int) function evpk_destroy (ctx) bind(C, name='evpk_destroy')
             import :: c_int, c_ptr

@@ -40,7 +40,7 @@
       public :: evpk_resident_state, evpk_state_changed_on_host, evpk_device_strength
       public :: evpk_bound_seconds, evpk_loop_seconds
       public :: evpk_download_all, evpk_sparse_io
-      public :: evpk_horizontal_remap
+      public :: evpk_horizontal_remap, evpk_eap
       save
 
       ! .true. (default): every array the reference's evp leaves modified comes back every call.  .false. (with
@@ -517,6 +517,67 @@
       if (rc /= 0) call abort_ice('horizontal_remap: evpk_transport_remap: '//trim(evpk_error_string(ctx)))
 
       end subroutine evpk_horizontal_remap
+
+!=======================================================================
+! eap(dt) (reference: ice_dyn_eap.F90:66-486) on the device.  The lookup tables and the structure tensor are private to the
+! reference's module ice_dyn_eap, so the call comes from inside it: the body of its `subroutine eap (dt)` becomes
+!
+!     use ice_dyn_evp, only: evpk_eap
+!     call evpk_eap (dt, nx_yield, ny_yield, na_yield, s11r, s12r, s22r, s11s, s12s, s22s, &
+!                    a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12,    &
+!                    e11, e12, e22, yieldstress11, yieldstress12, yieldstress22, s11, s12, s22)
+!
+! (INTEGRATION.md S3; tests/test_ref_interfaces.py compiles the reference's module edited that way).  init_eap, the restart
+! routines and the module variables stay the reference's.  Everything evp(dt) of this module does for kdyn = 1 -- inputs up,
+! ice_strength on the host, the loop and evp_finish on the device, outputs down -- is shared; the structure tensor lives on the
+! device between calls (uploaded at the first call and after a restart read: evpk_state_changed_on_host).
+
+      subroutine evpk_eap (dt, nx_yield, ny_yield, na_yield, s11r, s12r, s22r, s11s, s12s, s22s, &
+                           a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12,    &
+                           e11, e12, e22, yieldstress11, yieldstress12, yieldstress22, s11, s12, s22)
+
+      use ice_blocks, only: nx_block, ny_block
+      use ice_domain_size, only: max_blocks
+      use ice_exit, only: abort_ice
+
+      real (kind=dbl_kind), intent(in) :: dt
+      integer (kind=int_kind), intent(in) :: nx_yield, ny_yield, na_yield
+      real (kind=dbl_kind), dimension (nx_yield,ny_yield,na_yield), intent(in), target :: &
+         s11r, s12r, s22r, s11s, s12s, s22s
+      real (kind=dbl_kind), dimension (nx_block,ny_block,max_blocks), intent(inout), target :: &
+         a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12, &
+         e11, e12, e22, yieldstress11, yieldstress12, yieldstress22, s11, s12, s22
+
+      type (evpk_eap_state) :: es
+      integer (c_int) :: rc
+      logical (kind=log_kind) :: push
+      logical (kind=log_kind), save :: first = .true.
+
+      if (.not. ctx_ready) call evpk_setup
+      if (first) then
+         rc = evpk_eap_init (ctx, int(nx_yield, c_int32_t), int(ny_yield, c_int32_t), int(na_yield, c_int32_t), &
+                             loc_r8(s11r), loc_r8(s12r), loc_r8(s22r), loc_r8(s11s), loc_r8(s12s), loc_r8(s22s))
+         if (rc /= 0) call abort_ice('eap: evpk_eap_init: '//trim(evpk_error_string(ctx)))
+      endif
+      push = first .or. evpk_state_changed_on_host       ! (evp below clears the flag)
+      first = .false.
+      es%a11_c(1) = loc_r8(a11_1);  es%a11_c(2) = loc_r8(a11_2);  es%a11_c(3) = loc_r8(a11_3);  es%a11_c(4) = loc_r8(a11_4)
+      es%a12_c(1) = loc_r8(a12_1);  es%a12_c(2) = loc_r8(a12_2);  es%a12_c(3) = loc_r8(a12_3);  es%a12_c(4) = loc_r8(a12_4)
+      es%a11 = loc_r8(a11);  es%a12 = loc_r8(a12)
+      es%e11 = loc_r8(e11);  es%e12 = loc_r8(e12);  es%e22 = loc_r8(e22)
+      es%yieldstress11 = loc_r8(yieldstress11);  es%yieldstress12 = loc_r8(yieldstress12);  es%yieldstress22 = loc_r8(yieldstress22)
+      es%s11 = loc_r8(s11);  es%s12 = loc_r8(s12);  es%s22 = loc_r8(s22)
+      if (push) then
+         rc = evpk_eap_upload (ctx, es)
+         if (rc /= 0) call abort_ice('eap: evpk_eap_upload: '//trim(evpk_error_string(ctx)))
+      endif
+
+      call evp (dt)          ! the context is in EAP mode since evpk_eap_init: prep, the eap loop, finish
+
+      rc = evpk_eap_download (ctx, es)
+      if (rc /= 0) call abort_ice('eap: evpk_eap_download: '//trim(evpk_error_string(ctx)))
+
+      end subroutine evpk_eap
 
 !=======================================================================
 

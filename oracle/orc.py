@@ -201,7 +201,7 @@ def evp(d, params: OrcParams, f: Dict[str, np.ndarray], nsub: int = 0):
 
 def eap(d, params: OrcParams, f: Dict[str, np.ndarray], tables, nsub: int = 0):
     """orc_eap: eap(dt) (ice_dyn_eap.F90:66-486) in place on `f`, which also holds a11_1..4, a12_1..4 (in/out), a11, a12 and
-    the nine history fields (cice5_amd.synth.add_eap_state); tables = oracle.eap_tables.eap_tables()"""
+    the nine history fields (cice5_amd.synth.add_eap_state); tables = cice5_amd.eap_tables.eap_tables()"""
     g, keep = make_geom(d)
     of = make_fields(f)
     e = OrcEapState()

@@ -60,11 +60,21 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
         xmin = synth.global_min_dx(case)
         xp = env.get("TEST_XP", "shm")
         uid = ({"shm": b"EVPKSHM:", "ipc": b"EVPKIPC:"}[xp] + tag.encode()).ljust(128, b"\0")
+        eap = bool(env.get("TEST_EAP"))
+        if eap:                                   # kdyn = 2: the same slabs, exchange and fold around stress_eap / stepa
+            from cice5_amd.eap_tables import eap_tables
+            T = eap_tables()
+            synth.add_eap_state(f)
         s = dyn.EvpDynamics(d, f, ndte=ndte, xmin=xmin, device=0, unique_id=uid)
-        s.init_evp(3600.0)
+        if eap:
+            s.init_eap(3600.0, T)
+        else:
+            s.init_evp(3600.0)
         # reference: whole domain, same block size, in this process
         d1 = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns)
         f1 = synth.make_block_fields(case, d1)
+        if eap:
+            synth.add_eap_state(f1)
         p = orc.make_params(3600.0, ndte, xmin)
         bad = []
         ncalls = int(env.get("TEST_WANDER_CALLS", "0"))
@@ -78,14 +88,24 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
                     ff["aice"] *= 0.97
                     ff["vice"] *= 0.97
                     ff["strairxT"], ff["strairyT"] = ff["strairyT"].copy(), -ff["strairxT"]
-            s.evp(3600.0)
-            orc.evp(d1, p, f1)
+            if eap:
+                s.eap(3600.0)
+                orc.eap(d1, p, f1, T)
+            else:
+                s.evp(3600.0)
+                orc.evp(d1, p, f1)
             ref = {}
             for n, b in enumerate(d.local_blocks):
                 n1 = next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id)
                 for name in util.ALL_CELLS + util.NE_CELLS + util.PHYS_CELLS:
                     ref.setdefault(name, np.zeros_like(f[name]))[n] = f1[name][n1]
             bad += [(call,) + x for x in util.compare(d, f, ref)]
+            if eap:
+                ne = util.cell_mask(d, "ne")
+                for name in synth.EAP_STATE + synth.EAP_HISTORY:
+                    r = np.stack([f1[name][next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id)] for b in d.local_blocks])
+                    if not np.array_equal(f[name][ne], r[ne]):
+                        bad.append((call, name, int((f[name][ne] != r[ne]).sum())))
         if env.get("TEST_UPWIND"):
             # transport_upwind (row f-3) on the slab's resident velocities: its edge-velocity halos go through the same
             # exchange machinery (E-W ring, tripole fold of E-face / N-face fields with the mirror ranks)
@@ -242,6 +262,14 @@ def test_transport_upwind_across_slabs(ns, world):
 @pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 2, "ipc"), ("tripole", 4, "shm"), ("tripole", 3, "ipc")])
 def test_transport_remap_across_slabs(ns, world, xp):
     _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_REMAP": "1"}, xp=xp)
+
+
+@pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 2, "ipc"), ("tripole", 4, "shm")])
+def test_eap_across_slabs(ns, world, xp):
+    """kdyn = 2 on x-slabs: the velocity halo of every subcycle through the exchange machinery, T-cell state (stresses,
+    structure tensor) redundant on the shared ghost T column, as the reference's blocks have it"""
+    res = _run(world, ns, 240, 64, 20, 32, ndte=22, env={"TEST_EAP": "1"}, xp=xp)
+    assert all(r[3] == 0 for r in res)          # no two-subcycle EVP launches
 
 
 def test_x_slabs_one_subcycle_kernel_and_serial_exchange():

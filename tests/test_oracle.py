@@ -381,6 +381,58 @@ def test_remap_decomposition_invariance(ns):
                     assert np.array_equal(x, y), bs
 
 
+def test_fmath_sin_cos_atan2_within_two_ulp_of_libm():
+    """cice5_amd/csrc/evpk_fmath.h (the fixed sin / cos / atan2 the EAP kernels and their checker share): against libm at
+    most 1 ulp (sin, cos over the range of the EAP angles) and 2 ulp (atan2); the signed zeros of atan2 as C99 Annex F"""
+    import math
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    ulp = lambda v: np.spacing(abs(v)) if v != 0 else 5e-324
+    ws = wc = wa = 0.0
+    for x in np.concatenate([rng.uniform(-5.0, 2.0, 40000), [0.0, -0.0, math.pi / 2, -math.pi, math.pi / 4, 1e-300, -1.5 * math.pi]]):
+        x = float(x)
+        ws = max(ws, abs(L.orc_fm_sin(x) - math.sin(x)) / ulp(math.sin(x)))
+        wc = max(wc, abs(L.orc_fm_cos(x) - math.cos(x)) / ulp(math.cos(x)))
+    for y, x in zip(rng.normal(size=40000) * 10.0 ** rng.integers(-6, 6, 40000), rng.normal(size=40000) * 10.0 ** rng.integers(-6, 6, 40000)):
+        y, x = float(y), float(x)
+        wa = max(wa, abs(L.orc_fm_atan2(y, x) - math.atan2(y, x)) / ulp(math.atan2(y, x)))
+    assert ws <= 1.0 and wc <= 1.0 and wa <= 2.0, (ws, wc, wa)
+    for y, x in [(0.0, 0.0), (-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0), (1.0, 0.0), (-1.0, -0.0), (0.0, 3.0), (-0.0, -3.0), (2.0, 2.0), (-2.0, -2.0)]:
+        a, b = L.orc_fm_atan2(y, x), math.atan2(y, x)
+        assert a == b and math.copysign(1.0, a) == math.copysign(1.0, b), (y, x, a, b)
+
+
+def test_eap_tables_and_one_step():
+    """the lookup tables of init_eap (symmetries of the yield curve) and eap(dt): the structure tensor stays a tensor of a
+    distribution (1/2 <= largest principal value <= 1), an isotropic start stays isotropic without ice, the stresses the
+    tables give are bounded by the ice strength, and one block equals many blocks bit for bit"""
+    from cice5_amd.eap_tables import eap_tables
+    T = eap_tables()
+    s11r, s12r, s22r, s11s, s12s, s22s = T
+    assert all(t.shape == (21, 41, 41) for t in T)
+    assert np.abs(s11r).max() < 1.0 and np.abs(s22r).max() < 1.0 and np.abs(s12r).max() <= 0.5 + 1e-12       # ridging part: |sigma| <= 1 in units of P sin(2 phi)
+    assert (s11r <= 1e-12 + 0.12).all() and s11r.min() < -0.5                                                # mostly compressive
+    out = {}
+    for bs in [(48, 40), (12, 10)]:
+        case, d, f = util.make_case(48, 40, *bs, ns="tripole", land="continents")
+        synth.add_eap_state(f)
+        p = orc.make_params(3600.0, 40, synth.global_min_dx(case))
+        orc.eap(d, p, f, T)
+        out[bs] = {n: blocks.gather_global(d, f[n]) for n in ["uvel", "vvel", "a11_1", "a12_3", "a11", "e11", "s12", "yieldstress11", "stressp_2", "rdg_conv"]}
+        if bs == (48, 40):
+            for c in (1, 2, 3, 4):
+                a11, a12 = f[f"a11_{c}"], f[f"a12_{c}"]
+                lam = 0.5 + np.sqrt((a11 - 0.5) ** 2 + a12 ** 2)            # largest principal value of [[a11, a12], [a12, 1 - a11]]
+                assert (lam <= 1.0 + 1e-12).all() and (lam >= 0.5).all()
+                noice = f["icetmask"] == 0
+                assert (a11[noice] == 0.5).all() and (a12[noice] == 0.0).all()
+            assert np.abs(f["a11_1"] - 0.5).max() > 0.02
+            sig = np.abs(f["stressp_1"])
+            assert (sig <= 4.0 * f["strength"] + 1e-9).all()
+    for n, a in out[(48, 40)].items():
+        assert np.array_equal(a, out[(12, 10)][n]), n
+
+
 def test_principal_stress():
     import ctypes as ct
     nx = ny = 4

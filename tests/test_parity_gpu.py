@@ -916,7 +916,7 @@ EAP_NE = [f"a11_{c}" for c in (1, 2, 3, 4)] + [f"a12_{c}" for c in (1, 2, 3, 4)]
 
 
 def _eap_both(ns, bs, ndte, calls=1, nx=100, ny=116, revised=False):
-    from oracle.eap_tables import eap_tables
+    from cice5_amd.eap_tables import eap_tables
     T = eap_tables()
     case, d, f = util.make_case(nx, ny, *bs, ns=ns, land="continents")
     synth.add_eap_state(f)
@@ -966,7 +966,7 @@ def test_eap_three_calls_with_ice_that_disappears():
 
 def test_eap_structure_tensor_from_a_restart():
     """evpk_eap_upload: a11_1..4, a12_1..4 from the host (read_restart_eap, :1908-2010) before the first call"""
-    from oracle.eap_tables import eap_tables
+    from cice5_amd.eap_tables import eap_tables
     T = eap_tables()
     case, d, f = util.make_case(100, 116, 50, 58, ns="open", land="continents")
     synth.add_eap_state(f)

@@ -68,3 +68,34 @@ def test_transport_driver_compiles_against_the_shims_horizontal_remap(tmp_path):
     rc.compile(str(edited), True)
     assert os.path.exists(os.path.join(rc.mods, "ice_transport_driver.mod"))
 
+
+EAP_BODY = """      subroutine eap (dt)
+      use ice_dyn_evp, only: evpk_eap
+      real (kind=dbl_kind), intent(in) :: dt
+      call evpk_eap (dt, nx_yield, ny_yield, na_yield, s11r, s12r, s22r, s11s, s12s, s22s, &
+                     a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12,    &
+                     e11, e12, e22, yieldstress11, yieldstress12, yieldstress22, s11, s12, s22)
+      end subroutine eap
+"""
+
+
+def test_reference_eap_module_compiles_with_its_eap_body_replaced_by_the_shim_call(tmp_path):
+    """source/ice_dyn_eap.F90 with the body of `subroutine eap (dt)` (:66-486) replaced by the call INTEGRATION.md shows:
+    the module's own private tables and structure tensor match evpk_eap's dummies; ice_step_mod.F90 (`use ice_dyn_eap, only:
+    eap`, :1084) then compiles against the edited module.  The edited text exists in the scratch directory only."""
+    rc = R.RefCompile(str(tmp_path), [])
+    rc.need("ice_dyn_evp", include_top=False)
+    rc.compile(os.path.join(ROOT, "fortran", "evpk_mod.F90"), True)
+    rc.compile(os.path.join(ROOT, "fortran", "ice_dyn_evp.F90"), True)
+    rc.need("ice_dyn_eap", include_top=False, skip={"ice_dyn_evp"})
+    lines = open(os.path.join(R.REF, "source", "ice_dyn_eap.F90")).read().split("\n")
+    a = next(k for k, l in enumerate(lines) if l.strip().lower().startswith("subroutine eap (dt)"))
+    b = next(k for k, l in enumerate(lines) if l.strip().lower().startswith("end subroutine eap"))
+    assert 60 < a < 70 and 480 < b < 490
+    edited = tmp_path / "ice_dyn_eap_edited.F90"
+    edited.write_text("\n".join(lines[:a]) + "\n" + EAP_BODY + "\n".join(lines[b + 1:]) + "\n")
+    rc.compile(str(edited), True)
+    assert os.path.exists(os.path.join(rc.mods, "ice_dyn_eap.mod"))
+    rc.need("ice_step_mod", skip={"ice_dyn_evp", "ice_dyn_eap"})
+    assert os.path.join(R.REF, "source", "ice_step_mod.F90") in rc.done
+
