@@ -112,3 +112,74 @@ def test_random_configuration(seed, monkeypatch):
         bad = util.compare(d, fg, fo)
         assert not bad, (desc, call, bad[:4])
     s.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_R_N", "24"))))
+def test_random_remap_configuration(seed, monkeypatch):
+    """horizontal_remap (row f-3) on random grids / decompositions / boundaries / tracer trees / options, one rank, also through
+    the general halo path: bit-identical with the oracle"""
+    from cice5_amd import evpk
+    k = _config(seed + 500)
+    rng = k["rng"]
+    if rng.random() < 0.4:
+        monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+    nx, ny = max(k["nx"], 12), max(k["ny"], 12)
+    nx += (k["ns"] == "tripole") and (nx & 1)
+    trees = [(0, 1, 2 + 1), (0, 1, 2 + 1, 2 + 2), (1, 1, 2), (0,), (), (0, 2 + 1, 2 + 2, 1, 2 + 4)]
+    dep = trees[int(rng.integers(len(trees)))]
+    case, d, f, mm, tm, tables = util.remap_case(nx, ny, min(k["bsx"], nx), min(k["bsy"], ny), ns=k["ns"], ew=k["ew"], land=k["land"],
+                                                 ncat=int(rng.integers(1, 5)), trcr_depend=dep)
+    order, midpt = int(rng.integers(1, 4)), bool(rng.random() < 0.5)
+    umax = max(np.abs(f["uvel"]).max(), np.abs(f["vvel"]).max(), 1e-9)
+    dt = float(rng.uniform(0.05, 0.45)) * synth.global_min_dx(case) / umax
+    mo, to, mg, tg = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    rco = orc.horizontal_remap(d, dt, f, mo, to, *tables, integral_order=order, l_dp_midpt=midpt)
+    s = dyn.EvpDynamics(d, f, ndte=10, xmin=1.0e4)
+    s.set_evp_parameters(3600.0)
+    s.ctx.upload(f)
+    s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+    rcg = s.ctx.transport_remap(dt, mg, tg if tg.shape[2] else None, *tables, integral_order=order, l_dp_midpt=midpt)
+    s.close()
+    assert {0: 0, 1: evpk.REMAP_BAD_DEPARTURE, 2: evpk.REMAP_NEGATIVE_MASS}[rco] == rcg, (rco, rcg, k)
+    if rco == 0:
+        assert np.array_equal(mg, mo) and np.array_equal(tg, to), {n: v for n, v in k.items() if n != "rng"}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_E_N", "20"))))
+def test_random_eap_configuration(seed, monkeypatch):
+    """eap(dt) (row f-4) on random grids / decompositions / boundaries / ndte / classic and revised relaxation / turning angle,
+    one to three calls, also as a forced exchange: bit-identical with the oracle"""
+    from cice5_amd.eap_tables import eap_tables
+    k = _config(seed + 900)
+    rng = k["rng"]
+    if rng.random() < 0.4:
+        monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+    case = synth.SynthCase(nx=k["nx"], ny=k["ny"], ns_boundary=C.BND_NAMES[k["ns"]], ew_boundary=C.BND_NAMES[k["ew"]],
+                           land=k["land"], ice="full" if k["ice"] != "polar" else "polar")
+    d = blocks.create_distrb_cart(k["nx"], k["ny"], k["bsx"], k["bsy"], ew_boundary_type=k["ew"], ns_boundary_type=k["ns"])
+    f = synth.make_block_fields(case, d)
+    synth.add_eap_state(f)
+    T = eap_tables()
+    xmin = synth.global_min_dx(case)
+    cosw, sinw = (np.cos(0.4), np.sin(0.4)) if k["turn"] else (1.0, 0.0)
+    ndte = int(rng.choice([1, 2, 9, 10, 11, 21, 32]))
+    fo, fg = util.clone(f), util.clone(f)
+    p = orc.make_params(k["dt"], ndte, xmin, revised_evp=k["revised"], cosw=cosw, sinw=sinw, tilt_from_slope=k["tilt"])
+    s = dyn.EvpDynamics(d, fg, ndte=ndte, revised_evp=k["revised"], xmin=xmin, cosw=cosw, sinw=sinw, tilt_from_slope=k["tilt"],
+                        resident=k["resident"])
+    s.init_eap(k["dt"], T)
+    ne = util.cell_mask(d, "ne")
+    for call in range(k["ncalls"]):
+        if call:
+            for ff in (fo, fg):
+                ff["aice"] *= 0.8; ff["vice"] *= 0.8
+                ff["strairxT"], ff["strairyT"] = ff["strairyT"].copy(), -ff["strairxT"]
+        orc.eap(d, p, fo, T)
+        s.eap(k["dt"])
+        bad = util.compare(d, fg, fo)
+        for n in synth.EAP_STATE + synth.EAP_HISTORY:
+            if not np.array_equal(fg[n][ne], fo[n][ne]):
+                bad.append((n, int((fg[n][ne] != fo[n][ne]).sum())))
+        assert not bad, (call, bad[:6], {n: v for n, v in k.items() if n != "rng"})
+    s.close()
+

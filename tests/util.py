@@ -58,12 +58,14 @@ def compare(d, got: Dict[str, np.ndarray], ref: Dict[str, np.ndarray], names: Op
     return bad
 
 
-def remap_case(nx, ny, bsx, bsy, ns="open", ncat=3, seed=4, dt=3600.0, trcr_depend=(0, 1, 2 + 1)):
+def remap_case(nx, ny, bsx, bsy, ns="open", ncat=3, seed=4, dt=3600.0, trcr_depend=(0, 1, 2 + 1), ew="cyclic", land="continents"):
     """a state for horizontal_remap: areas aim(0:ncat) summing to 1 over ocean, hice / hsno (type 1), a surface tracer on
     the area (depend 0), one on the ice volume (depend 1: type 2 on hice) and one on the first tracer (type 2 / 3), and a
     smooth velocity field that vanishes on land; ghost cells current (halo updates of the oracle)"""
     from oracle import orc
-    case, d, f = make_case(nx, ny, bsx, bsy, ns=ns, land="continents")
+    case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[ns], ew_boundary=C.BND_NAMES[ew], land=land)
+    d = blocks.create_distrb_cart(nx, ny, bsx, bsy, ew_boundary_type=ew, ns_boundary_type=ns)
+    f = synth.make_block_fields(case, d)
     synth.add_remap_grid(case, d, f)
     I, J = blocks.block_index_windows(d)
     ttype, depend, has = orc.remap_tables(list(trcr_depend))
