@@ -42,6 +42,11 @@ python3 scripts/pcie_run.py > "$out/pcie.txt" 2>&1
 bash scripts/zone_sweep.sh > "$out/zone_sweep.txt" 2>&1
 bash scripts/xp_compare.sh > "$out/xp_compare.txt" 2>&1
 bash scripts/tile_ab.sh > "$out/tile_ab.txt" 2>&1
+# 5. rows f-3 / f-4: transport_remap and eap at the bench size (timing line, kernel trace)
+python3 scripts/remap_bench.py > "$out/remap_bench.json" 2> "$out/remap_bench.err"
+bash scripts/prof_remap.sh "$tag/remap" > "$out/remap_kernels.txt" 2>&1
+python3 scripts/eap_bench.py > "$out/eap_bench.json" 2> "$out/eap_bench.err"
+bash scripts/prof_eap.sh "$tag/eap" > "$out/eap_kernels.txt" 2>&1
 fi
 cp profiles/traffic.json "$out/traffic.json" 2>/dev/null
 ls -la "$out"
