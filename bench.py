@@ -246,6 +246,12 @@ def main():
             out["config"]["evp_incl_pcie_ms"] = evp_incl_pcie(d, f, a, xmin, local_rank)
         except Exception as e:
             out["config"]["evp_incl_pcie_ms"] = {"error": str(e)[:200]}
+        # informational: the rows SURVEY.md S8 marks "next" on the same grid and state -- eap(dt) (f-4) in place of evp(dt), then
+        # transport_remap's horizontal_remap (f-3) advecting an ice state resident in HBM with the velocities left on the device
+        try:
+            out["config"]["next_rows"] = next_rows(a, case, d, f, xmin, local_rank)
+        except Exception as e:
+            out["config"]["next_rows"] = {"error": str(e)[:300]}
     # where the wall time of this process went (the timed region is `steps` x ms_per_step; the rest is imports, synthetic
     # inputs, context creation, warm-up, the CPU baseline and the informational extras)
     out["wall_s"] = {"setup_imports_inputs_create_upload": t_setup, "timed_steps": dt_wall, "cpu_baseline": t_cpu,
@@ -360,6 +366,75 @@ def other_boundary(a, nx, ny, bsx, bsy, device):
             "value": 0.5 * (st.icellt + st.icellu) * a.ndte * r["steps"] / r["wall_s"],
             "active_T_cells": int(st.icellt), "loop_ms_per_step": r["loop_ms"] / r["steps"],
             "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_timed", "alg_bytes_per_launch")}}
+
+
+def next_rows(a, case, d, f, xmin, device, ncat=5, trcr_depend=(0, 1, 1, 1, 1, 2, 1, 1, 1, 1)):
+    """eap(dt) and evpk_transport_remap on the bench grid, wall clock around synchronised calls, state resident in HBM.
+    trcr_depend: Tsfc, 4 x qice, qsno, 4 x sice beyond hice, hsno (nilyr = 4, nslyr = 1: ntrace = 12)."""
+    import ctypes as ct
+    import numpy as np
+    import torch
+    from cice5_amd import dyn, synth
+    res = {}
+    synth.add_eap_state(f)
+    s = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=device)
+    s.init_eap(a.dt)
+    ctx = s.ctx
+    ctx.upload(f)
+    t = []
+    for n in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.prep(); ctx.subcycle(a.ndte); ctx.finish(); ctx.sync()
+        t.append(time.perf_counter() - t0)
+    st = ctx.stats()
+    res["eap"] = {"what": "eap(dt), kdyn = 2 (ice_dyn_eap.F90:66), same grid / state / ndte as the headline", "ms_per_eap": 1e3 * min(t[1:]),
+                  "value": 0.5 * (st.icellt + st.icellu) * a.ndte / min(t[1:]), "unit": "cell-updates/s", "loop_ms": float(st.loop_ms)}
+    # horizontal_remap with the velocities eap left: areas from the bench's aice split over ncat categories, tracers functions of it
+    synth.add_remap_grid(case, d, f)
+    ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+    ctx.download({"uvel": f["uvel"], "vvel": f["vvel"]})
+    umax = max(float(np.abs(f["uvel"]).max()), float(np.abs(f["vvel"]).max()), 1e-6)
+    dt_r = 0.3 * xmin / umax                                     # departure points up to 0.3 cells away
+    ntrace = 2 + len(trcr_depend)
+    depend, ttype = np.zeros(ntrace, np.int32), np.ones(ntrace, np.int32)
+    for nt, dep in enumerate(trcr_depend):
+        depend[2 + nt] = dep
+        ttype[2 + nt] = 1 if dep == 0 else (3 if dep > 2 and trcr_depend[dep - 3] > 0 else 2)
+    has = np.zeros(ntrace, np.int32)
+    has[depend[depend > 0] - 1] = 1
+    dev = torch.device("cuda", device)
+    aice = torch.from_numpy(f["aice"]).to(dev)
+    ocean = torch.from_numpy((f["tmask"] > 0).astype(np.float64)).to(dev)
+    mm = torch.zeros((d.nblocks, ncat + 1) + tuple(aice.shape[1:]), dtype=torch.float64, device=dev)
+    tm = torch.zeros((d.nblocks, ncat, ntrace) + tuple(aice.shape[1:]), dtype=torch.float64, device=dev)
+    w = np.arange(1, ncat + 1, dtype=np.float64); w /= w.sum()
+    for n in range(ncat):
+        mm[:, n + 1] = aice * float(w[n])
+        for k in range(ntrace):
+            tm[:, n, k] = torch.where(mm[:, n + 1] > 0, (k + 1.0) * (0.5 + 0.3 * aice) * (1.0 + 0.1 * n), torch.zeros_like(aice))
+    mm[:, 0] = (1.0 - aice) * ocean
+    m0, t0_ = mm.clone(), tm.clone()
+    p64, p32 = ct.POINTER(ct.c_double), ct.POINTER(ct.c_int32)
+    t = []
+    for n in range(3):
+        mm.copy_(m0); tm.copy_(t0_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = ctx._L.evpk_transport_remap(ctx._ctx, float(dt_r), ncat, ntrace, ct.cast(mm.data_ptr(), p64), ct.cast(tm.data_ptr(), p64),
+                                         ttype.ctypes.data_as(p32), depend.ctypes.data_as(p32), has.ctypes.data_as(p32), 3, 1, 0)
+        t.append(time.perf_counter() - t0)
+        if rc:
+            raise RuntimeError(f"evpk_transport_remap rc={rc}: " + ctx._L.evpk_last_error(ctx._ctx).decode())
+    cells = d.nx_global * d.ny_global
+    nfield = ncat + 1 + ncat * ntrace
+    res["transport_remap"] = {"what": "horizontal_remap (ice_transport_remap.F90:309), ncat = %d, ntrace = %d, ice state resident in HBM (device arrays), "
+                                      "velocities as eap left them" % (ncat, ntrace), "ms_per_call": 1e3 * min(t[1:]),
+                              "value": cells * nfield / min(t[1:]), "unit": "field-cell-updates/s", "fields": nfield,
+                              "compulsory_GBps": 2 * 8 * cells * nfield / min(t[1:]) / 1e9,
+                              "max_area_change": float((mm - m0).abs().max())}
+    s.close()
+    return res
 
 
 def cpu_baseline(d, f, a, xmin):

@@ -18,7 +18,7 @@
       use ice_flux
       use ice_atmo
       use ice_dyn_shared
-      use ice_dyn_evp, only: evp, evpk_npinned, evpk_device_strength
+      use ice_dyn_evp, only: evp, evpk_npinned, evpk_device_strength, evpk_eap
       use ice_mechred, only: kstrength, krdg_partic, krdg_redist
 #ifdef AusCOM
       use cpl_arrays_setup, only: sicemass
@@ -29,6 +29,11 @@
       integer (int_kind) :: hdr(10), trl(6), ios, n, i, nb, ncalls, call_no, ew, ns
       real (dbl_kind) :: sc(8), dt
       integer (int_kind), allocatable :: geo(:,:), itmp(:,:,:)
+      ! kdyn = 2: what the reference keeps in module ice_dyn_eap (tables, structure tensor, history fields)
+      logical :: run_eap = .false.
+      integer (int_kind) :: nxy, nyy, nay
+      real (dbl_kind), allocatable, dimension(:,:,:) :: s11r, s12r, s22r, s11s, s12s, s22s, &
+         a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12, e11, e12, e22, ys11, ys12, ys22, s11, s12, s22
       character (len=16) :: nsname
       common /mock_bnd/ nsname
 
@@ -93,6 +98,16 @@
          allocate (aicen(nx_block,ny_block,1,nb), vicen(nx_block,ny_block,1,nb))
          aicen = 0.0_dbl_kind; vicen = 0.0_dbl_kind
       endif
+      if (trl(1) == 2) then          ! EAP: table extents, the six tables, a11_1..4, a12_1..4
+         run_eap = .true.
+         nxy = trl(2); nyy = trl(3); nay = trl(4)
+         allocate (s11r(nxy,nyy,nay), s12r(nxy,nyy,nay), s22r(nxy,nyy,nay), s11s(nxy,nyy,nay), s12s(nxy,nyy,nay), s22s(nxy,nyy,nay))
+         read (10) s11r, s12r, s22r, s11s, s12s, s22s
+         call rd (a11_1); call rd (a11_2); call rd (a11_3); call rd (a11_4)
+         call rd (a12_1); call rd (a12_2); call rd (a12_3); call rd (a12_4)
+         call zr (a11); call zr (a12); call zr (e11); call zr (e12); call zr (e22)
+         call zr (ys11); call zr (ys12); call zr (ys22); call zr (s11); call zr (s12); call zr (s22)
+      endif
       close (10)
 
       call zr (divu); call zr (shear); call zr (rdg_conv); call zr (rdg_shear); call zr (prs_sig)
@@ -104,7 +119,13 @@
       allocate (sicemass(nx_block,ny_block,nb))     ! drivers/auscom/CICE_InitMod.F90 allocates it in the real model
 #endif
       do call_no = 1, ncalls
-         call evp (dt)
+         if (run_eap) then           ! what the body of the reference's `subroutine eap (dt)` becomes (INTEGRATION.md S3)
+            call evpk_eap (dt, nxy, nyy, nay, s11r, s12r, s22r, s11s, s12s, s22s, &
+                           a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12, &
+                           e11, e12, e22, ys11, ys12, ys22, s11, s12, s22)
+         else
+            call evp (dt)
+         endif
       enddo
 #ifdef AusCOM
       write (*,'(a,es12.5)') 'evp_driver: AusCOM sicemass max = ', maxval(sicemass)
@@ -119,6 +140,7 @@
       where (iceumask) itmp = 1
       write (11) itmp
       if (evpk_device_strength) write (11) strength
+      if (run_eap) write (11) a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12, e11, e12, e22, ys11, ys12, ys22, s11, s12, s22
       close (11)
       write (*,'(a,i0)') 'evp_driver: page-locked host arrays = ', evpk_npinned
       write (*,'(a,i0,a,i0,a,es12.5)') 'evp_driver: ', ncalls, ' call(s) of evp(dt) on ', nb, ' block(s); max |uvel| = ', maxval(abs(uvel))

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from cice5_amd import dyn, synth
+from cice5_amd import constants as C, dyn, synth
 from oracle import orc
 from tests import util
 
@@ -24,7 +24,7 @@ OUT_F64 = ["uvel", "vvel"] + util.SIGMA + ["divu", "shear", "rdg_conv", "rdg_she
                                             "strtlty", "fm", "uvel_init", "vvel_init"]
 
 
-def write_fixture(path, d, f, p, ncalls, device_strength=None):
+def write_fixture(path, d, f, p, ncalls, device_strength=None, eap_tables=None):
     ga = d.geom_arrays()
     with open(path, "wb") as fh:
         np.array([d.nx_global, d.ny_global, d.nx_block, d.ny_block, d.nblocks, d.ew_boundary, d.ns_boundary,
@@ -43,9 +43,16 @@ def write_fixture(path, d, f, p, ncalls, device_strength=None):
                      dtype=np.int32).tofile(fh)
             for n in ("aicen", "vicen", "aice0"):
                 f[n].tofile(fh)
+        if eap_tables is not None:           # trailer: kdyn = 2 -- table extents, tables, structure tensor
+            na, ny, nx = eap_tables[0].shape
+            np.array([2, nx, ny, na, 0, 0], dtype=np.int32).tofile(fh)
+            for t in eap_tables:
+                t.tofile(fh)
+            for n in synth.EAP_STATE:
+                f[n].tofile(fh)
 
 
-def read_output(path, d, with_strength=False):
+def read_output(path, d, with_strength=False, with_eap=False):
     shp = (d.nblocks, d.ny_block, d.nx_block)
     n = int(np.prod(shp))
     out = {}
@@ -55,6 +62,9 @@ def read_output(path, d, with_strength=False):
         out["iceumask"] = np.fromfile(fh, dtype=np.int32, count=n).reshape(shp)
         if with_strength:
             out["strength"] = np.fromfile(fh, dtype=np.float64, count=n).reshape(shp)
+        if with_eap:
+            for name in synth.EAP_STATE + synth.EAP_HISTORY:
+                out[name] = np.fromfile(fh, dtype=np.float64, count=n).reshape(shp)
     return out
 
 
@@ -161,3 +171,34 @@ def test_fortran_host_random_configuration(tmp_path, seed):
         orc.evp(d, po, fo)
     bad = util.compare(d, got, fo, names=[n for n in got if n != "strength"])
     assert not bad, ((nx, ny, bsx, bsy, ns, ndte, ncalls, sw), bad[:4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,bs,ncalls", [("open", (50, 58), 1), ("tripole", (25, 29), 2)])
+def test_fortran_host_eap(tmp_path, ns, bs, ncalls):
+    """kdyn = 2 from Fortran: `call evpk_eap (dt, nx_yield, ..., s11r, ..., a11_1, ..., s22)` -- the call that replaces the body
+    of the reference's `subroutine eap (dt)` -- through ISO_C_BINDING (evpk_eap_state, evpk_eap_init / upload / download) into
+    the HIP kernels, against the oracle"""
+    from cice5_amd.eap_tables import eap_tables
+    T = eap_tables()
+    case, d, f = util.make_case(100, 116, *bs, ns=ns, land="continents")
+    synth.add_eap_state(f)
+    rng = np.random.default_rng(8)
+    for n in synth.EAP_STATE:                  # a structure tensor "from a restart"
+        f[n] = rng.uniform(0.35, 0.65, f["uvel"].shape) if n.startswith("a11") else rng.uniform(-0.1, 0.1, f["uvel"].shape)
+        orc.halo_r8(d, f[n], C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+    xmin = synth.global_min_dx(case)
+    write_fixture(str(tmp_path / "in.bin"), d, f, dyn.set_evp_parameters(3600.0, 21, False, xmin), ncalls, eap_tables=T)
+    p = orc.make_params(3600.0, 21, xmin)
+    r = subprocess.run([DRIVER, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = read_output(str(tmp_path / "out.bin"), d, with_eap=True)
+    fo = util.clone(f)
+    for _ in range(ncalls):
+        orc.eap(d, p, fo, T)
+    assert not util.compare(d, out, fo, names=OUT_F64 + ["iceumask"])
+    ne = util.cell_mask(d, "ne")
+    for n in synth.EAP_STATE + synth.EAP_HISTORY:
+        assert np.array_equal(out[n][ne], fo[n][ne]), n
+    assert np.abs(fo["a11"]).max() > 0.3
+
