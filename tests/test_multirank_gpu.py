@@ -241,6 +241,11 @@ def test_cfg4_1440x1080_on_four_ranks():
     _run(4, "open", 1440, 1080, 30, 27, ndte=10, xp="ipc")
 
 
+def test_cfg4_1440x1080_tripole_on_four_ranks():
+    """the 0.25-degree ACCESS-OM2 grid is tripolar in production: the same decomposition with the fold between mirror ranks"""
+    _run(4, "tripole", 1440, 1080, 30, 27, ndte=10, xp="ipc")
+
+
 @pytest.mark.parametrize("xp", XPS)
 def test_cfg5_tripole_slabs_eight_wide_grid(xp):
     """BASELINE config 5 decomposition in miniature: tripole grid, 4 slabs of a 3600-column grid, few rows."""

@@ -76,6 +76,12 @@ def test_cfg3_auscom_360x300_six_blocks():
     _both(360, 300, 60, 300, land="continents", ndte=60)
 
 
+def test_cfg3_auscom_360x300_tripole():
+    """the 1-degree ACCESS-OM2 grid is tripolar in production: the same 24 blocks with ns_boundary_type = 'tripole', whole evp,
+    ndte = 120 (one-subcycle tile launches + the in-place fold of a small one-rank slab)"""
+    _both(360, 300, 15, 300, ns="tripole", land="continents")
+
+
 def test_padded_blocks():
     """block size that does not divide the grid (ice_blocks.F90:148-150 padding)."""
     _both(100, 116, 32, 40, land="continents", ndte=30)
