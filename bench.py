@@ -305,13 +305,10 @@ def roofline(r, icellt, icellu, revp):
     st = r["stats"]
     if r["k2_n"] > 0:
         base = "evpk::k_subcycle2t" if st.tile_kernel else ("evpk::k_subcycle2" if os.environ.get("EVPK_PREFETCH") == "0" else "evpk::k_subcycle2p")
-        nsub = int(getattr(st, "subcycles_per_launch", 2) or 2)
-        if nsub > 2:
-            base = "evpk::k_subcycleNt"
-        kname, kern_ms, launches, timed = base + f" (stress+stepu fused, {nsub} subcycles per launch)", r["k2_ms"] / r["k2_n"], r["k2_n"], r["k2_timed"]
+        kname, nsub, kern_ms, launches, timed = base + " (stress+stepu fused, two subcycles per launch)", 2, r["k2_ms"] / r["k2_n"], r["k2_n"], r["k2_timed"]
     else:
         kname, nsub, kern_ms, launches, timed = "evpk::k_subcycle (stress+stepu fused)", 1, r["k1_ms"] / max(r["k1_n"], 1), r["k1_n"], r["k1_timed"]
-    alg = fused_bytes(icellt, icellu, st, revp, nsub >= 2)      # (each element once per launch, however many subcycles it fuses)
+    alg = fused_bytes(icellt, icellu, st, revp, nsub == 2)
     ref = nsub * (ALG_BYTES_STRESS * icellt + ALG_BYTES_STEPU * icellu)
     ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

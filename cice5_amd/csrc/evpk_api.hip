@@ -281,12 +281,6 @@ struct evpk_ctx {
     long long evp_count = 0;         // evpk_prep calls so far
     long long last_dl[F_COUNT] = {};  // evp_count at which each field was last downloaded (state fields under their F_STATE0 ids)
     bool io_sparse_now = false;      // the last evpk_upload was a sparse one: evpk_download may skip inactive tiles too
-    // k_subcycleNt: NS subcycles per launch on small one-rank slabs (no ghost zones, no tripole band); 0 = off
-    int nsubN = 0, RN = 0, ncxN = 0, nryN = 0, nstripsN = 0;
-    int nsub_force = -1;             // EVPK_NSUB = 0 (off) / 4 / 6 fixes the choice
-    int *d_stripsN = nullptr;
-    unsigned char *d_flagsN = nullptr;
-    size_t flagsN_cap = 0;
     bool tile_mode = false;          // the pairs run k_subcycle2t (one row per wave, no march): chosen by tune_R2 when strips are scarce
     int tile_force = -1;             // EVPK_TILE=0 / 1 fixes the choice
     unsigned int *d_tune = nullptr;
@@ -812,7 +806,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->eap_pool, c->eap_tab, c->d_stripsN, c->d_flagsN};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->eap_pool, c->eap_tab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1140,7 +1134,6 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     }
     { const char *e = getenv("EVPK_PREFETCH"); c->prefetch = !(e && atoi(e) == 0); }
     { const char *e = getenv("EVPK_TILE"); c->tile_force = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
-    { const char *e = getenv("EVPK_NSUB"); const int v = e ? atoi(e) : -1; c->nsub_force = (v == 0 || v == 4 || v == 6) ? v : -1; }
     c->nsimd = 4 * prop.multiProcessorCount;
 
     // neighbours on the slab ring
@@ -1492,31 +1485,6 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     c->strips1_valid = false;
     if (!c->use_double && strips1(c)) return 1;
     if (c->use_double && tune_R2(c)) return 1;
-    // several subcycles per launch where a launch is one wave's dependent chain anyway (k_subcycleNt): the tile variant was chosen,
-    // one rank, no ghost zones, no tripole band.  NS = 4 (R <= 9) or 6 (R <= 5): R + 2 NS - 1 <= 16 waves per workgroup.
-    c->nsubN = 0;
-    if (c->use_double && c->tile_mode && c->nranks == 1 && !c->force_exchange && !c->band_mode && !c->zone_mode && c->nsub_force != 0) {
-        c->nsubN = c->nsub_force > 0 ? c->nsub_force : (c->R2 <= 5 ? 6 : 4);
-        c->RN = std::min(c->R2, 17 - 2 * c->nsubN);
-        const int W = 65 - 2 * c->nsubN;
-        c->ncxN = (s.nxl + W - 1) / W;
-        c->nryN = (s.nyl + 1 + c->RN - 1) / c->RN;
-        const size_t need = (size_t)c->ncxN * c->nryN;
-        if (c->flagsN_cap < need) {
-            if (c->d_flagsN) (void)hipFree(c->d_flagsN);
-            if (c->d_stripsN) (void)hipFree(c->d_stripsN);
-            c->d_flagsN = nullptr; c->d_stripsN = nullptr; c->flagsN_cap = 0;
-            HIPCHK(c, hipMalloc(&c->d_flagsN, need));
-            HIPCHK(c, hipMalloc(&c->d_stripsN, sizeof(int) * need));
-            c->flagsN_cap = need;
-        }
-    }
-    const int ns_totN = c->nsubN ? c->ncxN * c->nryN : 0;
-    std::vector<unsigned char> flagsN(ns_totN);
-    if (ns_totN) {
-        hipLaunchKernelGGL(k_strip_flagsN, dim3((ns_totN + 3) / 4), dim3(256), 0, c->stream, s, c->ncxN, c->nryN, c->RN, c->nsubN, c->d_flagsN);
-        HIPCHK(c, hipMemcpyAsync(flagsN.data(), c->d_flagsN, ns_totN, hipMemcpyDeviceToHost, c->stream));
-    }
     const int ns_tot2 = c->ncx2 * c->nry2;
     std::vector<unsigned char> flags2(c->use_double ? ns_tot2 : 0);
     unsigned long long cnt[2] = {0, 0};
@@ -1527,12 +1495,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     }
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<int> list2, listN;
-    if (ns_totN) {
-        for (int k = 0; k < ns_totN; k++) if (flagsN[k]) listN.push_back(k);
-        c->nstripsN = (int)listN.size();
-        if (c->nstripsN) HIPCHK(c, hipMemcpyAsync(c->d_stripsN, listN.data(), sizeof(int) * listN.size(), hipMemcpyHostToDevice, c->stream));
-    }
+    std::vector<int> list2;
     if (c->use_double) {
         for (int k = 0; k < ns_tot2; k++) if (flags2[k]) list2.push_back(k);
         c->nstrips2 = (int)list2.size();
@@ -1779,36 +1742,6 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         // (a small slab on a one-rank tripole grid: the band sequence of a pair -- two band launches, two folds, two hand-overs
         // between the streams, ~45 us -- costs more than two one-row-per-wave launches with their folds on one stream)
         const bool pairs = c->use_double && !(c->band_mode && c->tile_mode && c->nranks == 1 && !c->force_exchange);
-        // NS subcycles in one launch (k_subcycleNt): inside the evp, or ending it (LAST writes the diagnostics)
-        if (pairs && c->nsubN && nsub - n >= c->nsubN && c->ksub + c->nsubN <= c->p.ndte) {
-            const int NS = c->nsubN;
-            const bool lastN = (c->ksub + NS == c->p.ndte);
-            SubArgs aN = a;
-            aN.strips = c->d_stripsN; aN.nstrips = c->nstripsN; aN.ncx = c->ncxN; aN.R = c->RN; aN.G = 0;
-            aN.wrap = (c->ew == EVPK_BND_CYCLIC) ? 1 : 0;
-            if (join()) FAIL(c, "hipStreamWaitEvent failed");
-            if (c->nstripsN > 0) {
-                const dim3 gt(((aN.nstrips + 7) / 8) * 8), bt((aN.R + 2 * NS - 1) * 64);
-                const size_t lds = (size_t)(aN.R + 2 * NS - 1) * 4096;
-                if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
-#define EVPK_LNT(NS_)                                                                                                                   \
-    do {                                                                                                                                \
-        if (lastN) { if (revp) hipLaunchKernelGGL((k_subcycleNt<true, true, NS_>), gt, bt, lds, c->stream, aN); else hipLaunchKernelGGL((k_subcycleNt<false, true, NS_>), gt, bt, lds, c->stream, aN); } \
-        else       { if (revp) hipLaunchKernelGGL((k_subcycleNt<true, false, NS_>), gt, bt, lds, c->stream, aN); else hipLaunchKernelGGL((k_subcycleNt<false, false, NS_>), gt, bt, lds, c->stream, aN); } \
-    } while (0)
-                if (NS == 6) EVPK_LNT(6); else EVPK_LNT(4);
-#undef EVPK_LNT
-                if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
-                c->kev_is_double[c->kernel_launches] = 1;
-                c->kernel_launches++;
-                c->double_launches++;
-            }
-            evE_valid = false;
-            c->ksub += NS;
-            n += NS;
-            c->cur ^= 1;
-            continue;
-        }
         const bool pair_inside = pairs && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
         // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
         // the LAST variant of k_subcycle)
@@ -2454,6 +2387,6 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->bound_ms = c->bound_ms; o->bound_updates = c->bound_updates;
     o->compact_metrics = c->compact ? 1 : 0;
     o->transport = c->ipc ? EVPK_XP_IPC : c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
-    o->subcycles_per_launch = (c->nsubN && c->use_double) ? c->nsubN : 2;
+    o->reserved_ = 0;
     return 0;
 }

@@ -1954,182 +1954,6 @@ template __global__ void k_subcycle2t<true, false>(SubArgs);
 template __global__ void k_subcycle2t<false, true>(SubArgs);
 template __global__ void k_subcycle2t<true, true>(SubArgs);
 
-// ------------------------------------------------------------------------------------
-// k_subcycleNt<REVP, LAST, NS>: NS subcycles per launch, one row per wave -- k_subcycle2t with the pair generalised to NS.
-// A small grid (gx1, a 1-degree grid) is a few hundred workgroups: the launch lasts as long as one wave's dependent chain,
-// of which the fixed part -- dispatch, the loads of a row, the stores -- is ~8 us and each subcycle only ~1.3 us.  More
-// subcycles per launch amortise the fixed part; the price is redundancy that costs nothing while the chip is not full:
-// a workgroup of NW = R + 2 NS - 1 waves for R owned rows, 64 - (2 NS - 1) owned columns per wave.
-//   row of wave w:  r = jb - (NS - 1) + w
-//   subcycle k = 1 .. NS:   T_k on waves k-1 .. NW-k,   U_k on waves k-1 .. NW-k-1,   lanes >= k-1 (the east side sheds one
-//   lane per phase by itself: a lane whose east neighbour was not valid carries values nobody owned reads)
-//   owned: waves NS-1 .. NS-2+R, lanes NS-1 .. 63-NS, column of lane l: cx W + l - NS + 2, W = 65 - 2 NS
-// 2 NS - 1 workgroup barriers; LDS as in k_subcycle2t.  One rank, no ghost zones, no tripole band (those keep the pair kernels).
-// Same arithmetic in the same order: bit-identical with NS launches of k_subcycle.
-// ------------------------------------------------------------------------------------
-template <bool REVP, bool LAST, int NS>
-__global__ __launch_bounds__(1024) void k_subcycleNt(SubArgs a) {
-    extern __shared__ double tl[];
-    const Slab &s = a.s;
-    constexpr int W = 65 - 2 * NS;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int NW = blockDim.x >> 6;                   // R + 2 NS - 1
-    const int chunk = gridDim.x >> 3;
-    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (wg >= a.nstrips) return;                      // (the whole workgroup leaves: no barrier is left waiting)
-    const int st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
-    const int cx = st % a.ncx, ry = st / a.ncx;
-    const int R = a.R, nxl = s.nxl, nyl = s.nyl;
-    const int c = cx * W + lane - NS + 2;
-    const int jb = ry * R + 1;
-    const bool cyc = a.wrap != 0;
-    int ci = c, cm1 = c - 1;
-    bool okc, okm;
-    if (cyc) {
-        ci = (c - 1) % nxl; if (ci < 0) ci += nxl; ci += 1;
-        cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
-        okc = okm = true;
-    } else {
-        okc = (c >= -1 && c <= nxl + 2);
-        okm = (cm1 >= -1 && cm1 <= nxl + 2);
-        if (!okc) ci = 0;
-        if (!okm) cm1 = 0;
-    }
-    const bool tcol = cyc ? true : (c >= 0 && c <= nxl + 2);
-    const bool ucol = cyc ? true : (c >= 0 && c <= nxl + 1);
-    const bool own = (lane >= NS - 1 && lane <= 63 - NS && c >= 1 && c <= nxl);
-
-    const size_t pp = (size_t)s.pitch * 16;
-    const size_t rowb = (size_t)s.rstride * 16;
-    const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
-    const int SR = a.sr, SW = a.sw;
-    char *const base = reinterpret_cast<char *>(s.F);
-    double *const X = tl, *const Y = tl + (size_t)NW * 256;
-    double *const Xw = X + (size_t)w * 256 + lane, *const Yw = Y + (size_t)w * 256 + lane;
-
-    const int r = jb - (NS - 1) + w;                  // this wave's row
-    const bool rowok = (r >= 0 && r <= nyl + 1);
-    char *const rb = base + (size_t)(rowok ? r : 0) * rowb;
-
-    // ---------------- loads: the row's masks, (u, v) of this row and the one below, sigma, metrics, stepu inputs ----------------
-    unsigned char m = 0;
-    double u_c = 0.0, v_c = 0.0, u_m = 0.0, v_m = 0.0;            // (u, v) at (c, r), (c-1, r)
-    double us_c = 0.0, vs_c = 0.0, us_m = 0.0, vs_m = 0.0;        // ... at (c, r-1), (c-1, r-1)
-    if (rowok) {
-        if (okc) {
-            m = s.cmask[(size_t)r * s.pitch + C0 + ci];
-            const double2 q = ldp(rb, pp, SR + S_U, lo); u_c = q.x; v_c = q.y;
-        }
-        if (okm) { const double2 q = ldp(rb, pp, SR + S_U, lom); u_m = q.x; v_m = q.y; }
-    }
-    if (r - 1 >= 0 && r - 1 <= nyl + 1) {
-        const char *rs = base + (size_t)(r - 1) * rowb;
-        if (okc) { const double2 q = ldp(rs, pp, SR + S_U, lo); us_c = q.x; vs_c = q.y; }
-        if (okm) { const double2 q = ldp(rs, pp, SR + S_U, lom); us_m = q.x; vs_m = q.y; }
-    }
-    const bool tact = tcol && (m & CM_T) != 0;
-    const bool uact = ucol && (m & CM_U) != 0 && r >= 1 && r <= nyl;
-    Sig g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    UStat q1{0, 0, 0, 0, 0, 0, 0, 0};
-    double ui1 = 0.0, vi1 = 0.0;
-    if (__any(tact)) {
-        if (tact) { mt = load_tmet(rb, pp, lo); g = load_sig(rb, pp, SR, lo); }
-    }
-    if (__any(uact)) {
-        if (uact) {
-            q1 = load_ustat(rb, pp, lo);
-            if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo); ui1 = iv.x; vi1 = iv.y; }
-        }
-    }
-    double tarear = 0.0;
-    if (LAST && tact) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
-
-#pragma unroll
-    for (int k = 1; k <= NS; k++) {
-        const bool fin = (k == NS);
-        // ---------------- T_k(r) ----------------
-        const bool tk = tact && (w >= k - 1) && (w <= NW - k) && lane >= k - 1;
-        Str8 o{0, 0, 0, 0, 0, 0, 0, 0};
-        if (__any(tk)) {
-            if (tk) {
-                Diag dg;
-                if (fin && LAST) stress_cell<true>(mt, u_c, u_m, us_c, us_m, v_c, v_m, vs_c, vs_m, a.ecci, a.arlx1i, a.denom1, tarear, g, o, dg);
-                else stress_cell<false>(mt, u_c, u_m, us_c, us_m, v_c, v_m, vs_c, vs_m, a.ecci, a.arlx1i, a.denom1, 0.0, g, o, dg);
-                if (fin && own && w >= NS - 1 && w <= NS - 2 + R) {
-                    store_sig(rb, pp, SW, lo, g);
-                    if (cyc && c == 1) store_sig(rb, pp, SW, lo + (unsigned)nxl * 16u, g);     // east ghost T column = image of column 1
-                    if (LAST) {
-                        st1(rb, pp, F_DIVU, lo, dg.divu);       st1(rb, pp, F_RDGCONV, lo, dg.rdg_conv);
-                        st1(rb, pp, F_RDGSHEAR, lo, dg.rdg_shear); st1(rb, pp, F_SHEAR, lo, dg.shear);
-                        st1(rb, pp, F_PRSSIG, lo, dg.prs);
-                    }
-                }
-            }
-        }
-        const double s2n = shfl_dn1(o.s2), s4n = shfl_dn1(o.s4), s7n = shfl_dn1(o.s7), s8n = shfl_dn1(o.s8);
-        Xw[0] = o.s3; Xw[64] = o.s6; Xw[128] = s4n; Xw[192] = s8n;
-        __syncthreads();
-        // ---------------- U_k(r) ----------------
-        const bool uk = uact && (w >= k - 1) && (w <= NW - k - 1) && lane >= k - 1;
-        if (__any(uk)) {
-            if (uk) {
-                const double *Xn = Xw + 256;              // the row above
-                double un, vn, sxi, syi;
-                stepu_cell(q1, u_c, v_c, ui1, vi1, ((o.s1 + s2n) + Xn[0]) + Xn[128], ((o.s5 + Xn[64]) + s7n) + Xn[192],
-                           a.brlx, a.revp, a.cosw, a.sinw, un, vn, sxi, syi);
-                u_c = un; v_c = vn;                       // (an inactive cell keeps its velocity)
-                if (fin && own && w >= NS - 1 && w <= NS - 2 + R) {
-                    stp(rb, pp, SW + S_U, lo, un, vn);
-                    if (cyc) {
-                        if (c == 1) stp(rb, pp, SW + S_U, lo + (unsigned)nxl * 16u, un, vn);
-                        if (c == nxl) stp(rb, pp, SW + S_U, lo - (unsigned)nxl * 16u, un, vn);
-                    }
-                    if (LAST) { st1(rb, pp, F_STRINTX, lo, sxi); st1(rb, pp, F_STRINTY, lo, syi); }
-                }
-            }
-        }
-        if (!fin) {
-            u_m = shfl_up1(u_c); v_m = shfl_up1(v_c);     // (c-1, r); lane 0 is not used below
-            Yw[0] = u_c; Yw[64] = v_c; Yw[128] = u_m; Yw[192] = v_m;
-            __syncthreads();
-            if (w >= 1) {
-                const double *Ys = Yw - 256;              // the row below, after this subcycle
-                us_c = Ys[0]; vs_c = Ys[64]; us_m = Ys[128]; vs_m = Ys[192];
-            }
-        }
-    }
-}
-
-#define EVPK_INST_NT(NS_)                                               \
-    template __global__ void k_subcycleNt<false, false, NS_>(SubArgs);  \
-    template __global__ void k_subcycleNt<true, false, NS_>(SubArgs);   \
-    template __global__ void k_subcycleNt<false, true, NS_>(SubArgs);   \
-    template __global__ void k_subcycleNt<true, true, NS_>(SubArgs);
-EVPK_INST_NT(4)
-EVPK_INST_NT(6)
-#undef EVPK_INST_NT
-
-// strip activity for k_subcycleNt: strips of W = 65 - 2 NS columns (lane l of strip cx = column cx W + l - NS + 2) x R rows;
-// a workgroup stores owned cells only, so a strip counts when one of the cells it owns is active
-__global__ void k_strip_flagsN(Slab s, int ncx, int nry, int R, int NS, unsigned char *flags) {
-    const int sid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (sid >= ncx * nry) return;
-    const int cx = sid % ncx, ry = sid / ncx;
-    const int W = 65 - 2 * NS;
-    const int c = cx * W + lane - NS + 2;
-    const bool own = (lane >= NS - 1 && lane <= 63 - NS && c >= 1 && c <= s.nxl);
-    const int jb = ry * R + 1;
-    int any = 0;
-    if (own)
-        for (int r = jb; r < jb + R && r <= s.nyl + 1; r++)
-            if (s.cmask[mcell(s, c, r)]) any = 1;
-    const unsigned long long b = __ballot(any);
-    if (lane == 0) flags[sid] = b ? 1 : 0;
-}
-
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
 // cells: if given, also counts the active T / U cells on the physical cells each strip owns (icellt, icellu of the rank)

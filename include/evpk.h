@@ -159,7 +159,7 @@ typedef struct {
     int32_t bound_updates;             /* ... and their number */
     int32_t compact_metrics;           /* 1: the kernels rebuild the eight metric planes from HTN / HTE (evpk_geom) */
     int32_t transport;                 /* EVPK_XP_*: what carries the exchanges between ranks */
-    int32_t subcycles_per_launch;      /* of the fused kernel (kernel2_*): 2, or 4 / 6 where a small one-rank slab runs k_subcycleNt */
+    int32_t reserved_;
 } evpk_stats;
 
 enum { EVPK_XP_NONE = 0, EVPK_XP_RCCL = 1, EVPK_XP_SHM_RELAY = 2, EVPK_XP_IPC = 3, EVPK_XP_SELF = 4 };

@@ -16,9 +16,7 @@ pytestmark = pytest.mark.gpu
 MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH": "0"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_ZONE_M": "2"},
          {"EVPK_COMPACT_METRICS": "0"}, {"EVPK_STRIP_ROWS": "3"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_OVERLAP": "0"},
          {"EVPK_FORCE_EXCHANGE": "2"}, {"EVPK_FORCE_EXCHANGE": "2", "EVPK_ZONE_M": "1"},
-         {"EVPK_TILE": "1"}, {"EVPK_TILE": "1", "EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_TILE": "1", "EVPK_STRIP_ROWS": "2"}, {"EVPK_TILE": "0"},
-         {"EVPK_TILE": "1", "EVPK_NSUB": "4"}, {"EVPK_TILE": "1", "EVPK_NSUB": "6"}, {"EVPK_TILE": "1", "EVPK_NSUB": "6", "EVPK_STRIP_ROWS": "3"},
-         {"EVPK_TILE": "1", "EVPK_NSUB": "4", "EVPK_STRIP_ROWS": "9"}, {"EVPK_TILE": "1", "EVPK_NSUB": "0"}]
+         {"EVPK_TILE": "1"}, {"EVPK_TILE": "1", "EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_TILE": "1", "EVPK_STRIP_ROWS": "2"}, {"EVPK_TILE": "0"}]
 
 
 def _config(seed):
@@ -39,7 +37,7 @@ def _config(seed):
     bsx, bsy = min(bsx, nx), min(bsy, ny)
     if ns == "tripole" and ny % bsy == 1 and bsy < ny:
         bsy += 1           # a one-row top block is rejected (the reference's own result then depends on the decomposition)
-    return dict(nx=nx, ny=ny, bsx=bsx, bsy=bsy, ns=ns, ew=ew, ndte=int(rng.choice([1, 2, 5, 8, 13, 20, 24])),
+    return dict(nx=nx, ny=ny, bsx=bsx, bsy=bsy, ns=ns, ew=ew, ndte=int(rng.choice([1, 2, 5, 8, 13, 20])),
                 revised=bool(rng.random() < 0.3), turn=bool(rng.random() < 0.3), ice=str(rng.choice(["polar", "full", "patches", "dots"])),
                 land=str(rng.choice(["rows", "continents"])), mode=MODES[int(rng.integers(len(MODES)))], ncalls=int(rng.choice([1, 2, 3])),
                 resident=bool(rng.random() < 0.5), pin=bool(rng.random() < 0.2), sparse=bool(rng.random() < 0.25),
