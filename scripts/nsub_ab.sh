@@ -1,5 +1,6 @@
 #!/bin/bash
 # k_subcycleNt (NS subcycles per launch, small one-rank slabs) against the pair kernel: EVPK_NSUB = 0 / 4 / 6 / auto
+# (the record of an experiment: EVPK_NSUB exists in commit 395dac5 only -- profiles/r02_v3/nsub_rejected.txt)
 cd "$(dirname "$0")/.." || exit 1
 run() { python3 bench.py --steps 5 --warmup 2 --cpu-subcycles 0 "$@" 2>/dev/null | python3 -c "
 import json,sys

@@ -1034,3 +1034,63 @@ def test_caller_arrays_in_device_memory():
         bad = util.compare(d, got, fo)
         assert not bad, (call, bad[:4])
     s.close()
+
+
+def test_full_size_3600x2700_tripole_rows_f3_f4():
+    """BASELINE config 5's grid and boundary for the rows that follow the EVP path, whole grid against the oracle:
+    (a) eap(dt), ndte = 12 (stepa after subcycles 1 and 11, the LAST launch): velocities, stresses, structure tensor, history;
+    (b) horizontal_remap with the velocities that eap left on the device (2 categories, tracer types 1 and 2), bit for bit, and
+        the size-independent properties at this size: area and area x tracer integrals conserved, tracers within their old range."""
+    from cice5_amd.eap_tables import eap_tables
+    nx, ny = 3600, 2700
+    case, d, f = util.make_case(nx, ny, 450, 2700, ns="tripole", land="continents", dt=450.0)
+    synth.add_eap_state(f)
+    synth.add_remap_grid(case, d, f)
+    xmin = synth.global_min_dx(case)
+    T = eap_tables()
+    fo, fg = util.clone(f), util.clone(f)
+    orc.eap(d, orc.make_params(450.0, 12, xmin), fo, T)
+    s = dyn.EvpDynamics(d, fg, ndte=12, xmin=xmin)
+    s.init_eap(450.0, T)
+    s.eap(450.0)
+    bad = util.compare(d, fg, fo)
+    ne = util.cell_mask(d, "ne")
+    for n in EAP_NE:
+        if not np.array_equal(fg[n][ne], fo[n][ne]):
+            bad.append((n, int((fg[n][ne] != fo[n][ne]).sum())))
+    assert not bad, bad[:8]
+    assert np.abs(fo["a11_1"] - 0.5).max() > 1e-3 and np.abs(fo["uvel"]).max() > 1e-3
+    # (b)
+    ncat = 2
+    tables = orc.remap_tables([0, 1])                               # hice, hsno, an area tracer, one on the ice volume
+    ntrace = len(tables[0])
+    aice = f["aice"]
+    mm = np.zeros((d.nblocks, ncat + 1) + aice.shape[1:])
+    tm = np.zeros((d.nblocks, ncat, ntrace) + aice.shape[1:])
+    for n in range(ncat):
+        a = aice * (0.4 + 0.2 * n)
+        mm[:, n + 1] = a
+        for k in range(ntrace):
+            tm[:, n, k] = np.where(a > 0, (k + 1.0) * (0.5 + 0.3 * aice) * (1.0 + 0.1 * n), 0.0)
+    mm[:, 0] = (1.0 - aice) * (f["tmask"] > 0)
+    umax = max(np.abs(fo["uvel"]).max(), np.abs(fo["vvel"]).max())
+    dt = 0.3 * xmin / umax
+    mo, to, mg, tg = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    assert orc.horizontal_remap(d, dt, fo, mo, to, *tables) == 0
+    s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+    assert s.ctx.transport_remap(dt, mg, tg, *tables) == 0
+    s.close()
+    assert np.array_equal(mg, mo) and np.array_equal(tg, to)
+    phys = util.cell_mask(d, "phys")
+    ta = f["tarea"]
+    assert np.abs(mg - mm).max() > 1e-4
+    for n in range(ncat + 1):
+        a0, a1 = (mm[:, n] * ta)[phys].sum(), (mg[:, n] * ta)[phys].sum()
+        assert abs(a1 - a0) <= 1e-11 * abs(a0), n
+    for n in range(ncat):
+        q0, q1 = (mm[:, n + 1] * tm[:, n, 0] * ta)[phys].sum(), (mg[:, n + 1] * tg[:, n, 0] * ta)[phys].sum()       # ice volume
+        assert abs(q1 - q0) <= 1e-10 * abs(q0), n
+        ice = phys & (mg[:, n + 1] > 1e-9)
+        for k in (0, 2):                                                                                        # type-1 tracers stay in range
+            lo, hi = tm[:, n, k][tm[:, n, k] > 0].min(), tm[:, n, k].max()
+            assert tg[:, n, k][ice].min() >= lo * (1 - 1e-9) and tg[:, n, k][ice].max() <= hi * (1 + 1e-9), (n, k)
