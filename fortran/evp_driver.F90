@@ -18,7 +18,7 @@
       use ice_flux
       use ice_atmo
       use ice_dyn_shared
-      use ice_dyn_evp, only: evp, evpk_npinned, evpk_device_strength, evpk_eap
+      use ice_dyn_evp, only: evp, evpk_npinned, evpk_device_strength, evpk_eap, evpk_horizontal_remap
       use ice_mechred, only: kstrength, krdg_partic, krdg_redist
 #ifdef AusCOM
       use cpl_arrays_setup, only: sicemass
@@ -31,6 +31,13 @@
       integer (int_kind), allocatable :: geo(:,:), itmp(:,:,:)
       ! kdyn = 2: what the reference keeps in module ice_dyn_eap (tables, structure tensor, history fields)
       logical :: run_eap = .false.
+      ! transport_remap's horizontal_remap after the last evp: aim, trm and the tables of init_transport
+      logical :: run_remap = .false.
+      integer (int_kind) :: rm_ntrace, rm_order, rm_midpt
+      real (dbl_kind) :: rm_dt(1)
+      real (dbl_kind), allocatable :: aim(:,:,:,:), trm(:,:,:,:,:)
+      integer (int_kind), allocatable :: rm_type(:), rm_dep(:), rm_hasi(:)
+      logical (log_kind), allocatable :: rm_has(:)
       integer (int_kind) :: nxy, nyy, nay
       real (dbl_kind), allocatable, dimension(:,:,:) :: s11r, s12r, s22r, s11s, s12s, s22s, &
          a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12, e11, e12, e22, ys11, ys12, ys22, s11, s12, s22
@@ -108,6 +115,18 @@
          call zr (a11); call zr (a12); call zr (e11); call zr (e12); call zr (e22)
          call zr (ys11); call zr (ys12); call zr (ys22); call zr (s11); call zr (s12); call zr (s22)
       endif
+      if (trl(1) == 3) then          ! horizontal_remap: ncat, ntrace, integral_order, l_dp_midpt; dt; dxu, dyu, hm; tables; aim; trm
+         run_remap = .true.
+         ncat = trl(2); rm_ntrace = trl(3); rm_order = trl(4); rm_midpt = trl(5)
+         read (10) rm_dt
+         call rd (dxu); call rd (dyu); call rd (hm)
+         allocate (rm_type(rm_ntrace), rm_dep(rm_ntrace), rm_hasi(rm_ntrace), rm_has(rm_ntrace))
+         read (10) rm_type, rm_dep, rm_hasi
+         rm_has = rm_hasi /= 0
+         allocate (aim(nx_block,ny_block,0:ncat,nb), trm(nx_block,ny_block,rm_ntrace,ncat,nb))
+         read (10) aim
+         read (10) trm
+      endif
       close (10)
 
       call zr (divu); call zr (shear); call zr (rdg_conv); call zr (rdg_shear); call zr (prs_sig)
@@ -130,6 +149,9 @@
 #ifdef AusCOM
       write (*,'(a,es12.5)') 'evp_driver: AusCOM sicemass max = ', maxval(sicemass)
 #endif
+      ! the call of ice_transport_driver.F90:475-481, with the shim's horizontal_remap (INTEGRATION.md S3)
+      if (run_remap) call evpk_horizontal_remap (rm_dt(1), rm_ntrace, uvel, vvel, aim, trm, .false., rm_type, rm_dep, rm_has, &
+                                                 rm_order, rm_midpt /= 0)
 
       open (11, file=trim(fout), access='stream', form='unformatted', status='replace')
       write (11) uvel, vvel, stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
@@ -140,6 +162,7 @@
       where (iceumask) itmp = 1
       write (11) itmp
       if (evpk_device_strength) write (11) strength
+      if (run_remap) write (11) aim, trm
       if (run_eap) write (11) a11_1, a11_2, a11_3, a11_4, a12_1, a12_2, a12_3, a12_4, a11, a12, e11, e12, e22, ys11, ys12, ys22, s11, s12, s22
       close (11)
       write (*,'(a,i0)') 'evp_driver: page-locked host arrays = ', evpk_npinned

@@ -24,7 +24,7 @@ OUT_F64 = ["uvel", "vvel"] + util.SIGMA + ["divu", "shear", "rdg_conv", "rdg_she
                                             "strtlty", "fm", "uvel_init", "vvel_init"]
 
 
-def write_fixture(path, d, f, p, ncalls, device_strength=None, eap_tables=None):
+def write_fixture(path, d, f, p, ncalls, device_strength=None, eap_tables=None, remap=None):
     ga = d.geom_arrays()
     with open(path, "wb") as fh:
         np.array([d.nx_global, d.ny_global, d.nx_block, d.ny_block, d.nblocks, d.ew_boundary, d.ns_boundary,
@@ -43,6 +43,16 @@ def write_fixture(path, d, f, p, ncalls, device_strength=None, eap_tables=None):
                      dtype=np.int32).tofile(fh)
             for n in ("aicen", "vicen", "aice0"):
                 f[n].tofile(fh)
+        if remap is not None:                # trailer: horizontal_remap after the last evp
+            mm, tm, (ttype, depend, has), dt_r, order, midpt = remap
+            np.array([3, mm.shape[1] - 1, tm.shape[2], order, int(midpt), 0], dtype=np.int32).tofile(fh)
+            np.array([dt_r], dtype=np.float64).tofile(fh)
+            for n in ("dxu", "dyu", "hm"):
+                f[n].tofile(fh)
+            for a in (ttype, depend, has):
+                np.ascontiguousarray(a, dtype=np.int32).tofile(fh)
+            mm.tofile(fh)
+            tm.tofile(fh)
         if eap_tables is not None:           # trailer: kdyn = 2 -- table extents, tables, structure tensor
             na, ny, nx = eap_tables[0].shape
             np.array([2, nx, ny, na, 0, 0], dtype=np.int32).tofile(fh)
@@ -52,7 +62,7 @@ def write_fixture(path, d, f, p, ncalls, device_strength=None, eap_tables=None):
                 f[n].tofile(fh)
 
 
-def read_output(path, d, with_strength=False, with_eap=False):
+def read_output(path, d, with_strength=False, with_eap=False, remap_shapes=None):
     shp = (d.nblocks, d.ny_block, d.nx_block)
     n = int(np.prod(shp))
     out = {}
@@ -62,6 +72,9 @@ def read_output(path, d, with_strength=False, with_eap=False):
         out["iceumask"] = np.fromfile(fh, dtype=np.int32, count=n).reshape(shp)
         if with_strength:
             out["strength"] = np.fromfile(fh, dtype=np.float64, count=n).reshape(shp)
+        if remap_shapes is not None:
+            for name, shp_ in zip(("aim", "trm"), remap_shapes):
+                out[name] = np.fromfile(fh, dtype=np.float64, count=int(np.prod(shp_))).reshape(shp_)
         if with_eap:
             for name in synth.EAP_STATE + synth.EAP_HISTORY:
                 out[name] = np.fromfile(fh, dtype=np.float64, count=n).reshape(shp)
@@ -201,4 +214,45 @@ def test_fortran_host_eap(tmp_path, ns, bs, ncalls):
     for n in synth.EAP_STATE + synth.EAP_HISTORY:
         assert np.array_equal(out[n][ne], fo[n][ne]), n
     assert np.abs(fo["a11"]).max() > 0.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,bs,order,midpt", [("open", (50, 58), 3, True), ("tripole", (25, 29), 2, False)])
+def test_fortran_host_horizontal_remap(tmp_path, ns, bs, order, midpt):
+    """transport_remap's `call horizontal_remap (dt, ntrace, uvel, vvel, aim, trm, l_fixed_area, tracer_type, depend,
+    has_dependents, integral_order, l_dp_midpt)` (ice_transport_driver.F90:475-481) through the shim's evpk_horizontal_remap,
+    after an evp from the same Fortran host: aim / trm against the oracle's horizontal_remap on the oracle's velocities"""
+    case, d, f = util.make_case(100, 116, *bs, ns=ns, land="continents")
+    synth.add_thickness_distribution(f)
+    synth.add_remap_grid(case, d, f)
+    xmin = synth.global_min_dx(case)
+    ncat = f["aicen"].shape[1]
+    tables = orc.remap_tables([0, 1, 2 + 1, 2 + 2])
+    ntrace = len(tables[0])
+    mm = np.zeros((d.nblocks, ncat + 1) + f["aice0"].shape[1:])
+    tm = np.zeros((d.nblocks, ncat, ntrace) + f["aice0"].shape[1:])
+    mm[:, 0] = f["aice0"]
+    for n in range(ncat):
+        a, v = f["aicen"][:, n], f["vicen"][:, n]
+        mm[:, n + 1] = a
+        h = np.where(a > 1e-11, v / np.where(a > 1e-11, a, 1.0), 0.0)
+        tm[:, n, 0], tm[:, n, 1] = h, 0.2 * h
+        for k in range(2, ntrace):
+            tm[:, n, k] = np.where(a > 1e-11, -3.0 - n - 0.5 * k + 0.1 * h, 0.0)
+    for arr in (mm.reshape(d.nblocks, -1, *mm.shape[2:]), tm.reshape(d.nblocks, -1, *mm.shape[2:])):
+        for k in range(arr.shape[1]):
+            w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
+    fo = util.clone(f)
+    orc.evp(d, orc.make_params(3600.0, 30, xmin), fo)
+    dt_r = 0.35 * xmin / max(np.abs(fo["uvel"]).max(), np.abs(fo["vvel"]).max())
+    mo, to = mm.copy(), tm.copy()
+    assert orc.horizontal_remap(d, dt_r, fo, mo, to, *tables, integral_order=order, l_dp_midpt=midpt) == 0
+    write_fixture(str(tmp_path / "in.bin"), d, f, dyn.set_evp_parameters(3600.0, 30, False, xmin), 1,
+                  remap=(mm, tm, tables, dt_r, order, midpt))
+    r = subprocess.run([DRIVER, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = read_output(str(tmp_path / "out.bin"), d, remap_shapes=(mm.shape, tm.shape))
+    assert not util.compare(d, out, fo, names=["uvel", "vvel"])
+    assert np.abs(mo - mm).max() > 1e-4
+    assert np.array_equal(out["aim"], mo) and np.array_equal(out["trm"], to)
 
