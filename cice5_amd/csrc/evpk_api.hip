@@ -229,8 +229,10 @@ struct evpk_ctx {
     long long zone_bytes = 0;
     hipEvent_t evE = nullptr;   // after the most recent kernel launch on `stream`
     hipEvent_t evB0 = nullptr, evB1 = nullptr;   // tripole, single rank: band 1 + its fold on stream2 beside the main launch
-    // the two hand-overs of a pair through stream memory operations on signal memory (hipStreamWriteValue32 / hipStreamWaitValue32)
-    // where the device supports them: ~5 us per pair cheaper than an event record + wait pair (EVPK_HANDOVER=event restores events)
+    // EVPK_HANDOVER=value: the two hand-overs of a pair through stream memory operations on signal memory (hipStreamWriteValue32 /
+    // hipStreamWaitValue32) instead of an event record + wait pair: ~5 us per pair cheaper (3600x2700 tripole 14.87 -> 14.53 ms, 1440x1080
+    // 4.34 -> 4.03), bit-identical -- but NOT the default: a queue blocked in a value wait deadlocks under rocprofv3 --pmc (the
+    // counter passes serialise the dispatches of all queues), and starves partner ranks that share a device
     uint32_t *sigB = nullptr, *sigB1 = nullptr;  // pairs the main stream has completed / band sequences stream2 has completed (8 bytes each)
     uint32_t sig_seq = 0;
     bool handover_value = false;
@@ -1073,7 +1075,9 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
             const char *hv = getenv("EVPK_HANDOVER");
             int can = 0;
             (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
-            if (!(hv && !strcmp(hv, "event")) && can) {
+            // (one rank only: with several rank processes on ONE device -- the functional multi-rank checks -- queues blocked in a
+            // value wait and the partner ranks' spinning exchange kernels starve each other; between ranks the events stay)
+            if (hv && !strcmp(hv, "value") && can && c->nranks == 1) {
                 if (hipExtMallocWithFlags((void **)&c->sigB, 8, hipMallocSignalMemory) == hipSuccess &&
                     hipExtMallocWithFlags((void **)&c->sigB1, 8, hipMallocSignalMemory) == hipSuccess) {
                     HIPCHK(c, hipMemset(c->sigB, 0, 8));
