@@ -16,10 +16,10 @@ profile() {   # name, bench flags
   local name=$1; shift
   local w=$out/$name; mkdir -p "$w"
   python3 bench.py $COMMON "$@" > "$w/bench.json" 2> "$w/bench.err"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$w/trace" -o t -- python3 bench.py $COMMON "$@" > "$w/trace.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$w/trace" -o t -- python3 bench.py $COMMON "$@" > "$w/trace.log" 2>&1
   cp "$(ls "$w"/trace/*/*kernel_stats.csv "$w"/trace/*kernel_stats.csv 2>/dev/null | head -1)" "$w/kernel_stats.csv" 2>/dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$w/pmc_fetch" -o f -- python3 bench.py $COMMON "$@" --calib 3 > "$w/pmc_fetch.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$w/pmc_write" -o w -- python3 bench.py $COMMON "$@" --calib 3 > "$w/pmc_write.log" 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$w/pmc_fetch" -o f -- python3 bench.py $COMMON "$@" --calib 3 > "$w/pmc_fetch.log" 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$w/pmc_write" -o w -- python3 bench.py $COMMON "$@" --calib 3 > "$w/pmc_write.log" 2>&1
   python3 scripts/pmc_traffic.py "$(ls "$w"/pmc_fetch/*/*counter_collection.csv "$w"/pmc_fetch/*counter_collection.csv 2>/dev/null | head -1)" \
       "$(ls "$w"/pmc_write/*/*counter_collection.csv "$w"/pmc_write/*counter_collection.csv 2>/dev/null | head -1)" "$w/pmc_traffic.json" "$name" > /dev/null \
     && python3 scripts/update_traffic.py "$w/pmc_traffic.json" "$w/bench.json" "profiles/$tag/$name/pmc_traffic.json" >> "$out/traffic_updates.txt"
@@ -33,7 +33,7 @@ profile cfg2_gx1_320x384 --grid 320x384 --xblocks 1 --yblocks 1 --dt 3600 --land
 profile cfg3_360x300_24blocks --grid 360x300 --xblocks 24 --yblocks 1 --dt 3600 --ns open
 profile cfg4_1440x1080 --grid 1440x1080 --xblocks 8 --yblocks 4 --dt 1800 --ns open
 # 3. SQ counters of the hot kernel (one pass of <= 8 SQ counters)
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d "$out/pmc_sq" -o sq -- python3 bench.py $COMMON > "$out/pmc_sq.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d "$out/pmc_sq" -o sq -- python3 bench.py $COMMON > "$out/pmc_sq.log" 2>&1
 python3 scripts/pmc_sq.py "$out/pmc_sq" k_subcycle2p > "$out/sq_counters.txt"
 rm -rf "$out"/pmc_sq
 # 4. other configurations in one table, PCIe-inclusive run, x-slab machinery on one GPU
