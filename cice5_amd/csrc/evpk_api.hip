@@ -2240,10 +2240,11 @@ static int planes_halo(evpk_ctx *c, double **d_list, const signed char *d_sgn, i
     return 0;
 }
 
-extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, double *mm, double *tm, const int32_t *tracer_type,
-                                    const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
-                                    int32_t l_fixed_area) {
-    if (!c || !mm || ncat < 1 || ntrace < 0 || (ntrace > 0 && (!tm || !tracer_type || !depend || !has_dependents))) return 1;
+// st == nullptr: mm / tm are the caller's aim / trm; else the caller's state arrays (host pointers in *st) through the fused transforms
+static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, double *mm, double *tm, const int32_t *tracer_type,
+                      const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
+                      int32_t l_fixed_area, const RemapState *st) {
+    if (!c || (!st && !mm) || ncat < 1 || ntrace < 0 || (ntrace > 0 && ((!st && !tm) || !tracer_type || !depend || !has_dependents))) return 1;
     if (!c->uploaded) FAIL(c, "evpk_transport_remap: no velocities on the device (run evp first)");
     if (!c->have_lengths) FAIL(c, "evpk_transport_remap needs HTN and HTE in evpk_geom");
     if (!c->rm_grid) FAIL(c, "evpk_transport_remap: evpk_remap_init has not been called");
@@ -2324,29 +2325,61 @@ extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_
     RemapPlanes P{(double *const *)c->rm_tab, ncp, ntp};
     // the caller's arrays: in place where their memory is visible to the device, else through a staging copy
     const size_t n_mm = (size_t)c->nblocks * ncp * nblk, n_tm = (size_t)c->nblocks * ntp * nblk;
-    double *dmm = (double *)mapped_alias(mm), *dtm = ntp ? (double *)mapped_alias(tm) : nullptr;
-    const bool st_mm = !dmm, st_tm = ntp && !dtm;
-    if (st_mm || st_tm) {
-        const size_t need = (st_mm ? n_mm : 0) + (st_tm ? n_tm : 0);
-        if (c->rm_stage_n < need) {
-            if (c->rm_stage) (void)hipFree(c->rm_stage);
-            c->rm_stage = nullptr; c->rm_stage_n = 0;
-            HIPCHK(c, hipMalloc(&c->rm_stage, sizeof(double) * need));
-            c->rm_stage_n = need;
-        }
-        double *q = c->rm_stage;
-        if (st_mm) { HIPCHK(c, hipMemcpyAsync(q, mm, sizeof(double) * n_mm, hipMemcpyHostToDevice, c->stream)); dmm = q; q += n_mm; }
-        if (st_tm) { HIPCHK(c, hipMemcpyAsync(q, tm, sizeof(double) * n_tm, hipMemcpyHostToDevice, c->stream)); dtm = q; }
-    }
-    // mm(nx_block, ny_block, 0:ncat, max_blocks), tm(nx_block, ny_block, ntrace, ncat, max_blocks) -> planes, one launch per array
     const dim3 b(64, 4);
     const int nrg = (c->nyb + 3) / 4;
     if ((long long)nrg * c->nblocks > 65535 || ntp > 65535) FAIL(c, "evpk_transport_remap: too many blocks for one launch");
-    hipLaunchKernelGGL(k_gather_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dmm,
-                       nblk, (size_t)ncp * nblk, (double *const *)c->rm_tab, nrg);
-    if (ntp)
-        hipLaunchKernelGGL(k_gather_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ntp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dtm,
-                           nblk, (size_t)ntp * nblk, (double *const *)(c->rm_tab + o_tm), nrg);
+    double *dmm = nullptr, *dtm = nullptr;
+    bool st_mm = false, st_tm = false;
+    RemapState io{};
+    double *host5[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t n5[5] = {0, 0, 0, 0, 0};
+    bool staged5[5] = {false, false, false, false, false};
+    if (!st) {
+        dmm = (double *)mapped_alias(mm); dtm = ntp ? (double *)mapped_alias(tm) : nullptr;
+        st_mm = !dmm; st_tm = ntp && !dtm;
+        if (st_mm || st_tm) {
+            const size_t need = (st_mm ? n_mm : 0) + (st_tm ? n_tm : 0);
+            if (c->rm_stage_n < need) {
+                if (c->rm_stage) (void)hipFree(c->rm_stage);
+                c->rm_stage = nullptr; c->rm_stage_n = 0;
+                HIPCHK(c, hipMalloc(&c->rm_stage, sizeof(double) * need));
+                c->rm_stage_n = need;
+            }
+            double *q = c->rm_stage;
+            if (st_mm) { HIPCHK(c, hipMemcpyAsync(q, mm, sizeof(double) * n_mm, hipMemcpyHostToDevice, c->stream)); dmm = q; q += n_mm; }
+            if (st_tm) { HIPCHK(c, hipMemcpyAsync(q, tm, sizeof(double) * n_tm, hipMemcpyHostToDevice, c->stream)); dtm = q; }
+        }
+        // mm(nx_block, ny_block, 0:ncat, max_blocks), tm(nx_block, ny_block, ntrace, ncat, max_blocks) -> planes, one launch per array
+        hipLaunchKernelGGL(k_gather_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dmm,
+                           nblk, (size_t)ncp * nblk, (double *const *)c->rm_tab, nrg);
+        if (ntp)
+            hipLaunchKernelGGL(k_gather_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ntp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dtm,
+                               nblk, (size_t)ntp * nblk, (double *const *)(c->rm_tab + o_tm), nrg);
+    } else {
+        // aice0, aicen, vicen, vsnon, trcrn: state_to_tracers inside the gather
+        io = *st;
+        host5[0] = st->aice0; host5[1] = st->aicen; host5[2] = st->vicen; host5[3] = st->vsnon; host5[4] = st->trcrn;
+        n5[0] = (size_t)c->nblocks * nblk; n5[1] = n5[2] = n5[3] = n5[0] * ncat; n5[4] = n5[0] * ncat * st->ntrcr_dim;
+        double **dev5[5] = {&io.aice0, &io.aicen, &io.vicen, &io.vsnon, &io.trcrn};
+        size_t need = 0;
+        for (int q = 0; q < 5; q++) {
+            *dev5[q] = host5[q] ? (double *)mapped_alias(host5[q]) : nullptr;
+            staged5[q] = host5[q] && !*dev5[q];
+            if (staged5[q]) need += n5[q];
+        }
+        if (need) {
+            if (c->rm_stage_n < need) {
+                if (c->rm_stage) (void)hipFree(c->rm_stage);
+                c->rm_stage = nullptr; c->rm_stage_n = 0;
+                HIPCHK(c, hipMalloc(&c->rm_stage, sizeof(double) * need));
+                c->rm_stage_n = need;
+            }
+            double *q2 = c->rm_stage;
+            for (int q = 0; q < 5; q++)
+                if (staged5[q]) { HIPCHK(c, hipMemcpyAsync(q2, host5[q], sizeof(double) * n5[q], hipMemcpyHostToDevice, c->stream)); *dev5[q] = q2; q2 += n5[q]; }
+        }
+        hipLaunchKernelGGL(k_state_gather, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, io, P, nrg);
+    }
     HIPCHK(c, hipGetLastError());
     double **dl = c->rm_tab + nplanes;
     if (planes_halo(c, dl, c->rm_sgn, (int)nA, false)) return 1;
@@ -2370,16 +2403,43 @@ extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_
     // (ranks decide alone, as the reference's l_stop is per task: the caller aborts the run, abort_ice)
     if (bad & 1u) { c->err = "evpk_transport_remap: departure points out of bounds (ice_transport_remap.F90:1583-1607)"; return EVPK_REMAP_BAD_DEPARTURE; }
     if (bad & 2u) { c->err = "evpk_transport_remap: negative area / mass after the update (ice_transport_remap.F90:3622-3640)"; return EVPK_REMAP_NEGATIVE_MASS; }
-    hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
-                       (double *const *)c->rm_tab, dmm, nblk, (size_t)ncp * nblk, nrg);
-    if (ntp)
-        hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ntp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
-                           (double *const *)(c->rm_tab + o_tm), dtm, nblk, (size_t)ntp * nblk, nrg);
-    HIPCHK(c, hipGetLastError());
-    if (st_mm) HIPCHK(c, hipMemcpyAsync(mm, dmm, sizeof(double) * n_mm, hipMemcpyDeviceToHost, c->stream));
-    if (st_tm) HIPCHK(c, hipMemcpyAsync(tm, dtm, sizeof(double) * n_tm, hipMemcpyDeviceToHost, c->stream));
+    if (!st) {
+        hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
+                           (double *const *)c->rm_tab, dmm, nblk, (size_t)ncp * nblk, nrg);
+        if (ntp)
+            hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ntp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
+                               (double *const *)(c->rm_tab + o_tm), dtm, nblk, (size_t)ntp * nblk, nrg);
+        HIPCHK(c, hipGetLastError());
+        if (st_mm) HIPCHK(c, hipMemcpyAsync(mm, dmm, sizeof(double) * n_mm, hipMemcpyDeviceToHost, c->stream));
+        if (st_tm) HIPCHK(c, hipMemcpyAsync(tm, dtm, sizeof(double) * n_tm, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        // bound_state: the ghost ring of the NEW areas and tracers, then tracers_to_state on every cell of every block
+        if (planes_halo(c, dl, c->rm_sgn, (int)nA, false)) return 1;
+        hipLaunchKernelGGL(k_state_scatter, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, io, P, nrg);
+        HIPCHK(c, hipGetLastError());
+        double *dev5[5] = {io.aice0, io.aicen, io.vicen, io.vsnon, io.trcrn};
+        for (int q = 0; q < 5; q++)
+            if (staged5[q]) HIPCHK(c, hipMemcpyAsync(host5[q], dev5[q], sizeof(double) * n5[q], hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, double *mm, double *tm, const int32_t *tracer_type,
+                                    const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
+                                    int32_t l_fixed_area) {
+    return remap_impl(c, dt, ncat, ntrace, mm, tm, tracer_type, depend, has_dependents, integral_order, l_dp_midpt, l_fixed_area, nullptr);
+}
+
+extern "C" int evpk_transport_remap_state(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrcr, int32_t ntrcr_dim, int32_t nt_qsno, int32_t nslyr,
+                                          double rhos_lfresh, double *aice0, double *aicen, double *vicen, double *vsnon, double *trcrn,
+                                          const int32_t *tracer_type, const int32_t *depend, const int32_t *has_dependents,
+                                          int32_t integral_order, int32_t l_dp_midpt) {
+    if (!c || !aice0 || !aicen || !vicen || !vsnon || ntrcr < 0 || (ntrcr > 0 && !trcrn) || ntrcr_dim < ntrcr) return 1;
+    RemapState st{};
+    st.aice0 = aice0; st.aicen = aicen; st.vicen = vicen; st.vsnon = vsnon; st.trcrn = trcrn;
+    st.ncat = ncat; st.ntrcr = ntrcr; st.ntrcr_dim = ntrcr_dim; st.nt_qsno = nt_qsno; st.nslyr = nslyr; st.shift = rhos_lfresh;
+    return remap_impl(c, dt, ncat, 2 + ntrcr, nullptr, nullptr, tracer_type, depend, has_dependents, integral_order, l_dp_midpt, 0, &st);
 }
 
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {

@@ -538,6 +538,69 @@ __global__ void k_scatter_planes(Slab s, const BlockDesc *bd, int nxb, int nyb, 
     dst[(size_t)blockIdx.z * pstride + (size_t)b * bstride + (size_t)(j - 1) * nxb + (i - 1)] = src[blockIdx.z][mcell(s, si, sj)];
 }
 
+// ---- state_to_tracers (ice_transport_driver.F90:789-900) fused with the gather, tracers_to_state (:908-1003) + bound_state
+// (ice_state.F90:173-238) fused with the scatter: the caller's aice0, aicen, vicen, vsnon, trcrn instead of aim / trm ----
+struct RemapState {
+    double *aice0, *aicen, *vicen, *vsnon, *trcrn;      // block arrays: (nb, ny, nx), (nb, ncat, ny, nx) x 3, (nb, ncat, ntrcr_dim, ny, nx)
+    int ncat, ntrcr, ntrcr_dim, nt_qsno, nslyr;         // nt_qsno 1-based: tracers nt_qsno .. nt_qsno+nslyr-1 are snow enthalpies
+    double shift;                                       // rhos*Lfresh (:866, :988)
+};
+__global__ void k_state_gather(Slab s, const BlockDesc *bd, int nxb, int nyb, RemapState io, RemapPlanes P, int nrg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int b = blockIdx.y / nrg, j = (blockIdx.y % nrg) * blockDim.y + threadIdx.y + 1, n = blockIdx.z;
+    if (i > nxb || j > nyb) return;
+    const BlockDesc d = bd[b];
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
+    const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
+    if (!gather_take(s, d, i, j, si, sj)) return;
+    const size_t km = mcell(s, si, sj), nblk = (size_t)nxb * nyb, kb = (size_t)(j - 1) * nxb + (i - 1);
+    if (n == 0) { P.mm(0)[km] = io.aice0[(size_t)b * nblk + kb]; return; }
+    const size_t kc = ((size_t)b * io.ncat + (n - 1)) * nblk + kb;
+    const double a = io.aicen[kc];
+    P.mm(n)[km] = a;
+    const int ntrace = 2 + io.ntrcr, p0 = (n - 1) * ntrace;
+    const bool ice = a > RM_PUNY;
+    const double w1 = ice ? 1.0 / a : 0.0;
+    P.tm(p0)[km] = ice ? io.vicen[kc] * w1 : 0.0;                                     // hice
+    P.tm(p0 + 1)[km] = ice ? io.vsnon[kc] * w1 : 0.0;                                 // hsno
+    for (int it = 1; it <= io.ntrcr; it++) {
+        double v = 0.0;
+        if (ice) {
+            v = io.trcrn[(((size_t)b * io.ncat + (n - 1)) * io.ntrcr_dim + (it - 1)) * nblk + kb];
+            if (it >= io.nt_qsno && it < io.nt_qsno + io.nslyr) v = v + io.shift;
+        }
+        P.tm(p0 + 2 + it - 1)[km] = v;
+    }
+}
+// every cell of every block (ghost cells too: their slab cell holds the neighbour's new values or, on the slab's ring, what the
+// halo update of the planes brought) whose new area is > 0; the others keep what they had, as tracers_to_state leaves them
+__global__ void k_state_scatter(Slab s, const BlockDesc *bd, int nxb, int nyb, RemapState io, RemapPlanes P, int nrg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int b = blockIdx.y / nrg, j = (blockIdx.y % nrg) * blockDim.y + threadIdx.y + 1, n = blockIdx.z;
+    if (i > nxb || j > nyb) return;
+    const BlockDesc d = bd[b];
+    int si, sj;
+    if (!scatter_take(s, d, i, j, MODE_ALL, si, sj)) return;
+    const size_t km = mcell(s, si, sj), nblk = (size_t)nxb * nyb, kb = (size_t)(j - 1) * nxb + (i - 1);
+    if (n == 0) {                                                                     // aice0 = aim(:,:,0); not part of bound_state
+        if (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi) io.aice0[(size_t)b * nblk + kb] = P.mm(0)[km];
+        return;
+    }
+    const double a = P.mm(n)[km];
+    if (!(a > 0.0)) return;
+    const size_t kc = ((size_t)b * io.ncat + (n - 1)) * nblk + kb;
+    const int ntrace = 2 + io.ntrcr, p0 = (n - 1) * ntrace;
+    io.aicen[kc] = a;
+    io.vicen[kc] = a * P.tm(p0)[km];
+    io.vsnon[kc] = a * P.tm(p0 + 1)[km];
+    for (int it = 1; it <= io.ntrcr; it++) {
+        double v = P.tm(p0 + 2 + it - 1)[km];
+        if (it >= io.nt_qsno && it < io.nt_qsno + io.nslyr) v = v - io.shift;
+        io.trcrn[(((size_t)b * io.ncat + (n - 1)) * io.ntrcr_dim + (it - 1)) * nblk + kb] = v;
+    }
+}
+
 // ---- frame (two outermost rows / columns) of a list of planes <-> consecutive planes of the pair-interleaved slab, where
 // the general halo update works (several ranks, forced exchange); back: the ghost ring only ----
 __global__ void k_planes_frame(Slab s, double *const *planes, int f0, int nf, int back) {

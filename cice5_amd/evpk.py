@@ -89,7 +89,7 @@ EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "
            "evpk_subcycle", "evpk_finish", "evpk_download", "evpk_sync", "evpk_get_stats", "evpk_destroy",
            "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
            "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
-           "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap",
+           "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap", "evpk_transport_remap_state",
            "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download"]
 
 REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS = 11, 12        # include/evpk.h
@@ -135,6 +135,8 @@ def lib():
         L.evpk_remap_init.argtypes = [ctxp, c_f64p, c_f64p, c_f64p]
         L.evpk_transport_remap.argtypes = [ctxp, ct.c_double, ct.c_int32, ct.c_int32, c_f64p, c_f64p, c_i32p, c_i32p, c_i32p,
                                            ct.c_int32, ct.c_int32, ct.c_int32]
+        L.evpk_transport_remap_state.argtypes = ([ctxp, ct.c_double] + [ct.c_int32] * 5 + [ct.c_double] + [c_f64p] * 5 + [c_i32p] * 3 +
+                                                 [ct.c_int32] * 2)
         L.evpk_eap_init.argtypes = [ctxp, ct.c_int32, ct.c_int32, ct.c_int32] + [c_f64p] * 6
         L.evpk_eap_upload.argtypes = [ctxp, ct.POINTER(EapState)]
         L.evpk_eap_download.argtypes = [ctxp, ct.POINTER(EapState)]
@@ -320,6 +322,19 @@ class Context:
                                           int(integral_order), int(l_dp_midpt), int(l_fixed_area))
         if rc not in (0, REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS):
             self._chk(rc, "evpk_transport_remap")
+        return int(rc)
+
+    def transport_remap_state(self, dt: float, aice0, aicen, vicen, vsnon, trcrn, ntrcr: int, nt_qsno: int, nslyr: int, rhos_lfresh: float,
+                              tracer_type, depend, has_dependents, integral_order: int = 3, l_dp_midpt: bool = True) -> int:
+        """evpk_transport_remap_state: aice0 (nblocks, ny, nx), aicen / vicen / vsnon (nblocks, ncat, ny, nx), trcrn (nblocks, ncat, ntrcr_dim,
+        ny, nx) in place -- state_to_tracers, horizontal_remap, tracers_to_state and bound_state on the device"""
+        ncat, ntrcr_dim = aicen.shape[1], (trcrn.shape[2] if trcrn is not None else 0)
+        tt, dp, hd = (np.ascontiguousarray(a, dtype=np.int32) for a in (tracer_type, depend, has_dependents))
+        rc = self._L.evpk_transport_remap_state(self._ctx, float(dt), ncat, int(ntrcr), ntrcr_dim, int(nt_qsno), int(nslyr), float(rhos_lfresh),
+                                                _p64(aice0), _p64(aicen), _p64(vicen), _p64(vsnon), _p64(trcrn), _p32(tt), _p32(dp), _p32(hd),
+                                                int(integral_order), int(l_dp_midpt))
+        if rc not in (0, REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS):
+            self._chk(rc, "evpk_transport_remap_state")
         return int(rc)
 
     def eap_init(self, tables):

@@ -99,7 +99,7 @@
                 evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
                 evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
                 evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read, &
-                evpk_transport_upwind, evpk_remap_init, evpk_transport_remap, &
+                evpk_transport_upwind, evpk_remap_init, evpk_transport_remap, evpk_transport_remap_state, &
                 EVPK_REMAP_BAD_DEPARTURE, EVPK_REMAP_NEGATIVE_MASS, &
                 evpk_eap_state, evpk_eap_init, evpk_eap_upload, evpk_eap_download
 
@@ -218,6 +218,17 @@
             integer (c_int32_t), value :: ncat, ntrace
             type (c_ptr), value :: mm, tm, tracer_type, depend, has_dependents
             integer (c_int32_t), value :: integral_order, l_dp_midpt, l_fixed_area
+         end function
+         ! transport_remap with state_to_tracers / tracers_to_state / bound_state on the device too: the state arrays themselves
+         integer (c_int) function evpk_transport_remap_state (ctx, dt, ncat, ntrcr, ntrcr_dim, nt_qsno, nslyr, rhos_lfresh, &
+               aice0, aicen, vicen, vsnon, trcrn, tracer_type, depend, has_dependents, integral_order, l_dp_midpt) &
+               bind(C, name='evpk_transport_remap_state')
+            import :: c_int, c_ptr, c_double, c_int32_t
+            type (c_ptr), value :: ctx
+            real (c_double), value :: dt, rhos_lfresh
+            integer (c_int32_t), value :: ncat, ntrcr, ntrcr_dim, nt_qsno, nslyr
+            type (c_ptr), value :: aice0, aicen, vicen, vsnon, trcrn, tracer_type, depend, has_dependents
+            integer (c_int32_t), value :: integral_order, l_dp_midpt
          end function
          ! EAP (ice_dyn_eap.F90): tables of init_eap once, then the context runs eap(dt); structure tensor up / everything down
          integer (c_int) function evpk_eap_init (ctx, nx_yield, ny_yield, na_yield, s11r, s12r, s22r, s11s, s12s, s22s) &

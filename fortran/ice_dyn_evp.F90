@@ -40,7 +40,7 @@
       public :: evpk_resident_state, evpk_state_changed_on_host, evpk_device_strength
       public :: evpk_bound_seconds, evpk_loop_seconds
       public :: evpk_download_all, evpk_sparse_io
-      public :: evpk_horizontal_remap, evpk_eap
+      public :: evpk_horizontal_remap, evpk_eap, evpk_transport_remap_core
       save
 
       ! .true. (default): every array the reference's evp leaves modified comes back every call.  .false. (with
@@ -517,6 +517,54 @@
       if (rc /= 0) call abort_ice('horizontal_remap: evpk_transport_remap: '//trim(evpk_error_string(ctx)))
 
       end subroutine evpk_horizontal_remap
+
+!=======================================================================
+! The core of transport_remap (reference: ice_transport_driver.F90:198-627 with its compile-time-off checks): state_to_tracers,
+! horizontal_remap, tracers_to_state and bound_state in ONE call on the module arrays of ice_state -- for a host that wants the
+! whole advection on the device (its state in device or page-locked memory) instead of the call-compatible
+! evpk_horizontal_remap above.  In transport_remap the lines from the state_to_tracers loop (:340-349) through bound_state
+! (:500-503) become
+!     call evpk_transport_remap_core (dt, ntrace, tracer_type, depend, has_dependents, integral_order, l_dp_midpt)
+
+      subroutine evpk_transport_remap_core (dt, ntrace, tracer_type, depend, has_dependents, integral_order, l_dp_midpt)
+
+      use ice_constants, only: rhos, Lfresh
+      use ice_domain_size, only: ncat, nslyr, max_ntrcr
+      use ice_grid, only: dxu, dyu, hm
+      use ice_state, only: aice0, aicen, vicen, vsnon, trcrn, ntrcr, nt_qsno
+      use ice_exit, only: abort_ice
+
+      real (kind=dbl_kind), intent(in) :: dt
+      integer (kind=int_kind), intent(in) :: ntrace
+      integer (kind=int_kind), dimension (ntrace), intent(in) :: tracer_type, depend
+      logical (kind=log_kind), dimension (ntrace), intent(in) :: has_dependents
+      integer (kind=int_kind), intent(in) :: integral_order
+      logical (kind=log_kind), intent(in) :: l_dp_midpt
+
+      integer (c_int32_t), dimension (max(ntrace,1)), target :: ttype, dep, has
+      integer (c_int) :: rc
+      logical (kind=log_kind), save :: first = .true.
+
+      if (.not. c_associated(ctx)) call abort_ice('transport_remap: no velocities on the device: evp has not run yet')
+      if (ntrace /= ntrcr + 2) call abort_ice('transport_remap: ntrace /= ntrcr + 2')
+      if (first) then
+         rc = evpk_remap_init (ctx, loc_r8(dxu), loc_r8(dyu), loc_r8(hm))
+         if (rc /= 0) call abort_ice('transport_remap: evpk_remap_init: '//trim(evpk_error_string(ctx)))
+         first = .false.
+      endif
+      ttype(1:ntrace) = tracer_type(1:ntrace)
+      dep(1:ntrace) = depend(1:ntrace)
+      has(1:ntrace) = merge(1, 0, has_dependents(1:ntrace))
+      rc = evpk_transport_remap_state (ctx, dt, int(ncat, c_int32_t), int(ntrcr, c_int32_t), int(max_ntrcr, c_int32_t), &
+                                       int(nt_qsno, c_int32_t), int(nslyr, c_int32_t), rhos*Lfresh, &
+                                       loc_r8(aice0), loc_r8(aicen), loc_r8(vicen), loc_r8(vsnon), loc_r8(trcrn), &
+                                       c_loc(ttype), c_loc(dep), c_loc(has), int(integral_order, c_int32_t), &
+                                       merge(1_c_int32_t, 0_c_int32_t, l_dp_midpt))
+      if (rc == EVPK_REMAP_BAD_DEPARTURE) call abort_ice('remap transport: bad departure points')
+      if (rc == EVPK_REMAP_NEGATIVE_MASS) call abort_ice('remap transport: negative area')
+      if (rc /= 0) call abort_ice('transport_remap: evpk_transport_remap_state: '//trim(evpk_error_string(ctx)))
+
+      end subroutine evpk_transport_remap_core
 
 !=======================================================================
 ! eap(dt) (reference: ice_dyn_eap.F90:66-486) on the device.  The lookup tables and the structure tensor are private to the

@@ -18,7 +18,7 @@
       implicit none
       real (kind=dbl_kind), parameter :: c0 = 0.0_dbl_kind, c1 = 1.0_dbl_kind, &
          p001 = 0.001_dbl_kind, p01 = 0.01_dbl_kind, &
-         rhos = 330.0_dbl_kind, rhoi = 917.0_dbl_kind, rhow = 1026.0_dbl_kind, gravit = 9.80616_dbl_kind
+         Lfresh = 3.34e5_dbl_kind, rhos = 330.0_dbl_kind, rhoi = 917.0_dbl_kind, rhow = 1026.0_dbl_kind, gravit = 9.80616_dbl_kind
       integer (int_kind), parameter :: field_loc_center = 1, field_loc_NEcorner = 2, &
          field_type_scalar = 1, field_type_vector = 2
       end module ice_constants
@@ -26,7 +26,7 @@
       module ice_domain_size
       use ice_kinds_mod
       implicit none
-      integer (int_kind) :: nx_global, ny_global, max_blocks, ncat = 1
+      integer (int_kind) :: nx_global, ny_global, max_blocks, ncat = 1, nslyr = 1, max_ntrcr = 1
       end module ice_domain_size
 
       module ice_exit
@@ -159,7 +159,9 @@
       implicit none
       real (kind=dbl_kind), dimension(:,:,:), allocatable :: &
          aice, vice, vsno, aice_init, aice0, uvel, vvel, divu, shear, strength
-      real (kind=dbl_kind), dimension(:,:,:,:), allocatable :: aicen, vicen
+      real (kind=dbl_kind), dimension(:,:,:,:), allocatable :: aicen, vicen, vsnon
+      real (kind=dbl_kind), dimension(:,:,:,:,:), allocatable :: trcrn
+      integer (kind=int_kind) :: ntrcr = 0, nt_qsno = 1
       end module ice_state
 
       module ice_flux

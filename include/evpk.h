@@ -236,6 +236,22 @@ int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, d
                          const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
                          int32_t l_fixed_area);
 
+/* The same with the state transforms of transport_remap (ice_transport_driver.F90:198-627) on the device too: state_to_tracers
+ * (:789-900) inside the gather, tracers_to_state (:908-1003) and bound_state (ice_state.F90:173-238) inside the scatter, so that
+ * the caller hands over its state arrays as they are (the optional conservation / monotonicity checks of the reference are
+ * compile-time .false., :255-257, and are not reproduced):
+ *   aice0 (nx_block, ny_block, max_blocks), aicen, vicen, vsnon (nx_block, ny_block, ncat, max_blocks),
+ *   trcrn (nx_block, ny_block, ntrcr_dim, ncat, max_blocks) of which tracers 1 .. ntrcr are in use (ice_state.F90: max_ntrcr / ntrcr)
+ *   nt_qsno (1-based), nslyr: the snow enthalpy tracers, advected as trcrn + rhos*Lfresh (:866, :988); rhos_lfresh = that constant
+ *   tracer_type, depend, has_dependents: (2 + ntrcr), as init_transport sets them for hice, hsno and the ntrcr tracers
+ * In / out, every cell of every block: physical cells whose new area is > 0 are rewritten (the others keep their values, as
+ * tracers_to_state leaves them), ghost cells take their neighbours' new values (bound_state).  Ghost cells must be current on
+ * entry.  Return values as evpk_transport_remap. */
+int evpk_transport_remap_state(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrcr, int32_t ntrcr_dim, int32_t nt_qsno, int32_t nslyr,
+                               double rhos_lfresh, double *aice0, double *aicen, double *vicen, double *vsnon, double *trcrn,
+                               const int32_t *tracer_type, const int32_t *depend, const int32_t *has_dependents,
+                               int32_t integral_order, int32_t l_dp_midpt);
+
 /* the elastic-anisotropic-plastic rheology, eap(dt) (source/ice_dyn_eap.F90:66-486; kdyn = 2,
  * ice_step_mod.F90:1118).  eap is evp with another stress: evp_prep1/2, stepu, the velocity halo, evp_finish are shared
  * (:79-80), stress_eap (:1052-1467) with update_stress_rdg (:1474-1658) takes the place of stress, stepa (:1664-1787, with

@@ -203,6 +203,13 @@ void orc_evp(const orc_geom *g, const orc_params *p, orc_fields *f, int nsub_ove
 #ifdef __cplusplus
 }
 #endif
+/* transport_remap (ice_transport_driver.F90:198-627; remap_oracle.c): state_to_tracers, horizontal_remap, tracers_to_state, bound_state */
+int orc_transport_remap_state(const orc_geom *g, double dt, int ncat, int ntrcr, int ntrcr_dim, int nt_qsno, int nslyr, double rhos_lfresh,
+                              const double *uvel, const double *vvel, double *aice0, double *aicen, double *vicen, double *vsnon, double *trcrn,
+                              const int32_t *tracer_type, const int32_t *depend, const int32_t *has_dependents, int integral_order,
+                              int l_dp_midpt, const double *HTE, const double *HTN, const double *dxu, const double *dyu, const double *tarear,
+                              const double *hm);
+
 /* eap(dt) (ice_dyn_eap.F90:66-486): evp's driver with stress_eap for stress, stepa every tenth subcycle, no stress fold */
 void orc_eap(const orc_geom *g, const orc_params *p, orc_fields *f, orc_eap_state *e, int nsub_override, int64_t counts[2], double *loop_seconds);
 void orc_eap_stress(int nx, int ny, int ksub, int ndte, int icellt, const int32_t *indxti, const int32_t *indxtj, double arlx1i, double denom1,

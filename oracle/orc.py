@@ -124,6 +124,8 @@ def lib():
         _lib.orc_horizontal_remap.argtypes = ([ct.POINTER(OrcGeom), ct.c_double, ct.c_int, ct.c_int] + [c_f64p] * 4 + [ct.c_int] +
                                               [c_i32p] * 3 + [ct.c_int, ct.c_int] + [c_f64p] * 6)
         _lib.orc_horizontal_remap.restype = ct.c_int
+        _lib.orc_transport_remap_state.argtypes = ([ct.POINTER(OrcGeom), ct.c_double] + [ct.c_int] * 5 + [ct.c_double] + [c_f64p] * 7 +
+                                                   [c_i32p] * 3 + [ct.c_int] * 2 + [c_f64p] * 6)
         _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
         _lib.orc_principal_stress.argtypes = [ct.c_int, ct.c_int] + [c_f64p] * 6
         _lib.orc_set_halo_callback.argtypes = [HALO_CB, ct.c_void_p]
@@ -260,6 +262,20 @@ def horizontal_remap(d, dt: float, f: Dict[str, np.ndarray], mm: np.ndarray, tm:
                                     _p32(np.ascontiguousarray(depend, dtype=np.int32)),
                                     _p32(np.ascontiguousarray(has_dependents, dtype=np.int32)), int(integral_order), int(l_dp_midpt),
                                     _p64(f["HTE"]), _p64(f["HTN"]), _p64(f["dxu"]), _p64(f["dyu"]), _p64(f["tarear"]), _p64(f["hm"]))
+    del keep
+    return int(rc)
+
+
+def transport_remap_state(d, dt: float, f: Dict[str, np.ndarray], aice0, aicen, vicen, vsnon, trcrn, ntrcr: int, nt_qsno: int, nslyr: int,
+                          rhos_lfresh: float, tracer_type, depend, has_dependents, integral_order: int = 3, l_dp_midpt: bool = True) -> int:
+    """orc_transport_remap_state: aice0 (nb, ny, nx), aicen / vicen / vsnon (nb, ncat, ny, nx), trcrn (nb, ncat, ntrcr_dim, ny, nx), in place"""
+    g, keep = make_geom(d)
+    ncat, ntrcr_dim = aicen.shape[1], trcrn.shape[2]
+    rc = lib().orc_transport_remap_state(ct.byref(g), float(dt), ncat, int(ntrcr), ntrcr_dim, int(nt_qsno), int(nslyr), float(rhos_lfresh),
+                                         _p64(f["uvel"]), _p64(f["vvel"]), _p64(aice0), _p64(aicen), _p64(vicen), _p64(vsnon), _p64(trcrn),
+                                         _p32(np.ascontiguousarray(tracer_type, dtype=np.int32)), _p32(np.ascontiguousarray(depend, dtype=np.int32)),
+                                         _p32(np.ascontiguousarray(has_dependents, dtype=np.int32)), int(integral_order), int(l_dp_midpt),
+                                         _p64(f["HTE"]), _p64(f["HTN"]), _p64(f["dxu"]), _p64(f["dyu"]), _p64(f["tarear"]), _p64(f["hm"]))
     del keep
     return int(rc)
 

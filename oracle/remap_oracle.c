@@ -574,3 +574,81 @@ int orc_horizontal_remap(const orc_geom *g, double dt, int ncat, int ntrace, con
     free(dpx); free(dpy); free(mc); free(mx); free(my); free(tc); free(tx); free(ty);
     return rc;
 }
+
+/* ---------------------------------------------------------------------------
+ * transport_remap (ice_transport_driver.F90:198-627) with its optional checks off (they are compile-time .false., :255-257):
+ * state_to_tracers (:789-900), horizontal_remap, tracers_to_state (:908-1003), bound_state (ice_state.F90: the ghost-cell update of
+ * aicen, trcrn, vicen, vsnon; aice0 is not part of it).
+ * aice0 (nb, ny, nx); aicen, vicen, vsnon (nb, ncat, ny, nx); trcrn (nb, ncat, ntrcr_dim, ny, nx) of which the first ntrcr tracers are
+ * in use (the reference passes trcrn(:,:,1:ntrcr,:,iblk)); nt_qsno 1-based, nslyr: the snow enthalpy tracers, shifted by rhos*Lfresh.
+ * tracer_type / depend / has_dependents: (2 + ntrcr), as init_transport sets them.
+ * ------------------------------------------------------------------------- */
+int orc_transport_remap_state(const orc_geom *g, double dt, int ncat, int ntrcr, int ntrcr_dim, int nt_qsno, int nslyr, double rhos_lfresh,
+                              const double *uvel, const double *vvel, double *aice0, double *aicen, double *vicen, double *vsnon, double *trcrn,
+                              const int32_t *tracer_type, const int32_t *depend, const int32_t *has_dependents, int integral_order,
+                              int l_dp_midpt, const double *HTE, const double *HTN, const double *dxu, const double *dyu, const double *tarear,
+                              const double *hm) {
+    const int nx = g->nx_block, ny = g->ny_block, nb = g->nblocks, ntrace = 2 + ntrcr, ncp = ncat + 1;
+    const size_t nn = (size_t)nx * ny;
+    double *aim = calloc((size_t)nb * ncp * nn, 8), *trm = calloc((size_t)nb * ncat * ntrace * nn, 8);
+#define AIM(b, n) (aim + ((size_t)(b) * ncp + (n)) * nn)
+#define TRM(b, n, nt) (trm + (((size_t)(b) * ncat + ((n)-1)) * ntrace + (nt)) * nn)
+#define ST3(a, b, n) ((a) + ((size_t)(b) * ncat + ((n)-1)) * nn)
+#define TRC(b, n, it) (trcrn + (((size_t)(b) * ncat + ((n)-1)) * ntrcr_dim + (it)) * nn)
+    for (int b = 0; b < nb; b++) {                                                    /* state_to_tracers */
+        memcpy(AIM(b, 0), aice0 + (size_t)b * nn, nn * 8);
+        for (int n = 1; n <= ncat; n++) {
+            const double *an = ST3(aicen, b, n), *vi = ST3(vicen, b, n), *vs = ST3(vsnon, b, n);
+            double *am = AIM(b, n);
+            for (size_t k = 0; k < nn; k++) {
+                am[k] = an[k];
+                if (!(am[k] > puny)) continue;
+                const double w1 = c1 / am[k];
+                TRM(b, n, 0)[k] = vi[k] * w1;
+                TRM(b, n, 1)[k] = vs[k] * w1;
+                for (int it = 1; it <= ntrcr; it++) {
+                    const double v = TRC(b, n, it - 1)[k];
+                    TRM(b, n, 2 + it - 1)[k] = (it >= nt_qsno && it < nt_qsno + nslyr) ? v + rhos_lfresh : v;
+                }
+            }
+        }
+    }
+    const int rc = orc_horizontal_remap(g, dt, ncat, ntrace, uvel, vvel, aim, trm, 0, tracer_type, depend, has_dependents, integral_order,
+                                        l_dp_midpt, HTE, HTN, dxu, dyu, tarear, hm);
+    if (!rc) {
+        for (int b = 0; b < nb; b++) {                                                /* tracers_to_state: every cell of the block with aim > 0 */
+            memcpy(aice0 + (size_t)b * nn, AIM(b, 0), nn * 8);
+            for (int n = 1; n <= ncat; n++) {
+                double *an = ST3(aicen, b, n), *vi = ST3(vicen, b, n), *vs = ST3(vsnon, b, n);
+                const double *am = AIM(b, n);
+                for (size_t k = 0; k < nn; k++) {
+                    if (!(am[k] > c0)) continue;
+                    an[k] = am[k];
+                    vi[k] = am[k] * TRM(b, n, 0)[k];
+                    vs[k] = am[k] * TRM(b, n, 1)[k];
+                    for (int it = 1; it <= ntrcr; it++) {
+                        const double v = TRM(b, n, 2 + it - 1)[k];
+                        TRC(b, n, it - 1)[k] = (it >= nt_qsno && it < nt_qsno + nslyr) ? v - rhos_lfresh : v;
+                    }
+                }
+            }
+        }
+        /* bound_state: planes of one category / tracer are strided in these arrays, so each is copied out, updated, copied back */
+        double *w = malloc((size_t)nb * nn * 8);
+        for (int n = 1; n <= ncat; n++)
+            for (int q = 0; q < 3 + ntrcr; q++) {
+                for (int b = 0; b < nb; b++) {
+                    const double *src = q == 0 ? ST3(aicen, b, n) : q == 1 ? ST3(vicen, b, n) : q == 2 ? ST3(vsnon, b, n) : TRC(b, n, q - 3);
+                    memcpy(w + (size_t)b * nn, src, nn * 8);
+                }
+                orc_halo_r8(g, w, ORC_LOC_CENTER, ORC_KIND_SCALAR, 0.0);
+                for (int b = 0; b < nb; b++) {
+                    double *dst = q == 0 ? ST3(aicen, b, n) : q == 1 ? ST3(vicen, b, n) : q == 2 ? ST3(vsnon, b, n) : TRC(b, n, q - 3);
+                    memcpy(dst, w + (size_t)b * nn, nn * 8);
+                }
+            }
+        free(w);
+    }
+    free(aim); free(trm);
+    return rc;
+}

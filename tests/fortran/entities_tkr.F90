@@ -9,6 +9,7 @@
       subroutine r8_0 (a);  real (kind=dbl_kind), intent(in) :: a;  end subroutine
       subroutine r8_3 (a);  real (kind=dbl_kind), dimension(:,:,:), intent(in) :: a;  end subroutine
       subroutine r8_4 (a);  real (kind=dbl_kind), dimension(:,:,:,:), intent(in) :: a;  end subroutine
+      subroutine r8_5 (a);  real (kind=dbl_kind), dimension(:,:,:,:,:), intent(in) :: a;  end subroutine
       subroutine l_0 (a);   logical (kind=log_kind), intent(in) :: a;  end subroutine
       subroutine l_3 (a);   logical (kind=log_kind), dimension(:,:,:), intent(in) :: a;  end subroutine
       subroutine i4_0 (a);  integer (kind=int_kind), intent(in) :: a;  end subroutine
@@ -26,9 +27,9 @@
       use ice_boundary, only: ice_HaloUpdate
       use ice_blocks, only: block, get_block, nx_block, ny_block
       use ice_communicate, only: my_task, master_task, get_num_procs
-      use ice_constants, only: field_loc_center, field_type_scalar, c0, rhow, rhoi, rhos, gravit, p001, p01
+      use ice_constants, only: field_loc_center, field_type_scalar, c0, rhow, rhoi, rhos, gravit, p001, p01, Lfresh
       use ice_domain, only: nblocks, blocks_ice, halo_info, ew_boundary_type, ns_boundary_type
-      use ice_domain_size, only: max_blocks, nx_global, ny_global, ncat
+      use ice_domain_size, only: max_blocks, nx_global, ny_global, ncat, nslyr, max_ntrcr
       use ice_exit, only: abort_ice
       use ice_flux, only: rdg_conv, rdg_shear, prs_sig, strairxT, strairyT, strairx, strairy, uocn, vocn, &
           ss_tltx, ss_tlty, iceumask, fm, strtltx, strtlty, strocnx, strocny, strintx, strinty, strocnxT, strocnyT, &
@@ -36,7 +37,8 @@
           stress12_1, stress12_2, stress12_3, stress12_4
       use ice_grid, only: tmask, umask, dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, uarear, tinyarea, tarea, uarea, HTN, HTE, dxu, dyu, hm
       use ice_mechred, only: ice_strength, kstrength, krdg_partic, krdg_redist, mu_rdg, Cf
-      use ice_state, only: aice, vice, vsno, uvel, vvel, divu, shear, aice_init, aice0, aicen, vicen, strength
+      use ice_state, only: aice, vice, vsno, uvel, vvel, divu, shear, aice_init, aice0, aicen, vicen, strength, &
+          vsnon, trcrn, ntrcr, nt_qsno
       use ice_timers, only: timer_dynamics, timer_bound, ice_timer_start, ice_timer_stop
       use ice_dyn_shared, only: ndte, revised_evp, revp, ecci, denom1, arlx1i, brlx, cosw, sinw, fcor_blk, &
           uvel_init, vvel_init, evp_prep1, kdyn
@@ -77,6 +79,7 @@
       call i4_0 (kstrength);  call i4_0 (krdg_partic);  call i4_0 (krdg_redist);  call r8_0 (mu_rdg);  call r8_0 (Cf)
       call r8_3 (aice);  call r8_3 (vice);  call r8_3 (vsno);  call r8_3 (uvel);  call r8_3 (vvel);  call r8_3 (divu);  call r8_3 (shear)
       call r8_3 (aice_init);  call r8_3 (aice0);  call r8_4 (aicen);  call r8_4 (vicen);  call r8_3 (strength)
+      call r8_4 (vsnon);  call r8_5 (trcrn);  call i4_0 (ntrcr);  call i4_0 (nt_qsno);  call i4_0 (nslyr);  call i4_0 (max_ntrcr);  call r8_0 (Lfresh)
       call i4_0 (timer_dynamics);  call i4_0 (timer_bound)
       call i4_0 (ndte);  call i4_0 (kdyn);  call l_0 (revised_evp)
       call r8_0 (revp);  call r8_0 (ecci);  call r8_0 (denom1);  call r8_0 (arlx1i);  call r8_0 (brlx);  call r8_0 (cosw);  call r8_0 (sinw)

@@ -157,6 +157,27 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
                 bad.append(("transport_remap", int((ml != m1[loc]).sum() + (tl != t1[loc]).sum())))
             if not np.abs(m1 - m0).max() > 1e-4:
                 bad.append(("transport_remap did nothing", 0))
+        if env.get("TEST_REMAP_STATE"):
+            # transport_remap with the state transforms: bound_state's ghost cells come through the exchange machinery too
+            from tests.test_parity_gpu import _ice_state
+            synth.add_remap_grid(case, d1, f1)
+            synth.add_remap_grid(case, d, f)
+            ntrcr, ntrcr_dim, nt_qsno, nslyr = 4, 5, 3, 1
+            tables = orc.remap_tables([0, 1, 2, 0])
+            st1 = _ice_state(d1, f1, ntrcr, ntrcr_dim, nt_qsno, nslyr)
+            loc = [next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id) for b in d.local_blocks]
+            stl = [np.ascontiguousarray(a[loc]) for a in st1]
+            dtr = 0.4 * xmin / max(np.abs(f1["uvel"]).max(), np.abs(f1["vvel"]).max())
+            s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+            rc1 = orc.transport_remap_state(d1, dtr, f1, *st1, ntrcr, nt_qsno, nslyr, 1.1e8, *tables)
+            rc = s.ctx.transport_remap_state(dtr, *stl, ntrcr, nt_qsno, nslyr, 1.1e8, *tables)
+            if rc1 or rc:
+                bad.append(("transport_remap_state rc", rc1 * 100 + rc))
+            every = util.cell_mask(d, "all")
+            for name, a, r in zip(("aice0", "aicen", "vicen", "vsnon", "trcrn"), stl, st1):
+                m = np.broadcast_to(every if a.ndim == 3 else (every[:, None] if a.ndim == 4 else every[:, None, None]), a.shape)
+                if not np.array_equal(a[m], r[loc][m]):
+                    bad.append(("transport_remap_state " + name, int((a[m] != r[loc][m]).sum())))
         st = s.ctx.stats()
         s.close()
         if int(st.transport) != {"shm": 2, "ipc": 3}[xp]:
@@ -267,6 +288,11 @@ def test_transport_upwind_across_slabs(ns, world):
 @pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 2, "ipc"), ("tripole", 4, "shm"), ("tripole", 3, "ipc")])
 def test_transport_remap_across_slabs(ns, world, xp):
     _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_REMAP": "1"}, xp=xp)
+
+
+@pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 4, "ipc"), ("tripole", 2, "shm")])
+def test_transport_remap_state_across_slabs(ns, world, xp):
+    _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_REMAP_STATE": "1"}, xp=xp)
 
 
 @pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 2, "ipc"), ("tripole", 4, "shm")])

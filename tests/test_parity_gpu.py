@@ -1036,6 +1036,69 @@ def test_caller_arrays_in_device_memory():
     s.close()
 
 
+def _ice_state(d, f, ntrcr, ntrcr_dim, nt_qsno, nslyr):
+    """aice0, aicen, vicen, vsnon, trcrn of a synthetic thickness distribution, ghost cells current"""
+    synth.add_thickness_distribution(f)
+    aicen = np.ascontiguousarray(f["aicen"]); vicen = np.ascontiguousarray(f["vicen"])
+    ncat = aicen.shape[1]
+    # holes: a category without ice here and there, and cells whose ice is below puny
+    I, J = blocks.block_index_windows(d)
+    for b in range(d.nblocks):
+        x = (I[b] % d.nx_global)[None, :] * 0.37; y = J[b][:, None] * 0.23
+        for n in range(ncat):
+            hole = np.sin(x * (n + 1) + y) > 0.6
+            aicen[b, n][hole] = 0.0; vicen[b, n][hole] = 0.0
+            tiny = np.cos(x - y * (n + 2)) > 0.93
+            aicen[b, n][tiny] *= 1e-12; vicen[b, n][tiny] *= 1e-12
+    vsnon = 0.2 * vicen
+    aice0 = np.where(f["tmask"] > 0, 1.0 - aicen.sum(axis=1), 0.0)
+    trcrn = np.zeros((d.nblocks, ncat, ntrcr_dim) + aicen.shape[2:])
+    for n in range(ncat):
+        for it in range(ntrcr):
+            base = -5.0 - n - 0.3 * it if not (nt_qsno <= it + 1 < nt_qsno + nslyr) else -1.2e8 * (1 + 0.1 * n)
+            trcrn[:, n, it] = np.where(aicen[:, n] > 0, base * (1.0 + 0.05 * np.sin(aicen[:, n] * 40.0)), 0.0)
+        trcrn[:, n, ntrcr:] = 777.0                                     # tracers not in use are not touched
+    for arr in (aicen, vicen, vsnon, trcrn.reshape(d.nblocks, -1, *aicen.shape[2:])):
+        for k in range(arr.shape[1]):
+            w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
+    orc.halo_r8(d, aice0, C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+    return aice0, aicen, vicen, vsnon, trcrn
+
+
+@pytest.mark.parametrize("ns,bs", [("open", (100, 116)), ("open", (25, 29)), ("tripole", (50, 58)), ("tripole", (20, 29))])
+def test_transport_remap_with_the_state_transforms(ns, bs):
+    """transport_remap as a whole (ice_transport_driver.F90:198-627, its optional checks off): state_to_tracers, horizontal_remap,
+    tracers_to_state, bound_state -- the caller's aice0, aicen, vicen, vsnon, trcrn in, the same arrays out, every cell of every
+    block (ghost cells included) against the oracle, after a real evp; snow enthalpy shift, unused tracer slots, categories
+    without ice, cells whose new area is zero keep their values"""
+    nx, ny = (100, 116)
+    case, d, f = util.make_case(nx, ny, *bs, ns=ns, land="continents")
+    synth.add_remap_grid(case, d, f)
+    xmin = synth.global_min_dx(case)
+    ntrcr, ntrcr_dim, nt_qsno, nslyr = 6, 8, 4, 2                      # Tsfc, 2 x qice, 2 x qsno, one on the area; two unused slots
+    tables = orc.remap_tables([0, 1, 1, 2, 2, 0])
+    state = _ice_state(d, f, ntrcr, ntrcr_dim, nt_qsno, nslyr)
+    fo, fg = util.clone(f), util.clone(f)
+    orc.evp(d, orc.make_params(3600.0, 30, xmin), fo)
+    s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    so = [a.copy() for a in state]; sg = [a.copy() for a in state]
+    dt = 0.4 * xmin / max(np.abs(fo["uvel"]).max(), np.abs(fo["vvel"]).max())
+    shift = 330.0 * 3.34e5
+    assert orc.transport_remap_state(d, dt, fo, *so, ntrcr, nt_qsno, nslyr, shift, *tables) == 0
+    s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
+    assert s.ctx.transport_remap_state(dt, *sg, ntrcr, nt_qsno, nslyr, shift, *tables) == 0
+    s.close()
+    every = util.cell_mask(d, "all")
+    for name, a, b_, a0 in zip(("aice0", "aicen", "vicen", "vsnon", "trcrn"), sg, so, state):
+        m = every if a.ndim == 3 else (every[:, None] if a.ndim == 4 else every[:, None, None])
+        m = np.broadcast_to(m, a.shape)
+        assert np.array_equal(a[m], b_[m]), (name, int((a[m] != b_[m]).sum()))
+        assert np.abs(b_ - a0).max() > 0
+    assert np.array_equal(sg[4][:, :, ntrcr:], state[4][:, :, ntrcr:]) and (state[4][:, :, ntrcr:] == 777.0).any()
+
+
 def test_full_size_3600x2700_tripole_rows_f3_f4():
     """BASELINE config 5's grid and boundary for the rows that follow the EVP path, whole grid against the oracle:
     (a) eap(dt), ndte = 12 (stepa after subcycles 1 and 11, the LAST launch): velocities, stresses, structure tensor, history;
