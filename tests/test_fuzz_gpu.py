@@ -139,6 +139,22 @@ def test_random_remap_configuration(seed, monkeypatch):
     s.ctx.upload(f)
     s.ctx.remap_init(f["dxu"], f["dyu"], f["hm"])
     rcg = s.ctx.transport_remap(dt, mg, tg if tg.shape[2] else None, *tables, integral_order=order, l_dp_midpt=midpt)
+    if rng.random() < 0.5 and rco == 0:
+        # ... and transport_remap whole (state_to_tracers / tracers_to_state / bound_state on the device too), same context
+        from tests.test_parity_gpu import _ice_state
+        ntrcr = int(rng.integers(0, 5)); ntrcr_dim = ntrcr + int(rng.integers(0, 3))
+        nt_qsno, nslyr = (int(rng.integers(1, ntrcr + 1)), 1) if ntrcr else (1, 0)
+        tb2 = orc.remap_tables([int(rng.choice([0, 1, 2])) for _ in range(ntrcr)])
+        st = _ice_state(d, f, ntrcr, max(ntrcr_dim, 1), nt_qsno, nslyr)
+        so, sg = [a.copy() for a in st], [a.copy() for a in st]
+        r1 = orc.transport_remap_state(d, dt, f, *so, ntrcr, nt_qsno, nslyr, 1.1e8, *tb2, integral_order=order, l_dp_midpt=midpt)
+        r2 = s.ctx.transport_remap_state(dt, *sg, ntrcr, nt_qsno, nslyr, 1.1e8, *tb2, integral_order=order, l_dp_midpt=midpt)
+        assert {0: 0, 1: evpk.REMAP_BAD_DEPARTURE, 2: evpk.REMAP_NEGATIVE_MASS}[r1] == r2
+        if r1 == 0:
+            every = util.cell_mask(d, "all")
+            for name, a, b_ in zip(("aice0", "aicen", "vicen", "vsnon", "trcrn"), sg, so):
+                m = np.broadcast_to(every if a.ndim == 3 else (every[:, None] if a.ndim == 4 else every[:, None, None]), a.shape)
+                assert np.array_equal(a[m], b_[m]), (name, {n: v for n, v in k.items() if n != "rng"})
     s.close()
     assert {0: 0, 1: evpk.REMAP_BAD_DEPARTURE, 2: evpk.REMAP_NEGATIVE_MASS}[rco] == rcg, (rco, rcg, k)
     if rco == 0:

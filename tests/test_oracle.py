@@ -433,6 +433,63 @@ def test_eap_tables_and_one_step():
         assert np.array_equal(a, out[(12, 10)][n]), n
 
 
+def test_transport_remap_state_transforms():
+    """transport_remap whole (state_to_tracers, horizontal_remap, tracers_to_state, bound_state): without velocity the state
+    comes back to rounding (vicen = aicen * (vicen / aicen)), untouched where aicen <= puny; with it ice and snow volume and
+    the snow enthalpy (advected as trcrn + rhos Lfresh) are conserved, ghost cells equal their neighbours, unused tracer slots
+    are left alone"""
+    case, d, f = util.make_case(48, 40, 24, 20, ns="tripole", land="continents")
+    synth.add_remap_grid(case, d, f)
+    synth.add_thickness_distribution(f)
+    I, J = blocks.block_index_windows(d)
+    for b in range(d.nblocks):
+        x, y = 2 * np.pi * ((I[b] - 1) % 48 + 1)[None, :] / 48, np.pi * J[b][:, None] / 40
+        f["uvel"][b] = 0.3 * np.sin(2 * x) * np.cos(y) * f["umask"][b]
+        f["vvel"][b] = 0.2 * np.cos(3 * x + 1.0) * np.sin(2 * y) * f["umask"][b]
+    for n in ("uvel", "vvel"):
+        orc.halo_r8(d, f[n], C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+    aicen = np.ascontiguousarray(f["aicen"]); vicen = np.ascontiguousarray(f["vicen"])
+    ncat = aicen.shape[1]
+    aicen[:, 1][aicen[:, 1] > 0.05] *= 1e-13                       # a category mostly below puny
+    vicen[:, 1] = np.where(aicen[:, 1] < 1e-11, vicen[:, 1] * 1e-13, vicen[:, 1])
+    vsnon = 0.25 * vicen
+    aice0 = np.where(f["tmask"] > 0, 1.0 - aicen.sum(axis=1), 0.0)
+    ntrcr, ntrcr_dim, nt_qsno, nslyr, shift = 2, 3, 2, 1, 330.0 * 3.34e5
+    trcrn = np.zeros((d.nblocks, ncat, ntrcr_dim) + aicen.shape[2:])
+    trcrn[:, :, 0] = np.where(aicen > 0, -4.0, 0.0)
+    trcrn[:, :, 1] = np.where(aicen > 0, -1.2e8, 0.0)               # qsno: on the snow volume
+    trcrn[:, :, 2] = 55.0
+    tables = orc.remap_tables([0, 2])
+    st = [aice0, aicen, vicen, vsnon, trcrn]
+    f0 = dict(f); f0["uvel"] = np.zeros_like(f["uvel"]); f0["vvel"] = np.zeros_like(f["vvel"])
+    s0 = [a.copy() for a in st]
+    assert orc.transport_remap_state(d, 3600.0, f0, *s0, ntrcr, nt_qsno, nslyr, shift, *tables) == 0
+    phys = util.cell_mask(d, "phys")
+    tiny = phys[:, None] & (aicen <= 1e-11) & (aicen > 0)
+    ok = phys[:, None] & ~tiny
+    assert np.array_equal(s0[0][phys], aice0[phys]) and np.array_equal(s0[1][ok], aicen[ok])
+    assert np.allclose(s0[2][ok], vicen[ok], rtol=4e-16, atol=0.0) and np.allclose(s0[3][ok], vsnon[ok], rtol=4e-16, atol=0.0)
+    assert np.array_equal(s0[4][:, :, 0][ok], trcrn[:, :, 0][ok]) and np.allclose(s0[4][:, :, 1][ok], trcrn[:, :, 1][ok], rtol=1e-15, atol=0.0)
+    # 0 < aim <= puny: the tracers of such a cell are zero in trm, so its volumes come back as aim * 0 and qsno as 0 - rhos Lfresh
+    assert tiny.any() and not s0[2][tiny].any() and not s0[3][tiny].any() and (s0[4][:, :, 1][tiny] == -shift).all()
+    s1 = [a.copy() for a in st]
+    assert orc.transport_remap_state(d, 3600.0, f, *s1, ntrcr, nt_qsno, nslyr, shift, *tables) == 0
+    ta = f["tarea"]
+    for q in (2, 3):                                               # ice and snow volume
+        v0, v1 = (st[q] * ta[:, None])[:, :, phys[0]].sum() if d.nblocks == 1 else sum((st[q][b] * ta[b])[:, phys[b]].sum() for b in range(d.nblocks)), \
+                 sum((s1[q][b] * ta[b])[:, phys[b]].sum() for b in range(d.nblocks))
+        assert abs(v1 - v0) <= 1e-11 * abs(v0)
+    e0 = sum((st[3][b] * (st[4][b][:, 1] + shift) * ta[b])[:, phys[b]].sum() for b in range(d.nblocks))
+    e1 = sum((s1[3][b] * (s1[4][b][:, 1] + shift) * ta[b])[:, phys[b]].sum() for b in range(d.nblocks))
+    assert abs(e1 - e0) <= 1e-10 * abs(e0)
+    assert np.array_equal(s1[4][:, :, 2], trcrn[:, :, 2])           # the unused slot
+    for arr in (s1[1], s1[2], s1[3], s1[4][:, :, 0]):               # bound_state: ghost cells are their neighbours' values
+        for n in range(ncat):
+            w = np.ascontiguousarray(arr[:, n]); w2 = w.copy()
+            orc.halo_r8(d, w2, C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+            assert np.array_equal(w, w2)
+
+
 def test_principal_stress():
     import ctypes as ct
     nx = ny = 4
