@@ -1587,8 +1587,10 @@ extern "C" int evpk_eap_init(evpk_ctx *c, int32_t nx_yield, int32_t ny_yield, in
         for (int k = 0; k < 4; k++) { c->E.a12[k] = q; q += np; }
         for (int k = 0; k < 11; k++) { c->E.hist[k] = q; q += np; }
         for (int k = 0; k < 8; k++) { c->E.str[k] = q; q += np; }
+        for (int k = 0; k < 4; k++) { c->E.ang[k] = (double4 *)q; q += 4 * np; }
         for (int k = 0; k < 4; k++)      // init_eap (:529-551): isotropic structure tensor
             hipLaunchKernelGGL(k_fill_mplane, grid2d(s, B2D), B2D, 0, c->stream, s, c->E.a11[k], 0.5);
+        hipLaunchKernelGGL(k_eap_angles, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -1618,6 +1620,7 @@ extern "C" int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st) {
         hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, dev, nblk, eap_member(c, q));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // (the staging buffer is reused by the next array)
     }
+    hipLaunchKernelGGL(k_eap_angles, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

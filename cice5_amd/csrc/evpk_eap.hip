@@ -16,12 +16,14 @@
 
 namespace evpk {
 
-constexpr int EAP_NPLANES = 8 + 11 + 8;
+constexpr int EAP_NPLANES = 8 + 11 + 8 + 16;      // a11_c, a12_c; history; str; the angles (4 double4 planes)
 struct EapDev {
     const double *tab[6];                 // s11r, s12r, s22r, s11s, s12s, s22s: [na][ny][nx]
     int nxy, nyy, nay, pad_;
     double invsin;                        // c1/sin(pi2/c12) * invstressconviso (:1524-1526), evaluated once on the host with the same evpk_sincos
     double *a11[4], *a12[4];
+    double4 *ang[4];                      // per corner {gamma, cos gamma, sin gamma, a'}: functions of (a11, a12) only, which change
+                                          // every tenth subcycle (stepa) -- kept instead of recomputed in every stress_eap (eap_tensor_angles)
     double *hist[11];                     // a11, a12, e11, e12, e22, yieldstress11, yieldstress12, yieldstress22, s11, s12, s22
     double *str[8];
 };
@@ -41,12 +43,8 @@ static inline double eap_invsin() {
     return 1.0 / sn * invstressconviso;
 }
 
-// ---- update_stress_rdg (:1474-1658) ----
-template <bool LAST>
-__device__ __forceinline__ void eap_update_stress_rdg(const EapDev &E, double divu, double tension, double shear, double a11, double a12, double strength,
-                                                      double &stressp, double &stressm, double &stress12, double &alphar) {
-    const double kfriction = 0.45;
-    const double invsin = E.invsin;
+// ---- update_stress_rdg (:1474-1658), first part (:1528-1545): the principal axis of the structure tensor ----
+__device__ __forceinline__ double4 eap_tensor_angles(double a11, double a12) {
     const double a22 = 1.0 - a11;
     const double gamma = 0.5 * evpk_atan2((2.0 * a12), (a11 - a22));
     double Q11, Q12;
@@ -54,6 +52,17 @@ __device__ __forceinline__ void eap_update_stress_rdg(const EapDev &E, double di
     const double Q11Q11 = Q11 * Q11, Q11Q12 = Q11 * Q12, Q12Q12 = Q12 * Q12;
     double atempprime = Q11Q11 * a11 + 2.0 * Q11Q12 * a12 + Q12Q12 * a22;
     atempprime = fmax(atempprime, 1.0 - atempprime);
+    return make_double4(gamma, Q11, Q12, atempprime);
+}
+
+// ---- update_stress_rdg (:1474-1658), the rest ----
+template <bool LAST>
+__device__ __forceinline__ void eap_update_stress_rdg(const EapDev &E, double divu, double tension, double shear, double4 ang, double strength,
+                                                      double &stressp, double &stressm, double &stress12, double &alphar) {
+    const double kfriction = 0.45;
+    const double invsin = E.invsin;
+    const double gamma = ang.x, Q11 = ang.y, Q12 = ang.z, atempprime = ang.w;
+    const double Q11Q11 = Q11 * Q11, Q11Q12 = Q11 * Q12, Q12Q12 = Q12 * Q12;
     const double dtemp11 = 0.5 * (divu + tension), dtemp12 = shear * 0.5, dtemp22 = 0.5 * (divu - tension);
     double alpha = 0.5 * evpk_atan2((2.0 * dtemp12), (dtemp11 - dtemp22));
     if (alpha > gamma) alpha = alpha - EAP_PI;
@@ -106,8 +115,9 @@ __global__ void k_eap_reset(Slab s, EapDev E) {
     (void)k;
     const bool tact = (s.cmask[km] & CM_T) != 0;
     if (!tact) {
+        const double4 iso = eap_tensor_angles(0.5, 0.0);
 #pragma unroll
-        for (int c = 0; c < 4; c++) { E.a11[c][km] = 0.5; E.a12[c][km] = 0.0; }
+        for (int c = 0; c < 4; c++) { E.a11[c][km] = 0.5; E.a12[c][km] = 0.0; E.ang[c][km] = iso; }
 #pragma unroll
         for (int h = EH_E11; h <= EH_S22; h++) E.hist[h][km] = 0.0;      // (active cells are rewritten by every k_eap_stress)
     }
@@ -141,10 +151,10 @@ __global__ void __launch_bounds__(256) k_eap_stress(Slab s, EapDev E, int SB, do
     const double shearsw = -cyp * v_mm + dyt * v_im - cxp * u_mm + dxt * u_mj;
     const double shearse = -cym * v_im - dyt * v_mm - cxp * u_im + dxt * u_ij;
     double spt1, spt2, spt3, spt4, smt1, smt2, smt3, smt4, s12t1, s12t2, s12t3, s12t4, ar1 = 0.0, ar2 = 0.0, ar3 = 0.0, ar4 = 0.0;
-    eap_update_stress_rdg<LAST>(E, divune, tensionne, shearne, E.a11[0][km], E.a12[0][km], strength, spt1, smt1, s12t1, ar1);
-    eap_update_stress_rdg<LAST>(E, divunw, tensionnw, shearnw, E.a11[1][km], E.a12[1][km], strength, spt2, smt2, s12t2, ar2);
-    eap_update_stress_rdg<LAST>(E, divusw, tensionsw, shearsw, E.a11[2][km], E.a12[2][km], strength, spt3, smt3, s12t3, ar3);
-    eap_update_stress_rdg<LAST>(E, divuse, tensionse, shearse, E.a11[3][km], E.a12[3][km], strength, spt4, smt4, s12t4, ar4);
+    eap_update_stress_rdg<LAST>(E, divune, tensionne, shearne, E.ang[0][km], strength, spt1, smt1, s12t1, ar1);
+    eap_update_stress_rdg<LAST>(E, divunw, tensionnw, shearnw, E.ang[1][km], strength, spt2, smt2, s12t2, ar2);
+    eap_update_stress_rdg<LAST>(E, divusw, tensionsw, shearsw, E.ang[2][km], strength, spt3, smt3, s12t3, ar3);
+    eap_update_stress_rdg<LAST>(E, divuse, tensionse, shearse, E.ang[3][km], strength, spt4, smt4, s12t4, ar4);
     if (LAST) {                                                                       // :1219-1234
         const double tt = tensionne + tensionnw + tensionse + tensionsw, ss = shearne + shearnw + shearse + shearsw;
         FD(s, F_SHEAR, k) = 0.25 * tarear * sqrt(tt * tt + ss * ss);
@@ -261,6 +271,7 @@ __global__ void __launch_bounds__(256) k_eap_stepa(Slab s, EapDev E, int SB, dou
         a12n[c] = (a12 * dtei - m12) * dteikth;
         E.a11[c][km] = a11n[c];
         E.a12[c][km] = a12n[c];
+        E.ang[c][km] = eap_tensor_angles(a11n[c], a12n[c]);
     }
     E.hist[EH_A11][km] = 0.25 * (a11n[0] + a11n[1] + a11n[2] + a11n[3]);
     E.hist[EH_A12][km] = 0.25 * (a12n[0] + a12n[1] + a12n[2] + a12n[3]);
@@ -275,6 +286,14 @@ __global__ void k_scatter_mplane(Slab s, const BlockDesc *bd, int nxb, int nyb, 
     int si, sj;
     if (!scatter_take(s, bd[b], i, j, mode, si, sj)) return;
     dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = src[mcell(s, si, sj)];
+}
+
+// the angles of every cell from its (a11, a12): after init_eap's fill and after an upload of the structure tensor
+__global__ void k_eap_angles(Slab s, EapDev E) {
+    SLAB_IJ_ALL
+    (void)k;
+#pragma unroll
+    for (int c = 0; c < 4; c++) E.ang[c][km] = eap_tensor_angles(E.a11[c][km], E.a12[c][km]);
 }
 
 __global__ void k_fill_mplane(Slab s, double *P, double v) {
