@@ -441,16 +441,22 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, Remap
     double p1s[RM_GROUPS], p1x[RM_GROUPS], p1y[RM_GROUPS], p2s[RM_GROUPS];        // mtsum, mtxsum, mtysum of the last type-1 tracer; mtsum of the last type-2
 #pragma unroll
     for (int g = 0; g < RM_GROUPS; g++) { p1s[g] = 0.0; p1x[g] = 0.0; p1y[g] = 0.0; p2s[g] = 0.0; }
+    // the three central triangles (groups 4, 5, 6) usually draw on ONE cell (TC or BC): its tc, tx, ty are then loaded once per tracer
+    const bool cen5 = area[3] != 0.0 && area[4] != 0.0 && k2[4] == k2[3], cen6 = area[3] != 0.0 && area[5] != 0.0 && k2[5] == k2[3];
     for (int q0 = 0; q0 < tb.ntrace; q0++) {
         const int nt = tb.ord[q0], p = (n - 1) * tb.ntrace + nt, ty_ = tb.type[nt];
         const double *tcp = P.tc(p), *txp = P.tx(p), *typ = P.ty(p);
         double flx = 0.0;
+        double ctc = 0.0, ctx = 0.0, cty = 0.0;                   // of group 4's cell
         if (ty_ == 1) {                                                               // :3449-3468
             const bool keep = tb.has[nt] != 0;
 #pragma unroll
             for (int g = 0; g < RM_GROUPS; g++) {
                 if (area[g] == 0.0) continue;
-                const double tc = icg[g] ? tcp[k2[g]] : 0.0, tx = icg[g] ? txp[k2[g]] : 0.0, ty = icg[g] ? typ[k2[g]] : 0.0;
+                double tc, tx, ty;
+                if ((g == 4 && cen5) || (g == 5 && cen6)) { tc = ctc; tx = ctx; ty = cty; }
+                else { tc = icg[g] ? tcp[k2[g]] : 0.0; tx = icg[g] ? txp[k2[g]] : 0.0; ty = icg[g] ? typ[k2[g]] : 0.0; }
+                if (g == 3) { ctc = tc; ctx = tx; cty = ty; }
                 const double mts = ms[g][0] * tc + ms[g][1] * tx + ms[g][4] * ty;
                 flx = flx + area[g] * mts;
                 if (keep) {
@@ -463,7 +469,10 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, Remap
 #pragma unroll
             for (int g = 0; g < RM_GROUPS; g++) {
                 if (area[g] == 0.0) continue;
-                const double tc = icg[g] ? tcp[k2[g]] : 0.0, tx = icg[g] ? txp[k2[g]] : 0.0, ty = icg[g] ? typ[k2[g]] : 0.0;
+                double tc, tx, ty;
+                if ((g == 4 && cen5) || (g == 5 && cen6)) { tc = ctc; tx = ctx; ty = cty; }
+                else { tc = icg[g] ? tcp[k2[g]] : 0.0; tx = icg[g] ? txp[k2[g]] : 0.0; ty = icg[g] ? typ[k2[g]] : 0.0; }
+                if (g == 3) { ctc = tc; ctx = tx; cty = ty; }
                 const double mts = p1s[g] * tc + p1x[g] * tx + p1y[g] * ty;
                 flx = flx + area[g] * mts;
                 p2s[g] = mts;
@@ -472,7 +481,11 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, Remap
 #pragma unroll
             for (int g = 0; g < RM_GROUPS; g++) {
                 if (area[g] == 0.0) continue;
-                const double mts = p2s[g] * (icg[g] ? tcp[k2[g]] : 0.0);
+                double tc;
+                if ((g == 4 && cen5) || (g == 5 && cen6)) tc = ctc;
+                else tc = icg[g] ? tcp[k2[g]] : 0.0;
+                if (g == 3) ctc = tc;
+                const double mts = p2s[g] * tc;
                 flx = flx + area[g] * mts;
             }
         }
