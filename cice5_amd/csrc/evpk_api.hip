@@ -2253,6 +2253,7 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     if (!c->rm_grid) FAIL(c, "evpk_transport_remap: evpk_remap_init has not been called");
     if (l_fixed_area) FAIL(c, "evpk_transport_remap: l_fixed_area = .true. is not supported");
     if (ntrace > RM_MAXT) FAIL(c, "evpk_transport_remap: ntrace = %d exceeds %d", ntrace, RM_MAXT);
+    if (mask_elems(c->s) > 0xFFFFFFFFull) FAIL(c, "evpk_transport_remap: a plane of this slab has more than 2^32 cells");   // (k_remap_flux keeps 32-bit cell offsets)
     if (integral_order < 1 || integral_order > 3) FAIL(c, "evpk_transport_remap: integral_order = %d", integral_order);
     RemapTab tb{};
     tb.ncat = ncat; tb.ntrace = ntrace; tb.order = integral_order; tb.midpt = l_dp_midpt ? 1 : 0;

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EVPK_VERSION 2
+#define EVPK_VERSION 3
 
 /* boundary types: ice_domain.F90 domain_nml ew_boundary_type / ns_boundary_type */
 enum { EVPK_BND_CYCLIC = 0, EVPK_BND_OPEN = 1, EVPK_BND_CLOSED = 2, EVPK_BND_TRIPOLE = 3 };
