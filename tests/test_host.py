@@ -157,3 +157,20 @@ def test_restart_records_of_the_dynamics(tmp_path, ew):
     assert not f2["uvel"][0, 0, :].any()             # south ghost row (open)
     with pytest.raises(ValueError):
         restart.read_dynamics_records(io.BytesIO(raw), blocks.create_distrb_cart(nx + 2, ny, 26, 20), f2)
+
+
+def test_traffic_json_was_measured_on_the_committed_kernel_sources():
+    """profiles/traffic.json (HBM bytes per launch of the dominant kernel from rocprofv3 --pmc passes, read by bench.py) must
+    hold an entry of the headline workload under the hash of the csrc/ files as they are in the tree: a library change
+    without a new counter pass would otherwise leave `roofline.traffic` null in the bench line"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    sha = bench.source_sha()
+    ent = [e for e in json.load(open(os.path.join(root, "profiles", "traffic.json")))["entries"] if e.get("source_sha") == sha]
+    assert any("3600x2700 ndte=120" in e["workload"] and "ns=tripole" in e["workload"] for e in ent), sha
+    for e in ent:
+        assert 0.5e9 < e["hbm_bytes_per_launch"] < 2.0e9 or "3600x2700" not in e["workload"]
+
