@@ -428,10 +428,23 @@ def next_rows(a, case, d, f, xmin, device, ncat=5, trcr_depend=(0, 1, 1, 1, 1, 2
             raise RuntimeError(f"evpk_transport_remap rc={rc}: " + ctx._L.evpk_last_error(ctx._ctx).decode())
     cells = d.nx_global * d.ny_global
     nfield = ncat + 1 + ncat * ntrace
+    # planes a call moves through HBM, each counted once per kernel that reads or writes it: gather + scatter,
+    # construct (its three outputs per tracer only where the category has ice), two flux kernels, update
+    ncp, ntp = ncat + 1, ncat * ntrace
+    icefrac = float((m0[:, 1:] > 1.0e-11).double().mean())
+    # (what is only touched where a category has ice -- tc, tx, ty, the tracer reads of the update -- counted with the ice fraction)
+    planes = (4 * nfield                                             # gather + scatter: block arrays <-> planes
+              + (nfield + 1 + 2 * ncp + 3 * ntp * icefrac)           # construct: mm, tm, hm in; mx, my out; tc, tx, ty out where ice
+              + 2 * (3 * ncp + 3 * ntp * icefrac + nfield + 2)       # flux E, N: mm, mx, my, (tc, tx, ty), dp in; fluxes out
+              + (4 * ncp + ntp + 3 * ntp * icefrac))                 # update: mm in / out, mass fluxes; tm out, tm + tracer fluxes in where ice
+    moved = planes * cells * 8.0
     res["transport_remap"] = {"what": "horizontal_remap (ice_transport_remap.F90:309), ncat = %d, ntrace = %d, ice state resident in HBM (device arrays), "
                                       "velocities as eap left them" % (ncat, ntrace), "ms_per_call": 1e3 * min(t[1:]),
                               "value": cells * nfield / min(t[1:]), "unit": "field-cell-updates/s", "fields": nfield,
                               "compulsory_GBps": 2 * 8 * cells * nfield / min(t[1:]) / 1e9,
+                              "roofline": {"bound": "hbm", "achieved": moved / min(t[1:]) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": moved / min(t[1:]) / 1e9 / HBM_PEAK_GBS, "bytes_per_call": moved,
+                                           "note": "whole call (six kernels); every plane a kernel reads or writes counted once per kernel"},
                               "max_area_change": float((mm - m0).abs().max())}
     s.close()
     return res
