@@ -490,6 +490,33 @@ def test_transport_remap_state_transforms():
             assert np.array_equal(w, w2)
 
 
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_transport_remap_state_decomposition_invariance(ns):
+    """transport_remap whole: 1 block == N blocks on every physical cell (state_to_tracers and tracers_to_state are cell-local,
+    bound_state is what keeps the next step's ghost cells current)"""
+    ref = None
+    for bs in [(48, 40), (12, 10), (16, 20)]:
+        case, d, f = util.make_case(48, 40, *bs, ns=ns, land="continents")
+        synth.add_remap_grid(case, d, f)
+        I, J = blocks.block_index_windows(d)
+        for b in range(d.nblocks):
+            x, y = 2 * np.pi * ((I[b] - 1) % 48 + 1)[None, :] / 48, np.pi * J[b][:, None] / 40
+            f["uvel"][b] = 0.3 * np.sin(2 * x) * np.cos(y) * f["umask"][b]
+            f["vvel"][b] = 0.2 * np.cos(3 * x + 1.0) * np.sin(2 * y) * f["umask"][b]
+        for n in ("uvel", "vvel"):
+            orc.halo_r8(d, f[n], C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+        from tests.test_parity_gpu import _ice_state
+        st = _ice_state(d, f, 3, 4, 2, 1)
+        assert orc.transport_remap_state(d, 3600.0, f, *st, 3, 2, 1, 1.1e8, *orc.remap_tables([0, 2, 1])) == 0
+        out = [blocks.gather_global(d, st[0])] + [blocks.gather_global(d, np.ascontiguousarray(a[:, n])) for a in st[1:4] for n in range(a.shape[1])] + \
+              [blocks.gather_global(d, np.ascontiguousarray(st[4][:, n, k])) for n in range(st[4].shape[1]) for k in range(3)]
+        if ref is None:
+            ref = out
+        else:
+            for a, b_ in zip(ref, out):
+                assert np.array_equal(a, b_), bs
+
+
 def test_principal_stress():
     import ctypes as ct
     nx = ny = 4
