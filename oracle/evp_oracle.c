@@ -590,6 +590,7 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
     const int nxg = g->nx_global, nyg = g->ny_global;
     const size_t nn = (size_t)nx * ny;
     double *G = (double *)malloc(sizeof(double) * (size_t)nxg * nyg);
+    unsigned char *have = (unsigned char *)calloc((size_t)nxg * nyg, 1);      /* cells some local block owns */
 #pragma omp parallel for schedule(static)
     for (long long k = 0; k < (long long)nxg * nyg; k++) G[k] = fill;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -599,6 +600,7 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
             for (int i = g->ilo[b]; i <= g->ihi[b]; i++) {
                 int gi = g->iglob_lo[b] + (i - g->ilo[b]), gj = g->jglob_lo[b] + (j - g->jlo[b]);
                 G[GIX(gi, gj)] = ab[IX(i, j)];
+                have[GIX(gi, gj)] = 1;
             }
     }
     const int tripole = (g->ns_boundary == ORC_BND_TRIPOLE);
@@ -653,31 +655,43 @@ static void halo_generic(const orc_geom *g, double *a, const double *asrc, int l
                 int gi = wrap_i(g, g->iglob_lo[b] + (i - ilo));
                 int gj = g->jglob_lo[b] + (j - jlo);
                 if (stress_mode) {
-                    /* ice_HaloUpdate_stress: only the tripole north ghost row of array1 is written
-                       (serial/ice_boundary.F90:3330-3443); ghosts are NOT pre-filled. */
-                    if (top_block && j == jhi + 1 && i <= ihi + 1 && gi > 0) ab[IX(i, j)] = north[gi];
+                    /* ice_HaloUpdate_stress (serial/ice_boundary.F90:3269-3443): the tripole north ghost row of array1 is
+                       written from array2's top row, a ghost cell whose neighbour block is an eliminated land block gets
+                       `fill` (:3349-3350), nothing else is touched and nothing is pre-filled.  (Tripole grids are cyclic
+                       E-W: with 'open' / 'closed' the reference's copy out of the tripole buffer reads mirrored or
+                       out-of-range columns, :3752-3776 with :3420-3424 -- not supported here.) */
+                    if (phys || i > ihi + 1 || j > jhi + 1) continue;
+                    if (top_block && j == jhi + 1) { if (gi > 0) ab[IX(i, j)] = north[gi]; }
+                    else if (gi > 0 && gj >= 1 && gj <= nyg && !have[GIX(gi, gj)]) ab[IX(i, j)] = fill;
                     continue;
                 }
                 if (phys) {
                     if (top_block && j == jhi && (loc == ORC_LOC_NECORNER || loc == ORC_LOC_NFACE)) ab[IX(i, j)] = top[gi];
                     continue;
                 }
+                /* a ghost cell takes its neighbour's value (a message of the halo schedule; `fill` if that neighbour is an
+                   eliminated land block, serial/ice_boundary.F90:722-723).  A cell no message writes -- beyond an open /
+                   closed boundary, or padding of a short block -- keeps its value, except on the outermost nghost rows /
+                   columns of the block ARRAY, which the production backend fills first (mpi/ice_boundary.F90:1409-1416).
+                   Pinned by tests/golden/ref_*.npz (the reference's serial backend + that one rule). */
                 double v = fill;
-                if (i > ihi + 1 || j > jhi + 1) { ab[IX(i, j)] = v; continue; }   /* padding */
-                if (gi > 0) {
-                    if (gj < 1) { if (g->ns_boundary == ORC_BND_CYCLIC) v = G[GIX(gi, gj + nyg)]; }
-                    else if (gj > nyg) {
-                        if (g->ns_boundary == ORC_BND_CYCLIC) v = G[GIX(gi, gj - nyg)];
-                        else if (tripole && gj == nyg + 1) v = north[gi];
-                    } else {
-                        v = G[GIX(gi, gj)];
-                        if (top_block && j == jhi && (loc == ORC_LOC_NECORNER || loc == ORC_LOC_NFACE)) v = top[gi];
+                int has_src = 0;
+                if (!(i > ihi + 1 || j > jhi + 1)) {
+                    if (gi > 0) {
+                        if (gj < 1) { if (g->ns_boundary == ORC_BND_CYCLIC) { v = G[GIX(gi, gj + nyg)]; has_src = 1; } }
+                        else if (gj > nyg) {
+                            if (g->ns_boundary == ORC_BND_CYCLIC) { v = G[GIX(gi, gj - nyg)]; has_src = 1; }
+                            else if (tripole && gj == nyg + 1) { v = north[gi]; has_src = 1; }
+                        } else {
+                            v = G[GIX(gi, gj)]; has_src = 1;
+                            if (top_block && j == jhi && (loc == ORC_LOC_NECORNER || loc == ORC_LOC_NFACE)) v = top[gi];
+                        }
                     }
                 }
-                ab[IX(i, j)] = v;
+                if (has_src || i == 1 || i == nx || j == 1 || j == ny) ab[IX(i, j)] = v;
             }
     }
-    free(G); free(top); free(north);
+    free(G); free(have); free(top); free(north);
 }
 
 /* ---------------------------------------------------------------------------
@@ -741,14 +755,15 @@ static void sched_build_ne(const orc_geom *g, halo_sched *h) {
                     if (top_block && j == jhi) { h->tdst[h->ntop] = d; h->tgi[h->ntop++] = gi; }
                     continue;
                 }
-                if (i > ihi + 1 || j > jhi + 1 || gi <= 0) { h->fdst[h->nfill++] = d; continue; }
+                const int edge = (i == 1 || i == nx || j == 1 || j == ny);     /* cells without a source: see halo_generic */
+                if (i > ihi + 1 || j > jhi + 1 || gi <= 0) { if (edge) h->fdst[h->nfill++] = d; continue; }
                 if (gj < 1) {
                     if (g->ns_boundary == ORC_BND_CYCLIC && own[GIX(gi, gj + nyg)] >= 0) { h->cdst[h->ncopy] = d; h->csrc[h->ncopy++] = (size_t)own[GIX(gi, gj + nyg)]; }
-                    else h->fdst[h->nfill++] = d;
+                    else if (edge) h->fdst[h->nfill++] = d;
                 } else if (gj > nyg) {
                     if (g->ns_boundary == ORC_BND_CYCLIC && own[GIX(gi, gj - nyg)] >= 0) { h->cdst[h->ncopy] = d; h->csrc[h->ncopy++] = (size_t)own[GIX(gi, gj - nyg)]; }
                     else if (tripole && gj == nyg + 1) { h->ndst[h->nnorth] = d; h->ngi[h->nnorth++] = gi; }
-                    else h->fdst[h->nfill++] = d;
+                    else if (edge) h->fdst[h->nfill++] = d;
                 } else if (top_block && j == jhi) { h->tdst[h->ntop] = d; h->tgi[h->ntop++] = gi; }
                 else if (own[GIX(gi, gj)] >= 0) { h->cdst[h->ncopy] = d; h->csrc[h->ncopy++] = (size_t)own[GIX(gi, gj)]; }
                 else h->fdst[h->nfill++] = d;

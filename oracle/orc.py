@@ -286,6 +286,20 @@ def halo_r8(d, a: np.ndarray, loc: int, kind: int, fill: float = 0.0):
     del keep
 
 
+def halo_i4(d, a: np.ndarray, fill: int = 0):
+    """orc_halo_i4: centre / scalar update of an int32 block array (ice_HaloUpdate2DI4)"""
+    g, keep = make_geom(d)
+    lib().orc_halo_i4(ct.byref(g), _p32(a), int(fill))
+    del keep
+
+
+def halo_stress(d, a1: np.ndarray, a2: np.ndarray):
+    """orc_halo_stress: ice_HaloUpdate_stress(array1 = a1, array2 = a2, field_loc_center, field_type_scalar)"""
+    g, keep = make_geom(d)
+    lib().orc_halo_stress(ct.byref(g), _p64(a1), _p64(a2))
+    del keep
+
+
 def set_halo_callback(fn):
     """fn(array_ptr, loc, kind, fill, phase) -- phase 0 before, 1 after the local update; None clears.
     Returns the ctypes callback object, which the caller must keep alive."""
