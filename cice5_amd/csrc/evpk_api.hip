@@ -1042,15 +1042,25 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         covered += (long long)(d.ihi - d.ilo + 1) * (d.jhi - d.jlo + 1);
     }
     if (i1 > g->nx_global || j1 > g->ny_global) FAIL(c, "blocks exceed the global grid");
-    if (g->nranks > 1 && (j0 != 1 || j1 != g->ny_global))
-        FAIL(c, "multi-rank runs need x-slabs of whole columns (processor_shape slenderX1)");
-    if (g->nranks == 1 && (i0 != 1 || i1 != g->nx_global || j0 != 1 || j1 != g->ny_global)) {
-        // a single rank must see the whole domain, else its ghost ring has no source
-        FAIL(c, "single-rank context must cover the whole global grid (got i %d..%d, j %d..%d)", i0, i1, j0, j1);
+    // The slab is the rank's share of the DOMAIN, not the bounding box of the blocks that survived land-block elimination
+    // (ice_domain.F90:387-441: blocks without ocean are dropped, e.g. the all-land southern rows of a global grid): the
+    // x range follows create_distrb_cart's arithmetic for slenderX1 (ice_distribution.F90:603-640: contiguous ranges of
+    // ceil(nblocks_x / nprocs) block columns), the y range is the whole grid.  Cells no block covers read as land.
+    {
+        const int bsx = g->nx_block - 2, nbx = (g->nx_global - 1) / bsx + 1, nbx_pp = (nbx - 1) / g->nranks + 1;
+        const int r0 = g->rank * nbx_pp * bsx + 1, r1 = std::min((g->rank + 1) * nbx_pp * bsx, (int)g->nx_global);
+        if (r0 > r1) FAIL(c, "rank %d owns no block column (%d block columns on %d ranks)", g->rank, nbx, g->nranks);
+        if (i0 < r0 || i1 > r1)
+            FAIL(c, "%s (blocks span i %d..%d, the rank's share is %d..%d)", g->nranks > 1 ? "multi-rank runs need x-slabs of whole columns (processor_shape slenderX1)"
+                                                                                        : "single-rank context: blocks outside the grid", i0, i1, r0, r1);
+        i0 = r0; i1 = r1; j0 = 1; j1 = g->ny_global;
     }
     Slab &s = c->s;
     s.nxl = i1 - i0 + 1; s.nyl = j1 - j0 + 1; s.i0 = i0; s.j0 = j0; s.nxg = g->nx_global; s.nyg = g->ny_global;
     if (g->ns_boundary == EVPK_BND_TRIPOLE && (s.nyl < 2 || (g->nx_global & 1))) FAIL(c, "tripole needs ny >= 2 and even nx_global");
+    // (with 'open' / 'closed' E-W the reference's copy out of the tripole buffer follows mirrored ghost indices resp. reads
+    //  column nx_global + 1 of the buffer in ice_HaloUpdate_stress: serial/ice_boundary.F90:3752-3776, :3420-3424)
+    if (g->ns_boundary == EVPK_BND_TRIPOLE && g->ew_boundary != EVPK_BND_CYCLIC) FAIL(c, "a tripole grid must be cyclic in the E-W direction");
     c->full_cover = (covered == (long long)s.nxl * s.nyl);
     s.pitch = ((C0 + s.nxl + ZW_MAX + 1 + 7) / 8) * 8;     // columns 1-ZW_MAX .. nxl+ZW_MAX (ghost zones of up to ZW_MAX columns per side)
     s.rstride = NP * s.pitch;
@@ -2048,6 +2058,99 @@ extern "C" int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2) {
     if (download_f(c, sig1, F_SIG1, MODE_PHYS) || download_f(c, sig2, F_SIG2, MODE_PHYS)) return 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// ---- ice_HaloUpdate / ice_HaloUpdate_stress of a caller's block array on the device (SURVEY S8 row a3 as an entry point) ----
+static int halo_io_ptr(evpk_ctx *c, const double *host, size_t n, double **dev, bool *staged, double **pool, size_t *pool_n, bool upload) {
+    *dev = (double *)mapped_alias(host);
+    *staged = (*dev == nullptr);
+    if (*staged) {
+        if (*pool_n < n) {
+            if (*pool) (void)hipFree(*pool);
+            *pool = nullptr; *pool_n = 0;
+            HIPCHK(c, hipMalloc(pool, sizeof(double) * n));
+            *pool_n = n;
+        }
+        if (upload) HIPCHK(c, hipMemcpyAsync(*pool, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        *dev = *pool;
+    }
+    return 0;
+}
+
+extern "C" int evpk_halo_update(evpk_ctx *c, double *a, int32_t nz, int32_t field_loc, int32_t field_type, double fill) {
+    if (!c || !a) return 1;
+    if (!c->connected) FAIL(c, "evpk_halo_update: the context is not connected yet (evpk_connect)");
+    if (nz < 0 || field_loc < 1 || field_loc > 4 || field_type < 1 || field_type > 3) FAIL(c, "evpk_halo_update: bad nz / field_loc / field_type");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int np = nz > 0 ? nz : 1;
+    const size_t nblk = (size_t)c->nyb * c->nxb, n = (size_t)c->nblocks * np * nblk;
+    double *dev = nullptr; bool staged = false;
+    if (halo_io_ptr(c, a, n, &dev, &staged, &c->tp_stage, &c->tp_stage_n, true)) return 1;
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    const bool necorner = (field_loc == 2), vector = (field_type != 1);
+    const int loc_x = field_loc == 4 ? 2 : field_loc == 3 ? 3 : -1;            // k_fold_apply's codes for E face / N face
+    const int chunk = std::min(c->max_nf, (int)NSTATE);
+    for (int k0 = 0; k0 < np; k0 += chunk) {
+        const int nf = std::min(chunk, np - k0);
+        for (int q = 0; q < nf; q++) {
+            if (!c->full_cover) hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, (int)F_STATE2 + q, fill);
+            hipLaunchKernelGGL(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dev + (size_t)(k0 + q) * nblk),
+                               (size_t)np * nblk, (int)F_STATE2 + q);
+        }
+        if (halo(c, F_STATE2, nf, necorner, vector, fill, -1, nullptr, false, -1, 0, loc_x)) return 1;
+        for (int q = 0; q < nf; q++)
+            hipLaunchKernelGGL(k_scatter_halo, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (int)F_STATE2 + q, dev + (size_t)(k0 + q) * nblk,
+                               (size_t)np * nblk, fill, c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0,
+                               (field_loc == 2 || field_loc == 3) ? 1 : 0, 0, -1);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (staged) HIPCHK(c, hipMemcpyAsync(a, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return xp_check(c);
+}
+
+extern "C" int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2) {
+    if (!c || !a1 || !a2) return 1;
+    if (!c->connected) FAIL(c, "evpk_halo_update_stress: the context is not connected yet (evpk_connect)");
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nblk = (size_t)c->nyb * c->nxb, n = (size_t)c->nblocks * nblk;
+    // both arrays through one staging pool when they are plain host memory: [a1 | a2]
+    double *d1 = (double *)mapped_alias(a1), *d2 = (double *)mapped_alias(a2);
+    const bool staged1 = (d1 == nullptr), staged2 = (d2 == nullptr);
+    if (staged1 || staged2) {
+        if (c->tp_stage_n < 2 * n) {
+            if (c->tp_stage) (void)hipFree(c->tp_stage);
+            c->tp_stage = nullptr; c->tp_stage_n = 0;
+            HIPCHK(c, hipMalloc(&c->tp_stage, sizeof(double) * 2 * n));
+            c->tp_stage_n = 2 * n;
+        }
+        if (staged1) { HIPCHK(c, hipMemcpyAsync(c->tp_stage, a1, sizeof(double) * n, hipMemcpyHostToDevice, c->stream)); d1 = c->tp_stage; }
+        if (staged2) { HIPCHK(c, hipMemcpyAsync(c->tp_stage + n, a2, sizeof(double) * n, hipMemcpyHostToDevice, c->stream)); d2 = c->tp_stage + n; }
+    }
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+    const int fA = F_STATE2, fB = F_STATE2 + 1, fC = F_STATE2 + 2;
+    int fcov = -1;
+    if (!c->full_cover) {
+        // which ghost cells border an eliminated land block: the coverage of the slab, halo-updated like any centre scalar
+        // (beyond an open / closed boundary there is no neighbour at all: 1 = leave alone)
+        hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, fC, 0.0);
+        hipLaunchKernelGGL(k_cover_f, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, fC);
+        if (halo(c, fC, 1, false, false, 1.0)) return 1;
+        hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, fA, 0.0);
+        hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, fB, 0.0);
+        fcov = fC;
+    }
+    hipLaunchKernelGGL(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)d1, nblk, fA);
+    hipLaunchKernelGGL(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)d2, nblk, fB);
+    if (c->ns == EVPK_BND_TRIPOLE && halo(c, fA, 1, false, false, 0.0, fB)) return 1;
+    hipLaunchKernelGGL(k_scatter_halo, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, fA, d1, nblk, 0.0, c->ew == EVPK_BND_CYCLIC ? 1 : 0,
+                       c->ns == EVPK_BND_TRIPOLE ? 1 : 0, 0, 1, fcov);
+    HIPCHK(c, hipGetLastError());
+    if (staged1) HIPCHK(c, hipMemcpyAsync(a1, d1, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return xp_check(c);
 }
 
 // ---- the dynamics records of the binary restart (source/ice_restart_driver.F90:122-176 dumpfile, :295-412 restartfile) ---------

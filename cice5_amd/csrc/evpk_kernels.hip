@@ -123,6 +123,65 @@ __global__ void k_scatter_m(Slab s, const BlockDesc *bd, int nxb, int nyb, const
     dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = src[mcell(s, si, sj)];
 }
 
+// ---- evpk_halo_update: one (nx_block, ny_block) slice per block, blocks `bstride` doubles apart, <-> field f of the slab ----
+__global__ void k_gather_fs(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, size_t bstride, int f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    if (i < d.ilo || i > d.ihi || j < d.jlo || j > d.jhi) return;           // physical cells only: the update rewrites the ring
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
+    const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    FD(s, f, cell(s, si, sj)) = src[(size_t)b * bstride + (size_t)(j - 1) * nxb + (i - 1)];
+}
+
+// 1.0 on the physical cells of the blocks (cells of eliminated land blocks keep the plane's 0)
+__global__ void k_cover_f(Slab s, const BlockDesc *bd, int nxb, int nyb, int f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    if (i < d.ilo || i > d.ihi || j < d.jlo || j > d.jhi) return;
+    FD(s, f, cell(s, d.iglob_lo + (i - d.ilo) - s.i0 + 1, d.jglob_lo + (j - d.jlo) - s.j0 + 1)) = 1.0;
+}
+
+// What ice_HaloUpdate leaves in a block array (production backend, mpi/ice_boundary.F90:1331-1700): a ghost cell with a
+// neighbour takes the slab's value (the neighbour's, `fill` where that is an eliminated land block, the fold on the tripole
+// row; for NE-corner / N-face fields the fold also rewrites the top physical row); a cell nothing writes -- beyond an open /
+// closed boundary, padding of a short block -- keeps the caller's value unless it lies on the outermost row / column of the
+// ARRAY, which the reference fills first (:1409-1416).
+// stress != 0: ice_HaloUpdate_stress -- only the tripole north ghost row, and 0 next to an eliminated land block (fcov: the
+// halo-updated coverage plane, < 0 if every cell is covered)
+__global__ void k_scatter_halo(Slab s, const BlockDesc *bd, int nxb, int nyb, int f, double *dst, size_t bstride, double fill,
+                               int cyclic, int tripole, int top_row_too, int stress, int fcov) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    double *o = dst + (size_t)b * bstride + (size_t)(j - 1) * nxb + (i - 1);
+    const bool edge = (i == 1 || i == nxb || j == 1 || j == nyb);
+    const bool phys = (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1, sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    const int gi = s.i0 + si - 1, gj = s.j0 + sj - 1;
+    if (phys) {
+        if (top_row_too && !stress && tripole && gj == s.nyg) *o = FD(s, f, cell(s, si, sj));
+        return;
+    }
+    const bool padding = (i > d.ihi + 1 || j > d.jhi + 1);
+    const bool has_src = !padding && ((gi >= 1 && gi <= s.nxg) || cyclic) && ((gj >= 1 && gj <= s.nyg) || (tripole && gj == s.nyg + 1));
+    if (stress) {
+        if (!has_src) return;
+        if (tripole && gj == s.nyg + 1) *o = FD(s, f, cell(s, si, sj));
+        else if (fcov >= 0 && FD(s, fcov, cell(s, si, sj)) == 0.0) *o = 0.0;
+        return;
+    }
+    if (has_src) *o = FD(s, f, cell(s, si, sj));
+    else if (edge) *o = fill;
+}
+
 // restart records: physical cells of one field <-> a (ny_global, nx_global) array in global order (the layout
 // gather_global / scatter_global give the master task, ice_gather_scatter.F90); f < 0: the iceumask plane as 0 / 1
 __global__ void k_slab_to_global(Slab s, int f, double *G) {

@@ -132,6 +132,8 @@ def lib():
         L.evpk_connect.argtypes = [ctxp, ct.c_void_p]
         L.evpk_device_check.argtypes = [ct.c_int32]
         L.evpk_transport_upwind.argtypes = [ctxp, ct.c_double, ct.c_int32, c_f64p]
+        L.evpk_halo_update.argtypes = [ctxp, c_f64p, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double]
+        L.evpk_halo_update_stress.argtypes = [ctxp, c_f64p, c_f64p]
         L.evpk_remap_init.argtypes = [ctxp, c_f64p, c_f64p, c_f64p]
         L.evpk_transport_remap.argtypes = [ctxp, ct.c_double, ct.c_int32, ct.c_int32, c_f64p, c_f64p, c_i32p, c_i32p, c_i32p,
                                            ct.c_int32, ct.c_int32, ct.c_int32]
@@ -297,6 +299,16 @@ class Context:
 
     def principal_stress(self, sig1: np.ndarray, sig2: np.ndarray):
         self._chk(self._L.evpk_principal_stress(self._ctx, _p64(sig1), _p64(sig2)), "evpk_principal_stress")
+
+    def halo_update(self, a: np.ndarray, field_loc: int, field_type: int, fill: float = 0.0):
+        """evpk_halo_update (ice_HaloUpdate): a is (nblocks, ny_block, nx_block) or (nblocks, nz, ny_block, nx_block), in place"""
+        assert a.ndim in (3, 4)
+        self._chk(self._L.evpk_halo_update(self._ctx, _p64(a), 0 if a.ndim == 3 else int(a.shape[1]), int(field_loc), int(field_type),
+                                           float(fill)), "evpk_halo_update")
+
+    def halo_update_stress(self, a1: np.ndarray, a2: np.ndarray):
+        """evpk_halo_update_stress (ice_HaloUpdate_stress(array1 = a1, array2 = a2, centre, scalar)): a1 in place"""
+        self._chk(self._L.evpk_halo_update_stress(self._ctx, _p64(a1), _p64(a2)), "evpk_halo_update_stress")
 
     def transport_upwind(self, dt: float, works: np.ndarray):
         """evpk_transport_upwind: works is (nblocks, narr, ny_block, nx_block), advected in place"""

@@ -99,6 +99,7 @@
                 evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
                 evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
                 evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read, &
+                evpk_halo_update, evpk_halo_update_stress, &
                 evpk_transport_upwind, evpk_remap_init, evpk_transport_remap, evpk_transport_remap_state, &
                 EVPK_REMAP_BAD_DEPARTURE, EVPK_REMAP_NEGATIVE_MASS, &
                 evpk_eap_state, evpk_eap_init, evpk_eap_upload, evpk_eap_download
@@ -194,6 +195,17 @@
             character (kind=c_char), dimension(*), intent(in) :: path
             integer (c_int64_t), value :: byte_offset
             integer (c_int32_t), value :: big_endian
+         end function
+         ! ice_HaloUpdate / ice_HaloUpdate_stress of a block array on the device (include/evpk.h): a(nx_block,ny_block[,nz],nblocks)
+         integer (c_int) function evpk_halo_update (ctx, a, nz, field_loc, field_type, fill) bind(C, name='evpk_halo_update')
+            import :: c_int, c_ptr, c_double, c_int32_t
+            type (c_ptr), value :: ctx, a
+            integer (c_int32_t), value :: nz, field_loc, field_type
+            real (c_double), value :: fill
+         end function
+         integer (c_int) function evpk_halo_update_stress (ctx, a1, a2) bind(C, name='evpk_halo_update_stress')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ctx, a1, a2
          end function
          ! transport_upwind (ice_transport_driver.F90:634-772) on the resident velocities: works(nx_block,ny_block,narr,nblocks)
          ! as state_to_work fills it, advected in place

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EVPK_VERSION 3
+#define EVPK_VERSION 4
 
 /* boundary types: ice_domain.F90 domain_nml ew_boundary_type / ns_boundary_type */
 enum { EVPK_BND_CYCLIC = 0, EVPK_BND_OPEN = 1, EVPK_BND_CLOSED = 2, EVPK_BND_TRIPOLE = 3 };
@@ -198,6 +198,23 @@ int evpk_get_stats(evpk_ctx *c, evpk_stats *s);
  * stresses from the sigma_1 planes and prs_sig resident on the device after evpk_finish / evpk_run.
  * Physical cells of sig1, sig2 (block arrays) are written. */
 int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
+
+/* Row a3 as an entry point of its own: ice_HaloUpdate (mpi/ice_boundary.F90:1331 2DR8, :2451 3DR8) of a block array on the
+ * device -- upload, the halo / fold kernels and transports the evp path uses (N-S fill or tripole u-fold, E-W ring between the
+ * slab ranks), download.  Collective over the ranks of the context.
+ *   a          real(8) (nx_block, ny_block, nblocks) for nz == 0, (nx_block, ny_block, nz, nblocks) for nz >= 1    in / out
+ *   field_loc  1 centre, 2 NE corner, 3 N face, 4 E face; field_type 1 scalar, 2 vector, 3 angle (ice_constants.F90:198-220)
+ *   fill       the reference's optional fillValue (0 when absent)
+ * Written, as by the reference's production (MPI) backend: every ghost cell with a neighbour (its value; `fill` if the
+ * neighbour is an eliminated land block), the tripole top row for NE-corner / N-face fields, and the outermost row / column
+ * of the block array where nothing else writes (mpi/ice_boundary.F90:1409-1416).  Ghost cells beyond an open / closed
+ * boundary that are not on the array's edge (short blocks) and padding cells keep the caller's values.
+ * evpk_halo_update_stress: ice_HaloUpdate_stress(array1, array2, halo, field_loc_center, field_type_scalar)
+ * (mpi/ice_boundary.F90; ice_dyn_evp.F90:416-481): the tripole north ghost row of a1 from the top row of a2; a ghost cell
+ * next to an eliminated land block gets 0; nothing else is touched.
+ * Pinned by tests/golden/ref_*.npz (outputs of the reference's own routines). */
+int evpk_halo_update(evpk_ctx *c, double *a, int32_t nz, int32_t field_loc, int32_t field_type, double fill);
+int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2);
 
 /* SURVEY S8 row f-3, first step: transport_upwind (source/ice_transport_driver.F90:634-772) on the velocities the last evp
  * left on the device.  The cell-edge velocities uee, vnn (:688-701) and their halo updates (E face / N face vectors,

@@ -534,11 +534,12 @@ def test_errors_are_reported_not_fatal():
     with pytest.raises(evpk.EvpkError, match="NULL"):
         ctx.upload(g)
     ctx.close()
-    # a context that does not cover the whole grid on one rank is refused
-    d2 = blocks.create_distrb_cart(100, 116, 50, 116, nprocs=2, rank=0)
-    d2.nprocs = 1
+    # blocks outside the rank's share of the domain (create_distrb_cart's x ranges) are refused; missing blocks are not:
+    # they are eliminated land blocks (ice_domain.F90:387-441)
+    d2 = blocks.create_distrb_cart(100, 116, 50, 116, nprocs=2, rank=1)
+    d2.rank = 0
     f2 = synth.make_block_fields(case, d2)
-    with pytest.raises(evpk.EvpkError, match="whole global grid"):
+    with pytest.raises(evpk.EvpkError, match="slenderX1"):
         evpk.Context(d2, f2)
 
 
