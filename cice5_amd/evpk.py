@@ -90,7 +90,7 @@ EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "
            "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
            "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
            "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap", "evpk_transport_remap_state",
-           "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download"]
+           "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download", "evpk_halo_update", "evpk_halo_update_stress"]
 
 REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS = 11, 12        # include/evpk.h
 
