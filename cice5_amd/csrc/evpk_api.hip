@@ -36,6 +36,71 @@ using namespace evpk;
 static thread_local std::string g_create_err;
 
 // ------------------------------------------------------------------------------------------------------
+// Rendezvous of the rank processes on a POSIX shared-memory segment.  Rank 0 replaces whatever carries the name (a crashed
+// run may have left a segment behind; a previous context of this run may not have unlinked its own yet) and the other
+// ranks must not trust a segment until rank 0 OF THIS RUN has answered in it: every rank > 0 writes a fresh random word
+// into hello[r] of the segment it has mapped and waits for rank 0 to copy it into ack[r]; while it waits it re-opens the
+// name now and then, and starts over if the name has moved on to another inode.  A stale segment is never acknowledged
+// (its rank 0 is gone), so magic numbers, stages or IPC handles found in one are never read.  The last 4096 bytes of the
+// segment hold the two tables.
+// ------------------------------------------------------------------------------------------------------
+static constexpr size_t SHM_RDV_BYTES = 4096;
+static double shm_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static char *shm_rendezvous(const std::string &name, size_t total, int r, int n, const char *what, std::string &err) {
+    const double t0 = shm_now(), limit = 120.0;
+    auto hello = [&](char *b, int q) { return reinterpret_cast<uint64_t *>(b + total - SHM_RDV_BYTES) + q; };
+    auto ack = [&](char *b, int q) { return reinterpret_cast<uint64_t *>(b + total - SHM_RDV_BYTES / 2) + q; };
+    if ((size_t)n * 8 > SHM_RDV_BYTES / 2) { err = std::string(what) + ": too many ranks"; return nullptr; }
+    if (r == 0) {
+        shm_unlink(name.c_str());
+        int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)total) != 0) { if (fd >= 0) ::close(fd); err = std::string(what) + ": cannot create " + name; return nullptr; }
+        char *b = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (b == MAP_FAILED) { err = std::string(what) + ": mmap failed"; return nullptr; }
+        memset(b, 0, total);
+        for (int left = n - 1; left > 0;) {
+            left = 0;
+            for (int q = 1; q < n; q++) {
+                const uint64_t h = __atomic_load_n(hello(b, q), __ATOMIC_ACQUIRE);
+                if (h) __atomic_store_n(ack(b, q), h, __ATOMIC_RELEASE); else left++;
+            }
+            if (left) { usleep(200); if (shm_now() - t0 > limit) { munmap(b, total); shm_unlink(name.c_str()); err = std::string(what) + ": not every rank arrived at " + name; return nullptr; } }
+        }
+        return b;
+    }
+    uint64_t nonce = ((uint64_t)getpid() << 32) ^ (uint64_t)(shm_now() * 1e9) ^ ((uint64_t)r << 56);
+    for (;;) {
+        if (shm_now() - t0 > limit) { err = std::string(what) + ": timeout waiting for rank 0 at " + name; return nullptr; }
+        int fd = shm_open(name.c_str(), O_RDWR, 0600);
+        if (fd < 0) { usleep(1000); continue; }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || (size_t)st.st_size < total) { ::close(fd); usleep(1000); continue; }     // not sized yet (or a smaller stale one)
+        const ino_t ino = st.st_ino;
+        char *b = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (b == MAP_FAILED) { err = std::string(what) + ": mmap failed"; return nullptr; }
+        nonce = nonce * 6364136223846793005ULL + 1442695040888963407ULL;
+        if (!nonce) nonce = 1;
+        __atomic_store_n(hello(b, r), nonce, __ATOMIC_RELEASE);
+        bool stale = false;
+        for (long k = 0; __atomic_load_n(ack(b, r), __ATOMIC_ACQUIRE) != nonce; k++) {
+            usleep(200);
+            if (shm_now() - t0 > limit) break;
+            if ((k & 15) == 15) {          // does the name still lead to the segment I mapped?
+                int fd2 = shm_open(name.c_str(), O_RDWR, 0600);
+                struct stat s2;
+                if (fd2 < 0 || fstat(fd2, &s2) != 0 || s2.st_ino != ino) stale = true;
+                if (fd2 >= 0) ::close(fd2);
+                if (stale) break;
+            }
+        }
+        if (!stale && __atomic_load_n(ack(b, r), __ATOMIC_ACQUIRE) == nonce) return b;
+        munmap(b, total);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Host-staged shared-memory relay: a second transport with the semantics of the RCCL point-to-point calls
 // (ordered messages per (src, dst) pair), so that several ranks can run the real multi-rank code path on
 // ONE GPU in tests (RCCL refuses two ranks on one device).  Selected by a unique id that starts with
@@ -62,29 +127,9 @@ struct ShmRelay {
     int open(const std::string &nm, int r, int n, size_t slot_bytes, std::string &err) {
         rank = r; nranks = n; slot = (slot_bytes + 63) & ~size_t(63); name = "/" + nm;
         total = HDR + (size_t)n * n * (sizeof(Box) + slot);
-        int fd = -1;
-        if (r == 0) {
-            shm_unlink(name.c_str());
-            fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-            if (fd < 0 || ftruncate(fd, (off_t)total) != 0) { err = "shm relay: cannot create " + name; return 1; }
-        } else {
-            const double t0 = now();
-            while ((fd = shm_open(name.c_str(), O_RDWR, 0600)) < 0) {
-                usleep(1000);
-                if (now() - t0 > 120.0) { err = "shm relay: timeout opening " + name; return 1; }
-            }
-            struct stat st;
-            while (fstat(fd, &st) == 0 && (size_t)st.st_size < total) {
-                usleep(1000);
-                if (now() - t0 > 120.0) { err = "shm relay: segment never sized"; return 1; }
-            }
-        }
-        base = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        ::close(fd);
-        if (base == MAP_FAILED) { base = nullptr; err = "shm relay: mmap failed"; return 1; }
-        uint64_t *magic = reinterpret_cast<uint64_t *>(base);
-        if (r == 0) { memset(base, 0, HDR + (size_t)n * n * sizeof(Box)); for (int a = 0; a < n * n; a++) { Box *b = box(a / n, a % n); b->wr = b->rd = 0; } __atomic_store_n(magic, 0x4556504bULL, __ATOMIC_RELEASE); }
-        else if (!wait([&] { return __atomic_load_n(magic, __ATOMIC_ACQUIRE) == 0x4556504bULL; })) { err = "shm relay: rank 0 never initialised the segment"; return 1; }
+        total = ((total + 4095) / 4096) * 4096 + SHM_RDV_BYTES;
+        base = shm_rendezvous(name, total, r, n, "shm relay", err);       // (a fresh segment: every mailbox counter is 0)
+        if (!base) return 1;
         host.resize(slot);
         return 0;
     }
@@ -159,35 +204,9 @@ struct IpcXp {
         rank = r; nranks = n; name = "/" + nm;
         flags_off = ((64 + (size_t)n * 128 + 4095) / 4096) * 4096;
         flags_bytes = (((size_t)2 * n * n * 64 + 4095) / 4096) * 4096;
-        total = flags_off + flags_bytes;
-        int fd = -1;
-        if (r == 0) {
-            shm_unlink(name.c_str());
-            fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-            if (fd < 0 || ftruncate(fd, (off_t)total) != 0) { err = "ipc transport: cannot create " + name; return 1; }
-        } else {
-            const double t0 = now();
-            while ((fd = shm_open(name.c_str(), O_RDWR, 0600)) < 0) {
-                usleep(1000);
-                if (now() - t0 > 120.0) { err = "ipc transport: timeout opening " + name; return 1; }
-            }
-            struct stat st;
-            while (fstat(fd, &st) == 0 && (size_t)st.st_size < total) {
-                usleep(1000);
-                if (now() - t0 > 120.0) { err = "ipc transport: segment never sized"; return 1; }
-            }
-        }
-        base = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        ::close(fd);
-        if (base == MAP_FAILED) { base = nullptr; err = "ipc transport: mmap failed"; return 1; }
-        if (r == 0) { memset(base, 0, total); __atomic_store_n(magic(), 0x4950434bULL, __ATOMIC_RELEASE); }
-        else {
-            const double t0 = now();
-            while (__atomic_load_n(magic(), __ATOMIC_ACQUIRE) != 0x4950434bULL) {
-                usleep(200);
-                if (now() - t0 > 120.0) { err = "ipc transport: rank 0 never initialised the segment"; return 1; }
-            }
-        }
+        total = flags_off + flags_bytes + SHM_RDV_BYTES;
+        base = shm_rendezvous(name, total, r, n, "ipc transport", err);   // zero-filled by rank 0 of THIS run, see above
+        if (!base) return 1;
         return 0;
     }
     void close_() {
@@ -2507,9 +2526,13 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     HIPCHK(c, hipMemcpyAsync(&bad, c->rm_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (xp_check(c)) return 1;
-    // (ranks decide alone, as the reference's l_stop is per task: the caller aborts the run, abort_ice)
-    if (bad & 1u) { c->err = "evpk_transport_remap: departure points out of bounds (ice_transport_remap.F90:1583-1607)"; return EVPK_REMAP_BAD_DEPARTURE; }
-    if (bad & 2u) { c->err = "evpk_transport_remap: negative area / mass after the update (ice_transport_remap.F90:3622-3640)"; return EVPK_REMAP_NEGATIVE_MASS; }
+    // Ranks decide alone, as the reference's l_stop is per task (the caller aborts the run, abort_ice) -- but a rank that
+    // found a bad cell still takes part in the one exchange left on the state path (bound_state's ghost-ring update below),
+    // so that its slab neighbours are not left waiting for a partner: they return normally, it returns the error afterwards.
+    int badrc = 0;
+    if (bad & 1u) { c->err = "evpk_transport_remap: departure points out of bounds (ice_transport_remap.F90:1583-1607)"; badrc = EVPK_REMAP_BAD_DEPARTURE; }
+    else if (bad & 2u) { c->err = "evpk_transport_remap: negative area / mass after the update (ice_transport_remap.F90:3622-3640)"; badrc = EVPK_REMAP_NEGATIVE_MASS; }
+    if (badrc && !(st && c->nranks > 1)) return badrc;
     if (!st) {
         hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
                            (double *const *)c->rm_tab, dmm, nblk, (size_t)ncp * nblk, nrg);
@@ -2522,6 +2545,13 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     } else {
         // bound_state: the ghost ring of the NEW areas and tracers, then tracers_to_state on every cell of every block
         if (planes_halo(c, dl, c->rm_sgn, (int)nA, false)) return 1;
+        if (badrc) {                                  // the caller's arrays stay untouched
+            const std::string keep = c->err;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (xp_check(c)) return 1;
+            c->err = keep;
+            return badrc;
+        }
         hipLaunchKernelGGL(k_state_scatter, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, io, P, nrg);
         HIPCHK(c, hipGetLastError());
         double *dev5[5] = {io.aice0, io.aicen, io.vicen, io.vsnon, io.trcrn};
