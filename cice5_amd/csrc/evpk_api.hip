@@ -58,7 +58,8 @@ static char *shm_rendezvous(const std::string &name, size_t total, int r, int n,
         char *b = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         ::close(fd);
         if (b == MAP_FAILED) { err = std::string(what) + ": mmap failed"; return nullptr; }
-        memset(b, 0, total);
+        // (no memset: a segment created with O_EXCL and sized by ftruncate reads as zeros, and a rank that has already
+        //  mapped it may have written its hello word)
         for (int left = n - 1; left > 0;) {
             left = 0;
             for (int q = 1; q < n; q++) {
@@ -2151,7 +2152,7 @@ extern "C" int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2
     const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
     const int fA = F_STATE2, fB = F_STATE2 + 1, fC = F_STATE2 + 2;
     int fcov = -1;
-    if (!c->full_cover) {
+    if (!c->full_cover || c->nranks > 1) {     // (collective: another rank may have an eliminated block where this one has none)
         // which ghost cells border an eliminated land block: the coverage of the slab, halo-updated like any centre scalar
         // (beyond an open / closed boundary there is no neighbour at all: 1 = leave alone)
         hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, fC, 0.0);
