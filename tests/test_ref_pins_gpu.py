@@ -89,6 +89,8 @@ def _worker(rank, world, tag, xp, cfg, q):
         uid = ({"shm": b"EVPKSHM:", "ipc": b"EVPKIPC:"}[xp] + tag.encode()).ljust(128, b"\0")
         bad = []
         for ew, ns, land, case in P.cases(cfg, z):
+            if any(P.decomp(cfg, z, ew, ns, case, nprocs=world, rank=r).nblocks == 0 for r in range(world)):
+                continue            # a rank whose whole share is eliminated land (closed E-W rim): every rank must own a block
             d, ctx = _ctx(cfg, z, ew, ns, case, nprocs=world, rank=rank, unique_id=uid)
             ice = list(z[f"{case}/blocks/blocks_ice"])
             rows = [ice.index(b.block_id) for b in d.local_blocks]
