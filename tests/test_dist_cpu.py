@@ -1,15 +1,17 @@
-"""world_size-2 CPU test of the sharded path (gloo): x-slab decomposition, ring neighbours from
-evpk_slab_layout, and the halo protocol the multi-GPU library uses --
+"""world_size-2 CPU tests of the sharded path (gloo): x-slab decomposition, ring neighbours from evpk_slab_layout, and the
+exchange protocols the multi-GPU library speaks (cice5_amd/csrc/evpk_api.hip), modelled with the CPU oracle as the
+arithmetic of each rank and torch.distributed point-to-point calls as the transport:
 
-  * E-W: each rank sends its two physical edge columns over ALL rows (ghost rows included, which
-    carries the corners) and receives its two ghost columns; with two ranks on a cyclic ring one
-    message [W edge | E edge] goes each way (cice5_amd/csrc/evpk_api.hip, halo()).
-  * tripole: the two top rows are all-gathered and every rank applies the fold locally
-    (k_fold_pack / k_fold_apply).
+  * `test_two_rank_ghost_zones_gloo` -- the communication-avoiding E-W protocol of the two-subcycle kernel
+    (exchange_cols): every rank carries W = 2 m ghost-zone columns per side, advances them redundantly, loses two valid
+    columns per launch (= two subcycles) and receives the neighbour's W edge columns of the whole prognostic state (u, v,
+    twelve stresses, all rows) once per m launches; m = 1, 2, 4.  No message inside the 2 m subcycles in between.
+  * `test_two_rank_slab_exchange_gloo` -- the one-subcycle protocol (halo()): E-W edge columns over ALL rows (ghost rows
+    included, which carries the corners) after every subcycle; on tripole grids the fold as POINT-TO-POINT messages with
+    the mirror ranks (fold_p2p: each rank sends its two top rows to the ranks that own the mirror images of its columns and
+    folds its own columns only; the ghost columns of the two rows come with the E-W exchange that follows).
 
-The arithmetic on each rank is the CPU oracle with its local halo update patched through a hook;
-the result must equal the single-process oracle bit for bit (as the reference is decomposition
-invariant).
+The result must equal the single-process oracle bit for bit (the reference is decomposition invariant).
 """
 import os
 import socket
@@ -116,18 +118,35 @@ def _worker(rank, world, port, ns, q):
                     saved["rows"] = loc_rows
                 return
             if tripole:
-                # all-gather the two top rows (global rows ny-1, ny) of every rank's columns
-                t = torch.from_numpy(saved.pop("rows"))
-                parts = [torch.zeros_like(t) for _ in range(world)]
-                dist.all_gather(parts, t)
-                allrows = np.concatenate([p.numpy() for p in parts], axis=1)
-                B1 = np.concatenate([[0.0], allrows[0]])
-                B2 = np.concatenate([[0.0], allrows[1]])
+                # point-to-point with the mirror ranks (fold_p2p): my columns g = i0..i1 read the rows at nx - g (NE corner)
+                # and nx - g + 1 (centre); every rank works the partner set out from the slab starts alone
+                w = nx // world
+                owner = lambda g: ((g - 1) % nx) // w
+                need = sorted({owner(nx - g + k) for g in range(i0, i1 + 1) for k in (0, 1)})
+                gives = sorted(r for r in range(world) if any(owner(nx - g + k) == rank for g in range(r * w + 1, (r + 1) * w + 1) for k in (0, 1)))
+                mine = torch.from_numpy(saved.pop("rows"))
+                got = {}
+                reqs = [dist.isend(mine.clone(), r) for r in gives if r != rank]
+                for r in need:
+                    if r == rank:
+                        got[r] = mine.numpy()
+                    else:
+                        t = torch.zeros_like(mine)
+                        dist.recv(t, r)
+                        got[r] = t.numpy()
+                for q in reqs:
+                    q.wait()
+                B1 = np.full(nx + 1, np.nan); B2 = np.full(nx + 1, np.nan)      # only the partners' columns are known
+                for r, rows in got.items():
+                    B1[r * w + 1:(r + 1) * w + 1] = rows[0]
+                    B2[r * w + 1:(r + 1) * w + 1] = rows[1]
                 top, north = _fold_rows(nx, B1, B2, loc == C.LOC_NECORNER, sgn)
                 for n, b in enumerate(d.local_blocks):
                     if b.tripole:
-                        for i in range(1, d.nx_block + 1):
-                            g = (b.iglob_lo + (i - b.ilo) - 1) % nx + 1
+                        for i in range(1, d.nx_block + 1):                      # the slab's own columns only (a block's ghost
+                            g = (b.iglob_lo + (i - b.ilo) - 1) % nx + 1         # column inside the slab is one of them)
+                            if not (i0 <= g <= i1):
+                                continue
                             a[n, b.jhi, i - 1] = north[g - 1]
                             if top is not None:
                                 a[n, b.jhi - 1, i - 1] = top[g - 1]
@@ -183,6 +202,96 @@ def test_two_rank_slab_exchange_gloo(ns):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ns, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in procs:
+        res.append(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()
+    for rank, bad in res:
+        assert not bad, f"rank {rank}: {bad}"
+
+
+def _zone_worker(rank, world, port, m, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          OMP_NUM_THREADS="2")
+        import torch
+        import torch.distributed as dist
+        from cice5_amd import blocks, constants as C, evpk, synth
+        from oracle import orc
+        from tests import util
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        nx, ny, ndte = 48, 40, 24
+        W = 2 * m                                    # ghost-zone columns per side; one exchange per m launches of two subcycles
+        nxl = nx // world
+        i0 = rank * nxl + 1
+        lay = evpk.slab_layout(nx, world, rank, C.BND_CYCLIC, i0, i0 + nxl - 1)
+        west, east = lay["west"], lay["east"]
+        assert nxl >= W and west == east == 1 - rank
+        case = synth.SynthCase(nx=nx, ny=ny, land="continents")
+        # the rank's slab with its zones as ONE block of an open-ended strip: columns i0-W .. i0+nxl-1+W of the global grid
+        # (cyclic), every field a function of the global cell index, so zone columns start out as the neighbour's own
+        next_ = nxl + 2 * W
+        dx = blocks.create_distrb_cart(next_, ny, next_, ny, ew_boundary_type="open")
+        Iw, Jw = blocks.block_index_windows(dx)
+        I, J = np.broadcast_arrays((Iw[0] + i0 - W - 1)[None, :], Jw[0][:, None])
+        f = synth.make_block_fields(synth.SynthCase(nx=next_, ny=ny), dx)
+        cache = {}
+        for name in synth.GRID_FIELDS + synth.INPUT_FIELDS + synth.MASK_FIELDS:
+            f[name][0] = case.field(name, I, J, cache)
+        xmin = synth.global_min_dx(case)
+        p = orc.make_params(3600.0, ndte, xmin)
+        state = ["uvel", "vvel"] + util.SIGMA
+        nex = 0
+        for launch in range(ndte // 2):
+            orc.evp(dx, p, f, nsub=2)                # one launch of the two-subcycle kernel: the zones lose two columns per side
+            if (launch + 1) % m:
+                continue
+            # zones used up: my W edge columns of the state, all rows, to each neighbour; theirs into my zones
+            # (block array column index = strip column, the west ghost column of the block being index 0)
+            sendW = torch.from_numpy(np.stack([f[n][0][:, W + 1:2 * W + 1] for n in state]).copy())
+            sendE = torch.from_numpy(np.stack([f[n][0][:, nxl + 1:nxl + W + 1] for n in state]).copy())
+            recvE, recvW = torch.zeros_like(sendW), torch.zeros_like(sendE)
+            if rank == 0:
+                dist.send(sendW, west); dist.send(sendE, east); dist.recv(recvE, east); dist.recv(recvW, west)
+            else:
+                dist.recv(recvE, east); dist.recv(recvW, west); dist.send(sendW, west); dist.send(sendE, east)
+            for k, n in enumerate(state):
+                f[n][0][:, nxl + W + 1:nxl + 2 * W + 1] = recvE[k].numpy()      # the east neighbour's west edge
+                f[n][0][:, 1:W + 1] = recvW[k].numpy()                          # the west neighbour's east edge
+            nex += 1
+        assert nex == ndte // (2 * m)
+        # reference: the whole domain in this process, one evp of ndte subcycles, another block size
+        d1 = blocks.create_distrb_cart(nx, ny, 12, 10)
+        f1 = synth.make_block_fields(case, d1)
+        orc.evp(d1, p, f1)
+        bad = []
+        for name in state:
+            G = blocks.gather_global(d1, f1[name])[:, i0 - 1:i0 - 1 + nxl]
+            L = f[name][0][1:ny + 1, W + 1:W + nxl + 1]
+            if not np.array_equal(G, L):
+                bad.append((name, int((G != L).sum())))
+        assert np.abs(f["uvel"]).max() > 1e-3
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bad))
+    except Exception:
+        q.put((rank, ["EXC " + traceback.format_exc()]))
+
+
+@pytest.mark.parametrize("m", [1, 2, 4])
+def test_two_rank_ghost_zones_gloo(m):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zone_worker, args=(r, 2, port, m, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = []

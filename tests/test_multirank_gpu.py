@@ -267,6 +267,28 @@ def test_cfg4_1440x1080_tripole_on_four_ranks():
     _run(4, "tripole", 1440, 1080, 30, 27, ndte=10, xp="ipc")
 
 
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_cfg4_1440x1080_ndte120_on_four_ranks(ns):
+    """BASELINE config 4 as BASELINE.json states it -- 1440x1080, ndte = 120, 4 x-slab ranks (here sharing the one GPU): two
+    whole evp calls, every output of every rank against the single-process oracle (full ghost-zone cycles, the LAST2 ending
+    across ranks, finish)"""
+    res = _run(4, ns, 1440, 1080, 30, 27, ndte=120, xp="ipc")
+    assert all(r[3] > 0 for r in res)
+
+
+@pytest.mark.parametrize("what", ["TEST_REMAP_STATE", "TEST_EAP"])
+def test_cfg4_shape_rows_f3_f4_on_four_ranks(what):
+    """transport_remap (with the state transforms) and eap(dt) across four x-slabs at config 4's shape and block size, tripole"""
+    _run(4, "tripole", 1440, 1080, 30, 27, ndte=22 if what == "TEST_EAP" else 12, env={what: "1"}, xp="ipc")
+
+
+def test_cfg5_shape_ndte240_on_four_ranks():
+    """BASELINE config 5's subcycle count (ndte = 240) on a config-5-shaped tripole grid: 3600 columns in four 900-column
+    slabs, the whole evp (120 pairs with their band launches and folds between mirror ranks, the stress folds, finish), twice"""
+    res = _run(4, "tripole", 3600, 96, 450, 48, ndte=240, xp="ipc")
+    assert all(r[3] > 0 for r in res)
+
+
 @pytest.mark.parametrize("xp", XPS)
 def test_cfg5_tripole_slabs_eight_wide_grid(xp):
     """BASELINE config 5 decomposition in miniature: tripole grid, 4 slabs of a 3600-column grid, few rows."""
