@@ -14,6 +14,24 @@
 #include <math.h>
 #include <string.h>
 
+#ifdef ORC_EAP_LIBM
+/* second build of this file (libevp_oracle_libm.so): the host's libm instead of the fixed algorithms -- what another compiler
+ * of the reference would evaluate.  Only tests/test_oracle.py::test_eap_libm_* use it, to STATE the tolerance of kdyn = 2. */
+static inline void orc_libm_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
+#define evpk_sincos orc_libm_sincos
+#define evpk_atan2 atan2
+#endif
+
+/* counting mode (orc_eap_lookup_counts): next to every table lookup of update_stress_rdg and every branch decision of
+ * calc_ffrac the same quantities are evaluated with libm's sin / cos / atan2 on the SAME inputs; counted are the lookups
+ * whose index triple (kx, ky, ka) and the decisions whose outcome differ */
+static int g_eap_count = 0;
+static long long g_eap_n[4] = {0, 0, 0, 0};      /* lookups, lookups that differ, ffrac decisions, decisions that differ */
+void orc_eap_lookup_counts(long long out[4], int enable) {
+    for (int k = 0; k < 4; k++) { out[k] = g_eap_n[k]; g_eap_n[k] = 0; }
+    g_eap_count = enable;
+}
+
 #define IX(i, j) ((size_t)((j)-1) * (size_t)nx + (size_t)((i)-1))
 
 static const double c0 = 0.0, c1 = 1.0, c2 = 2.0, c3 = 3.0, p001 = 0.001, p1 = 0.1, p2 = 0.2, p25 = 0.25, p5 = 0.5;
@@ -73,6 +91,37 @@ static void update_stress_rdg(int last, double divu, double tension, double shea
     kx = kx < 1 ? 1 : (kx > nxy ? nxy : kx);
     ky = ky < 1 ? 1 : (ky > nyy ? nyy : ky);
     ka = ka < 1 ? 1 : (ka > nay ? nay : ka);
+    if (g_eap_count) {
+        /* the same with libm on the same inputs */
+        const double g2 = p5 * atan2((c2 * a12), (a11 - a22));
+        const double q11 = cos(g2), q12 = sin(g2);
+        double ap = q11 * q11 * a11 + c2 * (q11 * q12) * a12 + q12 * q12 * a22;
+        ap = fmax(ap, c1 - ap);
+        double al = p5 * atan2((c2 * (shear * p5)), (p5 * (divu + tension) - p5 * (divu - tension)));
+        if (al > g2) al = al - pi;
+        if (al < g2 - pi) al = al + pi;
+        const double y2 = g2 - al;
+        const double d11 = cos(al), d12 = sin(al);
+        const double e11 = p5 * (divu + tension), e12 = shear * p5, e22 = p5 * (divu - tension);
+        double t1 = d11 * (d11 * e11 + c2 * d12 * e12) + d12 * d12 * e22;
+        double t2 = d12 * (d12 * e11 - c2 * d11 * e12) + d11 * d11 * e22;
+        double x2 = c0;
+        if (fabs(t1) > puny || fabs(t2) > puny) {
+            const double il = c1 / sqrt(t1 * t1 + t2 * t2);
+            x2 = atan2(t2 * il, t1 * il);
+        }
+        if (x2 < PIQ) x2 = x2 + PI2;
+        int kx2 = (int)((x2 - PIQ - pi) * invdx) + 1, ky2 = (int)(y2 * invdy) + 1, ka2 = (int)((ap - p5) * invda) + 1;
+        kx2 = kx2 < 1 ? 1 : (kx2 > nxy ? nxy : kx2);
+        ky2 = ky2 < 1 ? 1 : (ky2 > nyy ? nyy : ky2);
+        ka2 = ka2 < 1 ? 1 : (ka2 > nay ? nay : ka2);
+#pragma omp atomic
+        g_eap_n[0]++;
+        if (kx2 != kx || ky2 != ky || ka2 != ka) {
+#pragma omp atomic
+            g_eap_n[1]++;
+        }
+    }
     const size_t q = ((size_t)(ka - 1) * nyy + (ky - 1)) * nxy + (kx - 1);
     const double stemp11r = e->s11r[q], stemp12r = e->s12r[q], stemp22r = e->s22r[q];
     const double stemp11s = e->s11s[q], stemp12s = e->s12s[q], stemp22s = e->s22s[q];
@@ -199,11 +248,31 @@ static double calc_ffrac(int blockno, double stressp, double stressm, double str
     const double sigma_1 = Q11Q11 * sigma11 + c2 * Q11Q12 * sigma12 + Q12Q12 * sigma22;
     const double sigma_2 = Q12Q12 * sigma11 - c2 * Q11Q12 * sigma12 + Q11Q11 * sigma22;
     const double diffuse = blockno == 1 ? kfrac * (a1x - Q12Q12) : kfrac * (a1x + Q11Q12);
-    if (sigma_1 >= c0 && sigma_2 >= c0) return c0;
-    if (sigma_1 >= c0 && sigma_2 < c0) return diffuse;
-    if (sigma_2 == c0) return c0;
-    if (sigma_1 <= c0 && sigma_1 / sigma_2 <= threshold) return diffuse;
-    return c0;
+    int branch;                                   /* 0: no fracture term, 1: the diffuse term */
+    if (sigma_1 >= c0 && sigma_2 >= c0) branch = 0;
+    else if (sigma_1 >= c0 && sigma_2 < c0) branch = 1;
+    else if (sigma_2 == c0) branch = 0;
+    else if (sigma_1 <= c0 && sigma_1 / sigma_2 <= threshold) branch = 1;
+    else branch = 0;
+    if (g_eap_count && blockno == 1) {
+        const double g2 = p5 * atan2((c2 * sigma12), (sigma11 - sigma22));
+        const double q11 = cos(g2), q12 = sin(g2);
+        const double s1 = q11 * q11 * sigma11 + c2 * (q11 * q12) * sigma12 + q12 * q12 * sigma22;
+        const double s2 = q12 * q12 * sigma11 - c2 * (q11 * q12) * sigma12 + q11 * q11 * sigma22;
+        int b2;
+        if (s1 >= c0 && s2 >= c0) b2 = 0;
+        else if (s1 >= c0 && s2 < c0) b2 = 1;
+        else if (s2 == c0) b2 = 0;
+        else if (s1 <= c0 && s1 / s2 <= threshold) b2 = 1;
+        else b2 = 0;
+#pragma omp atomic
+        g_eap_n[2]++;
+        if (b2 != branch) {
+#pragma omp atomic
+            g_eap_n[3]++;
+        }
+    }
+    return branch ? diffuse : c0;
 }
 
 /* ---------------------------------------------------------------------------

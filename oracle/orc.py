@@ -98,6 +98,33 @@ def _limit_threads():
     return int(os.environ["OMP_NUM_THREADS"])
 
 
+_lib_libm = None
+
+
+def lib_libm():
+    """the restatement built with the host's libm for the EAP angles (oracle/Makefile: libevp_oracle_libm.so)"""
+    global _lib_libm
+    if _lib_libm is None:
+        build()
+        path = os.path.join(_HERE, "libevp_oracle_libm.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "eap_oracle.c")):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "libevp_oracle_libm.so"], stdout=subprocess.DEVNULL)
+        L = ct.CDLL(path)
+        L.orc_set_num_threads.argtypes = [ct.c_int]
+        L.orc_set_num_threads(_limit_threads())
+        L.orc_eap.argtypes = lib().orc_eap.argtypes
+        _lib_libm = L
+    return _lib_libm
+
+
+def eap_lookup_counts(enable: bool):
+    """(lookups, lookups whose index triple differs under libm, calc_ffrac decisions, decisions that differ) since the last
+    call; enable / disable the counting mode of eap_oracle.c"""
+    out = (ct.c_longlong * 4)()
+    lib().orc_eap_lookup_counts(out, int(enable))
+    return tuple(int(v) for v in out)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -129,6 +156,7 @@ def lib():
         _lib.orc_halo_stress.argtypes = [ct.POINTER(OrcGeom), c_f64p, c_f64p]
         _lib.orc_principal_stress.argtypes = [ct.c_int, ct.c_int] + [c_f64p] * 6
         _lib.orc_set_halo_callback.argtypes = [HALO_CB, ct.c_void_p]
+        _lib.orc_eap_lookup_counts.argtypes = [ct.POINTER(ct.c_longlong), ct.c_int]
         _lib.orc_exp.argtypes = [ct.c_double]
         _lib.orc_exp.restype = ct.c_double
         _lib.orc_ice_strength.argtypes = [ct.c_int] * 7 + [c_i32p] * 2 + [c_f64p] * 6 + [ct.POINTER(OrcParams)]
@@ -201,7 +229,7 @@ def evp(d, params: OrcParams, f: Dict[str, np.ndarray], nsub: int = 0):
     return int(counts[0]), int(counts[1]), float(secs[0])
 
 
-def eap(d, params: OrcParams, f: Dict[str, np.ndarray], tables, nsub: int = 0):
+def eap(d, params: OrcParams, f: Dict[str, np.ndarray], tables, nsub: int = 0, libm: bool = False):
     """orc_eap: eap(dt) (ice_dyn_eap.F90:66-486) in place on `f`, which also holds a11_1..4, a12_1..4 (in/out), a11, a12 and
     the nine history fields (cice5_amd.synth.add_eap_state); tables = cice5_amd.eap_tables.eap_tables()"""
     g, keep = make_geom(d)
@@ -218,7 +246,7 @@ def eap(d, params: OrcParams, f: Dict[str, np.ndarray], tables, nsub: int = 0):
         setattr(e, n, _p64(f[n]))
     counts = (ct.c_int64 * 2)()
     secs = (ct.c_double * 2)(0.0, 0.0)
-    lib().orc_eap(ct.byref(g), ct.byref(params), ct.byref(of), ct.byref(e), int(nsub), counts, secs)
+    (lib_libm() if libm else lib()).orc_eap(ct.byref(g), ct.byref(params), ct.byref(of), ct.byref(e), int(nsub), counts, secs)
     del keep
     return int(counts[0]), int(counts[1]), float(secs[0])
 
