@@ -1,7 +1,7 @@
 /*
  * oracle/evp_oracle.c -- CPU restatement of the CICE5 EVP dynamics path (plain C99).
  *
- * TEST INFRASTRUCTURE ONLY (see evp_oracle.h).  PARITY UNPINNED (see evp_oracle.h).
+ * TEST INFRASTRUCTURE ONLY.  Parity: halo updates and ice_strength pinned by the reference's own output, the rest UNPINNED (see evp_oracle.h).
  *
  * Every routine follows the operation order of the Fortran it cites, with
  * -ffp-contract=off so that no multiply-add is fused.  Fortran evaluates

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py -- never by the cice5_amd product path.
-PARITY UNPINNED (see oracle/evp_oracle.h).
+Parity: halo updates / ice_strength pinned by reference output (tests/golden/ref_*.npz), the rest UNPINNED (oracle/evp_oracle.h).
 """
 from __future__ import annotations
 
