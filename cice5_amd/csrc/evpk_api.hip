@@ -260,6 +260,7 @@ struct evpk_ctx {
     std::vector<BlockDesc> bd;
     BlockDesc *d_bd = nullptr;
     bool full_cover = true;
+    bool band_fused = true;       // EVPK_BAND_FUSED (default 1): see subcycle_impl
     int ew = 0, ns = 0, rank = 0, nranks = 1, west = -1, east = -1, device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // interior strips of k_subcycle2 while `stream` exchanges the edge columns
@@ -759,14 +760,15 @@ static int halo_stress12(evpk_ctx *c, int f0) {
 
 // ---- launch of the two-subcycle kernel (plain or LDS-prefetch variant) ------------------------------------
 static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp, bool last2) {
+    const int nband8 = (a.nband + 7) & ~7;      // the tripole top band as the first workgroups of the launch (band_pair)
     if (c->tile_mode) {      // small-slab variant: one workgroup of R + 3 waves per strip, one row per wave
-        const dim3 gt(((a.nstrips + 7) / 8) * 8), bt((a.R + 3) * 64);
-        const size_t lds = (size_t)(a.R + 3) * 4096;
+        const dim3 gt(((a.nstrips + 7) / 8) * 8 + nband8), bt((a.R + 3) * 64);
+        const size_t lds = std::max((size_t)(a.R + 3) * 4096, a.nband ? sizeof(double) * BAND_LDS_DOUBLES : (size_t)0);
         if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, true>), gt, bt, lds, st, a); }
         else       { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false>), gt, bt, lds, st, a); }
         return;
     }
-    const dim3 g((((a.nstrips + 3) / 4 + 7) / 8) * 8), b(256);     // multiple of 8: XCD remap in the kernel
+    const dim3 g((((a.nstrips + 3) / 4 + 7) / 8) * 8 + nband8), b(256);     // multiple of 8: XCD remap in the kernel
     if (c->prefetch) {
 #define EVPK_L2P(RV, L2, CMX) hipLaunchKernelGGL((k_subcycle2p<RV, L2, CMX>), g, b, 0, st, a)
         if (c->compact) {
@@ -1253,6 +1255,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         // (they are divisors in to_ugrid / to_tgrid; the reference never visits them)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (const char *bf = getenv("EVPK_BAND_FUSED")) c->band_fused = atoi(bf) != 0;
     const char *tk = getenv("EVPK_TIME_KERNELS");
     c->time_kernels = tk ? std::max(0, std::min(atoi(tk), 2)) : 1;
     // a multi-rank context without a unique id stays unconnected until evpk_connect (two-phase start)
@@ -1791,14 +1794,18 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30;
+        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0;
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
         // (a small slab on a one-rank tripole grid: the band sequence of a pair -- two band launches, two folds, two hand-overs
         // between the streams, ~35 us -- costs more than two one-row-per-wave launches with their folds on one stream: 2.4 ms
         // against 1.9 per evp at 360x300, even at 720x540, measured again with the stream-memory hand-overs)
-        const bool pairs = c->use_double && !(c->band_mode && c->tile_mode && c->nranks == 1 && !c->force_exchange);
+        // tripole on ONE rank: the top band of a pair runs as extra workgroups of the pair's own launch (band_pair: a strip
+        // and its mirror image in one workgroup, the fold between the subcycles in its LDS) -- no band launches, no second
+        // stream, no hand-overs; EVPK_BAND_FUSED=0 brings the launches on stream2 back
+        const bool fused_band = c->band_mode && c->band_fused && wrap && (c->prefetch || c->tile_mode) && s.nyl >= 4;
+        const bool pairs = c->use_double && (fused_band || !(c->band_mode && c->tile_mode && c->nranks == 1 && !c->force_exchange));
         const bool pair_inside = pairs && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
         // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
         // the LAST variant of k_subcycle)
@@ -1826,7 +1833,10 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 else if (revp) hipLaunchKernelGGL((k_subcycle_t<false, true>), g, b, lds, st, bb);
                 else hipLaunchKernelGGL((k_subcycle_t<false, false>), g, b, lds, st, bb);
             };
-            if (c->band_mode) {
+            if (fused_band) {
+                a.nband = (s.nxl / 2 + 1 + 60) / 61;          // strips A cover columns 0 .. nx/2, their mirror images the rest
+                a.jmax = s.nyl - 2;
+            } else if (c->band_mode) {
                 b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0; b1.G = 0;
                 b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
                 b2 = b1;
@@ -1887,7 +1897,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 HIPCHK(c, hipEventRecord(c->evE, c->stream));
                 evE_valid = true;
             }
-            if (c->band_mode) {
+            if (c->band_mode && !fused_band) {
                 if (c->handover_value) HIPCHK(c, hipStreamWaitValue32(c->stream, c->sigB1, c->sig_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
                 else HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
             }

@@ -963,6 +963,8 @@ struct SubArgs {
     int jb0;           // > 0: band launch -- every strip starts at row jb0 (tripole top band), strips[] holds cx only
     int jmax;          // k_subcycle2: rows above are not stored (tripole, single rank: the band launches own rows >= nyl-1)
     int G;             // k_subcycle2 in ghost-zone mode: columns 1-G .. nxl+G are advanced (zones of G+2 columns per side)
+    int nband;         // > 0 (tripole, one rank, cyclic E-W): the first nband8 = 8*ceil(nband/8) workgroups of the launch are the
+                       // tripole top band (band_pair); the strips follow
 };
 
 // Neighbour-lane exchange as DPP whole-wave shifts (v_mov_b32_dpp wave_shl:1 / wave_shr:1, VALU only) instead of
@@ -1584,6 +1586,225 @@ __global__ void k_verify_metrics(Slab s, unsigned int *mismatch) {
     if (!ok) atomicAdd(mismatch, 1u);
 }
 
+// ------------------------------------------------------------------------------------
+// band_pair: the tripole TOP BAND of a pair of subcycles as workgroups OF THE MAIN LAUNCH (one rank, cyclic E-W).
+// The fold (serial/ice_boundary.F90:801-888, :3752-3776) mixes mirrored columns between the two fused subcycles, but only U
+// rows >= N-1 and T rows >= N-1 of the pair's result depend on it (N = nyl); the main strips leave those rows alone (jmax =
+// N-2).  Until round 3 they were redone by two band launches and two fold launches on a second stream, with two stream
+// hand-overs per pair (~17 us, and the band launches queued behind the main launch's resident workgroups).  Here ONE
+// workgroup owns a strip A and its mirror image B, so that the fold between the subcycles is a matter of this workgroup's
+// LDS -- no launch, no stream, no inter-workgroup synchronisation:
+//   strip A of band workgroup k: lane l <-> column 61 k - 1 + l,  strip B: lane l <-> column nx - 61 k - 61 + l   (cyclic);
+//   the mirror image of A's lane l is B's lane 62 - l (NE-corner fold: column g <-> nx - g, 0 == nx).
+//   phase A  T1 rows N-2 .. N+1 (wave w: row N-2+w, strips A and B in turn), 64 lanes       -> LDS: str terms, sigma_1
+//   phase B  U1 rows N-2 .. N, lanes 0..62                                                    -> LDS
+//   fold 1   top row symmetrised, ghost row N+1 <- mirrored row N-1 (lanes 0..62)              in LDS
+//   phase C  T2 rows N-1 .. N+1, lanes 1..62; sigma stored for lanes 1..61                    -> LDS: str terms
+//   phase D  U2 rows N-1, N, lanes 1..61; row N-1 stored                                      -> LDS
+//   fold 2   rows N and N+1 of the new state stored (+ the E-W ghost images)
+// Lanes 1..61 of the A and B strips of all band workgroups cover every column once or twice (overlaps compute the same
+// bits).  Arithmetic, operation order and the rule for inactive top-row cells are those of k_subcycle_t +
+// k_halo_tripole_ne1: bit-identical (tests: every tripole case, test_two_subcycle_kernel_equals_single).
+// Uses waves 0..3 of the workgroup and BAND_LDS_DOUBLES doubles of LDS; every wave takes part in the barriers.
+// ------------------------------------------------------------------------------------
+constexpr int BAND_LDS_DOUBLES = 2048 + 1024 + 4608 + 512;      // X, U1, S1, V2 = 64 KiB
+
+template <bool REVP, bool LAST2>
+__device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) {
+    const Slab &s = a.s;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nx = s.nxl, N = s.nyl, h = nx >> 1;
+    const size_t pp = (size_t)s.pitch * 16;
+    const size_t rowb = (size_t)s.rstride * 16;
+    char *const base = reinterpret_cast<char *>(s.F);
+    const int SR = a.sr, SW = a.sw;
+    const double sgn = -1.0;                                       // (u, v): a vector
+    double *const X = lds;                                         // [strip][row 0..3][4][64]
+    double *const U1 = X + 2048;                                   // [strip][row 0..3][u, v][64]     rows N-2 .. N+1
+    double *const S1 = U1 + 1024;                                  // [strip][row 1..3][12][64]
+    double *const V2 = S1 + 4608;                                  // [strip][row 1..2][u, v][64]
+    const bool rw = (w < 4);
+    const int r = N - 2 + (rw ? w : 0);                            // this wave's row
+    char *const rb = base + (size_t)r * rowb;
+    auto wrapc = [&](int c) { int q = (c - 1) % nx; if (q < 0) q += nx; return q + 1; };
+    int ci[2];
+    unsigned lo[2];
+    unsigned char m[2] = {0, 0};
+    double uc[2] = {0, 0}, vc[2] = {0, 0}, k1[2] = {0, 0}, k2[2] = {0, 0}, k5[2] = {0, 0}, k7[2] = {0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int c = (t ? nx - 61 * k - 61 : 61 * k - 1) + lane;
+        ci[t] = wrapc(c);
+        lo[t] = (unsigned)(C0 + ci[t]) * 16u;
+    }
+
+    // ---------------- phase A: T1(r), both strips ----------------
+    if (rw) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const unsigned lom = (unsigned)(C0 + wrapc(ci[t] - 1)) * 16u;
+            m[t] = s.cmask[(size_t)r * s.pitch + C0 + ci[t]];
+            const double2 q0 = ldp(rb, pp, SR + S_U, lo[t]), q1 = ldp(rb, pp, SR + S_U, lom);
+            const char *rs = rb - rowb;
+            const double2 q2 = ldp(rs, pp, SR + S_U, lo[t]), q3 = ldp(rs, pp, SR + S_U, lom);
+            uc[t] = q0.x; vc[t] = q0.y;
+            const bool tact = (m[t] & CM_T) != 0;
+            Str8 o{0, 0, 0, 0, 0, 0, 0, 0};
+            Sig g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (__any(tact)) {
+                if (tact) {
+                    const TMet mt = load_tmet(rb, pp, lo[t]);
+                    g = load_sig(rb, pp, SR, lo[t]);
+                    Diag dg;
+                    stress_cell<false>(mt, q0.x, q1.x, q2.x, q3.x, q0.y, q1.y, q2.y, q3.y, a.ecci, a.arlx1i, a.denom1, 0.0, g, o, dg);
+                }
+            }
+            const double s2n = shfl_dn1(o.s2), s4n = shfl_dn1(o.s4), s7n = shfl_dn1(o.s7), s8n = shfl_dn1(o.s8);
+            double *const Xq = X + (size_t)((t * 4 + w) * 4) * 64 + lane;
+            Xq[0] = o.s3; Xq[64] = o.s6; Xq[128] = s4n; Xq[192] = s8n;
+            k1[t] = o.s1; k2[t] = s2n; k5[t] = o.s5; k7[t] = s7n;
+            if (w >= 1) {
+                double *const Sq = S1 + (size_t)((t * 3 + (w - 1)) * 12) * 64 + lane;
+                Sq[0] = g.sp1; Sq[64] = g.sp2; Sq[128] = g.sp3; Sq[192] = g.sp4; Sq[256] = g.sm1; Sq[320] = g.sm2;
+                Sq[384] = g.sm3; Sq[448] = g.sm4; Sq[512] = g.s121; Sq[576] = g.s122; Sq[640] = g.s123; Sq[704] = g.s124;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase B: U1(r), rows N-2 .. N ----------------
+    if (w <= 2) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            double u1 = uc[t], v1 = vc[t];                          // an inactive cell keeps its velocity
+            const bool uact = (m[t] & CM_U) != 0 && r >= 1 && r <= N;
+            if (__any(uact)) {
+                if (uact) {
+                    const UStat q = load_ustat(rb, pp, lo[t]);
+                    double ui = 0.0, vi = 0.0, sxi, syi;
+                    if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo[t]); ui = iv.x; vi = iv.y; }
+                    const double *Xn = X + (size_t)((t * 4 + w + 1) * 4) * 64 + lane;      // the T row above
+                    stepu_cell(q, uc[t], vc[t], ui, vi, ((k1[t] + k2[t]) + Xn[0]) + Xn[128], ((k5[t] + Xn[64]) + k7[t]) + Xn[192],
+                               a.brlx, a.revp, a.cosw, a.sinw, u1, v1, sxi, syi);
+                }
+            }
+            double *const Uq = U1 + (size_t)((t * 4 + w) * 2) * 64 + lane;
+            Uq[0] = u1; Uq[64] = v1;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- fold 1 (k_halo_tripole_ne1's arithmetic): waves 0, 1 <-> strips A, B; lanes 0 .. 62 ----------------
+    {
+        double tu = 0, tv = 0, gu = 0, gv = 0;
+        const bool f1 = (w < 2) && lane <= 62;
+        if (f1) {
+            const int t = w, g = ci[t];
+            const double *Ut = U1 + (size_t)((t * 4 + 2) * 2) * 64 + lane;                  // my top row
+            const double *Um = U1 + (size_t)(((1 - t) * 4 + 2) * 2) * 64 + (62 - lane);     // the mirror column's top row
+            const double *Rm = U1 + (size_t)(((1 - t) * 4 + 1) * 2) * 64 + (62 - lane);     // ... and its row N-1
+            const double Tu = Ut[0], Tv = Ut[64], Mu = Um[0], Mv = Um[64];
+            if (g == nx || g == h) { tu = sgn * Tu; tv = sgn * Tv; }
+            else if (g < h) { tu = sgn * (sgn * (0.5 * (Tu + sgn * Mu))); tv = sgn * (sgn * (0.5 * (Tv + sgn * Mv))); }
+            else { tu = sgn * (0.5 * (Mu + sgn * Tu)); tv = sgn * (0.5 * (Mv + sgn * Tv)); }
+            gu = sgn * Rm[0]; gv = sgn * Rm[64];
+        }
+        __syncthreads();
+        if (f1) {
+            const int t = w;
+            double *const Ut = U1 + (size_t)((t * 4 + 2) * 2) * 64 + lane;
+            double *const Ug = U1 + (size_t)((t * 4 + 3) * 2) * 64 + lane;
+            Ut[0] = tu; Ut[64] = tv; Ug[0] = gu; Ug[64] = gv;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase C: T2(r), rows N-1 .. N+1 (waves 1 .. 3), lanes 1 .. 62 ----------------
+    if (w >= 1 && w <= 3) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const bool t2act = (m[t] & CM_T) != 0 && lane >= 1 && lane <= 62;
+            Str8 o{0, 0, 0, 0, 0, 0, 0, 0};
+            if (__any(t2act)) {
+                if (t2act) {
+                    const double *Uq = U1 + (size_t)((t * 4 + w) * 2) * 64 + lane, *Us = Uq - 128;
+                    const double *Sq = S1 + (size_t)((t * 3 + (w - 1)) * 12) * 64 + lane;
+                    Sig g{Sq[0], Sq[64], Sq[128], Sq[192], Sq[256], Sq[320], Sq[384], Sq[448], Sq[512], Sq[576], Sq[640], Sq[704]};
+                    const TMet mt = load_tmet(rb, pp, lo[t]);
+                    double tarear = 0.0;
+                    if (LAST2) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo[t] + (F_TAREAR & 1) * 8);
+                    Diag dg;
+                    stress_cell<LAST2>(mt, Uq[0], Uq[-1], Us[0], Us[-1], Uq[64], Uq[63], Us[64], Us[63], a.ecci, a.arlx1i, a.denom1, tarear, g, o, dg);
+                    if (lane <= 61) {
+                        store_sig(rb, pp, SW, lo[t], g);
+                        if (ci[t] == 1) store_sig(rb, pp, SW, lo[t] + (unsigned)nx * 16u, g);     // east ghost T column = image of column 1
+                        if (LAST2) {
+                            st1(rb, pp, F_DIVU, lo[t], dg.divu);       st1(rb, pp, F_RDGCONV, lo[t], dg.rdg_conv);
+                            st1(rb, pp, F_RDGSHEAR, lo[t], dg.rdg_shear); st1(rb, pp, F_SHEAR, lo[t], dg.shear);
+                            st1(rb, pp, F_PRSSIG, lo[t], dg.prs);
+                        }
+                    }
+                }
+            }
+            const double s2n = shfl_dn1(o.s2), s4n = shfl_dn1(o.s4), s7n = shfl_dn1(o.s7), s8n = shfl_dn1(o.s8);
+            double *const Xq = X + (size_t)((t * 4 + w) * 4) * 64 + lane;
+            Xq[0] = o.s3; Xq[64] = o.s6; Xq[128] = s4n; Xq[192] = s8n;
+            k1[t] = o.s1; k2[t] = s2n; k5[t] = o.s5; k7[t] = s7n;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase D: U2(r), rows N-1, N (waves 1, 2), lanes 1 .. 61 ----------------
+    if (w >= 1 && w <= 2) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const double *Uq = U1 + (size_t)((t * 4 + w) * 2) * 64 + lane;
+            const double u1 = Uq[0], v1 = Uq[64];
+            double u2 = u1, v2 = v1;
+            const bool uact = (m[t] & CM_U) != 0 && lane >= 1 && lane <= 61;       // (r <= N)
+            if (__any(uact)) {
+                if (uact) {
+                    const UStat q = load_ustat(rb, pp, lo[t]);
+                    double ui = 0.0, vi = 0.0, sxi, syi;
+                    if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo[t]); ui = iv.x; vi = iv.y; }
+                    const double *Xn = X + (size_t)((t * 4 + w + 1) * 4) * 64 + lane;
+                    stepu_cell(q, u1, v1, ui, vi, ((k1[t] + k2[t]) + Xn[0]) + Xn[128], ((k5[t] + Xn[64]) + k7[t]) + Xn[192],
+                               a.brlx, a.revp, a.cosw, a.sinw, u2, v2, sxi, syi);
+                    if (w == 1) {                                   // row N-1 is final; row N goes through the fold below
+                        stp(rb, pp, SW + S_U, lo[t], u2, v2);
+                        if (ci[t] == 1) stp(rb, pp, SW + S_U, lo[t] + (unsigned)nx * 16u, u2, v2);
+                        if (ci[t] == nx) stp(rb, pp, SW + S_U, lo[t] - (unsigned)nx * 16u, u2, v2);
+                    }
+                    if (LAST2) { st1(rb, pp, F_STRINTX, lo[t], sxi); st1(rb, pp, F_STRINTY, lo[t], syi); }
+                }
+            }
+            double *const Vq = V2 + (size_t)((t * 2 + (w - 1)) * 2) * 64 + lane;
+            Vq[0] = u2; Vq[64] = v2;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- fold 2: rows N and N+1 of the new state, lanes 1 .. 61 ----------------
+    if (w < 2 && lane >= 1 && lane <= 61) {
+        const int t = w, g = ci[t];
+        const double *Vt = V2 + (size_t)((t * 2 + 1) * 2) * 64 + lane;
+        const double *Vm = V2 + (size_t)(((1 - t) * 2 + 1) * 2) * 64 + (62 - lane);
+        const double *Rm = V2 + (size_t)(((1 - t) * 2 + 0) * 2) * 64 + (62 - lane);
+        const double Tu = Vt[0], Tv = Vt[64], Mu = Vm[0], Mv = Vm[64];
+        double tu, tv;
+        if (g == nx || g == h) { tu = sgn * Tu; tv = sgn * Tv; }
+        else if (g < h) { tu = sgn * (sgn * (0.5 * (Tu + sgn * Mu))); tv = sgn * (sgn * (0.5 * (Tv + sgn * Mv))); }
+        else { tu = sgn * (0.5 * (Mu + sgn * Tu)); tv = sgn * (0.5 * (Mv + sgn * Tv)); }
+        const double gu = sgn * Rm[0], gv = sgn * Rm[64];
+        char *const rN = base + (size_t)N * rowb, *const rG = rN + rowb;
+        stp(rN, pp, SW + S_U, lo[t], tu, tv);
+        stp(rG, pp, SW + S_U, lo[t], gu, gv);
+        if (g == 1) { stp(rN, pp, SW + S_U, lo[t] + (unsigned)nx * 16u, tu, tv); stp(rG, pp, SW + S_U, lo[t] + (unsigned)nx * 16u, gu, gv); }
+        if (g == nx) { stp(rN, pp, SW + S_U, lo[t] - (unsigned)nx * 16u, tu, tv); stp(rG, pp, SW + S_U, lo[t] - (unsigned)nx * 16u, gu, gv); }
+    }
+}
+
 constexpr int PF_SLOTS = 18;     // 0,1: (u,v) at c, c-1; 2..6: metrics; 7..12: sigma; 13..16: stepu inputs; 17: uvel_init
 
 __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
@@ -1595,11 +1816,18 @@ __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
 template <bool REVP, bool LAST2, bool CM>
 __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two workgroups per CU: at most 256 VGPRs
     __shared__ double2 smem[4 * PF_SLOTS * 64];
+    static_assert(sizeof(double2) * 4 * PF_SLOTS * 64 >= sizeof(double) * BAND_LDS_DOUBLES, "the band workgroups use the same LDS");
     const Slab &s = a.s;
     const int lane = threadIdx.x & 63;
     double2 *const L = smem + (size_t)(threadIdx.x >> 6) * PF_SLOTS * 64;     // this wave's slots
-    const int chunk = gridDim.x >> 3;
-    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int nband8 = (a.nband + 7) & ~7;
+    if ((int)blockIdx.x < nband8) {              // tripole top band of this pair of subcycles (one rank): see band_pair
+        if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, reinterpret_cast<double *>(smem));
+        return;
+    }
+    const int bidx = (int)blockIdx.x - nband8;
+    const int chunk = ((int)gridDim.x - nband8) >> 3;
+    const int wg = (bidx & 7) * chunk + (bidx >> 3);
     const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (sid >= a.nstrips) return;
     const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
@@ -1870,8 +2098,14 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = blockDim.x >> 6;                   // R + 3
-    const int chunk = gridDim.x >> 3;
-    const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int nband8 = (a.nband + 7) & ~7;
+    if ((int)blockIdx.x < nband8) {                   // tripole top band of this pair (one rank; the launch asks for the LDS)
+        if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, tl);
+        return;
+    }
+    const int bidx = (int)blockIdx.x - nband8;
+    const int chunk = ((int)gridDim.x - nband8) >> 3;
+    const int wg = (bidx & 7) * chunk + (bidx >> 3);
     if (wg >= a.nstrips) return;                      // (the whole workgroup leaves: no barrier is left waiting)
     const int st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
     const int cx = st % a.ncx, ry = st / a.ncx;
