@@ -717,12 +717,32 @@ def test_restart_records_from_the_device_state(ns, tmp_path):
     assert not bad, bad[:6]
 
 
+@pytest.mark.parametrize("shape", [(360, 300, 15, 300, 120), (130, 96, 130, 96, 31), (1440, 1080, 360, 1080, 8), (62, 40, 31, 20, 13)])
+@pytest.mark.parametrize("tile", ["", "0", "1"])
+def test_tripole_band_launches_on_the_second_stream(shape, tile, monkeypatch):
+    """EVPK_BAND_FUSED=0: the one-rank tripole top band as it ran until round 3 -- two band launches and two folds per pair
+    on the second stream (still the path of x-slab ranks) -- stays bit-identical; and the fused band (default) under both the
+    marching and the one-row-per-wave pair kernels (EVPK_TILE fixes the tuner's choice)."""
+    nx, ny, bsx, bsy, ndte = shape
+    if tile:
+        monkeypatch.setenv("EVPK_TILE", tile)
+    _both(nx, ny, bsx, bsy, ns="tripole", land="continents", ndte=ndte, ncalls=2)
+    monkeypatch.setenv("EVPK_BAND_FUSED", "0")
+    _both(nx, ny, bsx, bsy, ns="tripole", land="continents", ndte=ndte)
+
+
 def test_bound_time_is_reported():
     """evpk_stats.bound_ms: the halo / fold updates of the subcycle loop (timer_bound in the reference) are timed with
-    sampled HIP events: none on a cyclic one-rank open grid (the kernel wraps in place), some on a tripole grid."""
-    for ns, want in (("open", False), ("tripole", True)):
+    sampled HIP events: none on a cyclic one-rank open grid (the kernel wraps in place) nor on a one-rank tripole grid whose
+    pairs fold inside the launch (band_pair; ndte even: no one-subcycle tail), some when the fold is a launch of its own
+    (odd ndte: the tail subcycle; EVPK_BAND_FUSED=0: the band launches on the second stream)."""
+    for ns, ndte, env, want in (("open", 30, None, False), ("tripole", 30, None, False), ("tripole", 31, None, True),
+                                ("tripole", 30, "0", True)):
+        if env is not None:
+            os.environ["EVPK_BAND_FUSED"] = env
         case, d, f = util.make_case(130, 96, 130, 96, ns=ns, land="continents")
-        s = dyn.EvpDynamics(d, f, ndte=30, xmin=synth.global_min_dx(case))
+        s = dyn.EvpDynamics(d, f, ndte=ndte, xmin=synth.global_min_dx(case))
+        os.environ.pop("EVPK_BAND_FUSED", None)
         s.init_evp(3600.0)
         s.evp(3600.0)
         st = s.ctx.stats()
