@@ -746,7 +746,9 @@ def test_bound_time_is_reported():
         s.init_evp(3600.0)
         s.evp(3600.0)
         st = s.ctx.stats()
-        assert (st.bound_updates > 0) == want and (st.bound_ms > 0.0) == want, (ns, st.bound_updates, st.bound_ms)
+        assert (st.bound_updates > 0) == want, (ns, ndte, env, st.bound_updates, st.bound_ms)
+        if not want or st.bound_updates >= 5:          # (every fifth update is timed)
+            assert (st.bound_ms > 0.0) == want, (ns, ndte, env, st.bound_updates, st.bound_ms)
         s.close()
 
 
