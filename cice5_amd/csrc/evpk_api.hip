@@ -2606,6 +2606,8 @@ extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
     (void)hipMemsetAsync(b, 0x22, EVPK_CALIB_BIG_BYTES, c->stream);
     for (int k = 0; k < nrep; k++)
         hipLaunchKernelGGL(k_calib_copy_big, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double2 *)a, b, n);
+    for (int k = 0; k < nrep; k++)      // ... and with 8 B per lane: the plain planes of rows f-3 / f-4
+        hipLaunchKernelGGL(k_calib_copy_big8, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, (const double *)a, (double *)b, 2 * n);
     const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
     (void)hipFree(a); (void)hipFree(b);
     if (e1 != hipSuccess || e2 != hipSuccess) FAIL(c, "evpk_calibrate: copy failed");

@@ -524,6 +524,11 @@ __global__ void k_calib_copy_pair(Slab s, int fsrc_even, int fdst_even) {
 
 // profiling aid, second form: a streaming copy between two buffers far larger than the 256 MiB Infinity Cache (16 B per
 // lane, coalesced): n double2 read, n double2 written, nothing the caches can absorb
+// the same byte count with 8 B per lane (the access shape of the plain planes of horizontal_remap / eap)
+__global__ void k_calib_copy_big8(const double *__restrict__ src, double *__restrict__ dst, size_t n) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] = src[k];
+}
 __global__ void k_calib_copy_big(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) dst[k] = src[k];

@@ -15,3 +15,9 @@ for r in rows[:14]:
     print(r["Name"][:70].ljust(70), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"])
 PY
 tail -1 "$out/bench.log"
+# HBM traffic per kernel: separate FETCH_SIZE / WRITE_SIZE passes (ONE call of the remap + calibration copies)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o f -- python3 scripts/remap_bench.py --cpu-grid 0 --reps 1 --calib 2 > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -o w -- python3 scripts/remap_bench.py --cpu-grid 0 --reps 1 --calib 2 > "$out/pmc_write.log" 2>&1
+python3 scripts/pmc_kernels.py "$(find "$out/pmc_fetch" -name "*counter_collection.csv" | tail -1)" "$(find "$out/pmc_write" -name "*counter_collection.csv" | tail -1)" \
+    "k_remap|k_gather_planes|k_scatter_planes|k_state_|k_planes_" "$out/pmc_traffic.json" 8
+rm -rf "$out/pmc_fetch" "$out/pmc_write"

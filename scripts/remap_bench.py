@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--trcr", default="0,1,1,1,1,2,1,1,1,1")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu-grid", default="360x300", help="grid of the CPU sample (same state per cell, 0 = skip)")
+    ap.add_argument("--calib", type=int, default=0, help="untimed calibration copies (1 GiB each way, 16 and 8 B per lane) for rocprofv3 --pmc runs")
     a = ap.parse_args()
     import torch
     from cice5_amd import blocks, constants as C, dyn, synth
@@ -106,6 +107,8 @@ def main():
         times.append(time.perf_counter() - t)
         assert rc == 0, (rc, L.evpk_last_error(ctx))
     moved = float((dmm - m0).abs().max())
+    if a.calib:
+        s.ctx.calibrate(a.calib)
     s.close()
     ms = 1e3 * min(times[1:])
     cells = nx * ny
