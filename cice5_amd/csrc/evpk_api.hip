@@ -2529,9 +2529,20 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     const int SB = c->cur ? F_STATE1 : F_STATE0;
     hipLaunchKernelGGL(k_remap_dp, g2, B2D, 0, c->stream, s, SB, dt, dxu, dyu, tb.midpt, (int)F_SIG1, (int)F_SIG2, c->rm_bad);
     if (halo(c, F_SIG1, 2, true, true, 0.0)) return 1;
+    // fluxes + update: one tiled kernel whose edge transports stay in the LDS (EVPK_REMAP_FUSED=0 or more than 14 tracers: the
+    // three kernels that hand fe, fn, tfe, tfn over through HBM)
+    const size_t flux_lds = sizeof(double) * 2 * 256 * (size_t)(1 + ntrace);
+    static const bool fused_env = !(getenv("EVPK_REMAP_FUSED") && atoi(getenv("EVPK_REMAP_FUSED")) == 0);
+    if (fused_env && flux_lds <= 60 * 1024) {
+        hipLaunchKernelGGL(k_remap_fluxupd, dim3((s.nxl + RM_TILE - 2) / (RM_TILE - 1), (s.nyl + RM_TILE - 2) / (RM_TILE - 1), ncp), dim3(256), flux_lds, c->stream,
+                           s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2, c->rm_bad);
+        // the new masses were written beside the old ones (plane fe(n)): in place of mm(n) now that every tile is done
+        HIPCHK(c, hipMemcpyAsync(c->rm_pool, c->rm_pool + (size_t)3 * ncp * np, sizeof(double) * (size_t)ncp * np, hipMemcpyDeviceToDevice, c->stream));
+    } else {
     hipLaunchKernelGGL(k_remap_flux<false>, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
     hipLaunchKernelGGL(k_remap_flux<true>, dim3((s.nxl + 63) / 64, (s.nyl + 1 + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
     hipLaunchKernelGGL(k_remap_update, dim3((s.nxl + 63) / 64, (s.nyl + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, c->rm_bad);
+    }
     HIPCHK(c, hipGetLastError());
     unsigned bad = 0;
     HIPCHK(c, hipMemcpyAsync(&bad, c->rm_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream));

@@ -353,21 +353,16 @@ __device__ __forceinline__ void rm_edge_triangles(int i, int j, FDP dxy /* (ii, 
 // ---- transport_integrals (:3199-3509): one thread per (edge, category); the triangles are rebuilt per category (a few hundred
 // operations against the loads of the integrals), the six mass sums of every triangle stay in registers while the tracers go by
 // in dependency order (RemapTab::ord), so no per-thread array is indexed at run time ----
-template <bool NORTH>
-__global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, RemapTab tb, RemapPlanes P, const double *dxu, const double *dyu, int fdx, int fdy) {
-    // east edges: i = 0 .. nxl, j = 1 .. nyl;  north edges: i = 1 .. nxl, j = 0 .. nyl   (:1823-1826, :1849-1852)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x + (NORTH ? 1 : 0);
-    const int j = blockIdx.y * blockDim.y + threadIdx.y + (NORTH ? 0 : 1);
-    const int n = blockIdx.z;
-    if (i > s.nxl || j > s.nyl) return;
-    const size_t km = mcell(s, i, j);
+// put(-1, v): the mass transport of the edge; put(nt, v): mass * tracer nt.  Every one of them is delivered exactly once.
+template <bool NORTH, typename PUT>
+__device__ __forceinline__ void rm_flux_edge(const Slab &s, const RemapTab &tb, const RemapPlanes &P, const double *dxu, const double *dyu,
+                                             int fdx, int fdy, int i, int j, int n, PUT put) {
     const size_t ka = cell(s, i, j), kb = NORTH ? cell(s, i - 1, j) : cell(s, i, j - 1);
     const bool moving = FD(s, fdx, kb) != 0.0 || FD(s, fdy, kb) != 0.0 || FD(s, fdx, ka) != 0.0 || FD(s, fdy, ka) != 0.0;   // :1911-1929
-    double *const fm = NORTH ? P.fn(n) : P.fe(n);
     if (!moving) {
-        fm[km] = 0.0;
+        put(-1, 0.0);
         if (n >= 1)
-            for (int nt = 0; nt < tb.ntrace; nt++) (NORTH ? P.tfn((n - 1) * tb.ntrace + nt) : P.tfe((n - 1) * tb.ntrace + nt))[km] = 0.0;
+            for (int nt = 0; nt < tb.ntrace; nt++) put(nt, 0.0);
         return;
     }
     double area[RM_GROUPS];
@@ -431,11 +426,11 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, Remap
             mflx = mflx + area[g] * msum;
         }
     }
-    fm[km] = mflx;
+    put(-1, mflx);
     if (n == 0) return;
     if (!anyice) {
         // tc = tx = ty = 0 where mm <= puny (construct_fields): every mtsum is a sum of (finite) * 0 and every flux 0 + (+-0) = +0
-        for (int nt = 0; nt < tb.ntrace; nt++) (NORTH ? P.tfn((n - 1) * tb.ntrace + nt) : P.tfe((n - 1) * tb.ntrace + nt))[km] = 0.0;
+        for (int nt = 0; nt < tb.ntrace; nt++) put(nt, 0.0);
         return;
     }
     double p1s[RM_GROUPS], p1x[RM_GROUPS], p1y[RM_GROUPS], p2s[RM_GROUPS];        // mtsum, mtxsum, mtysum of the last type-1 tracer; mtsum of the last type-2
@@ -489,9 +484,80 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, Remap
                 flx = flx + area[g] * mts;
             }
         }
-        (NORTH ? P.tfn(p) : P.tfe(p))[km] = flx;
+        put(nt, flx);
     }
 }
+
+// one thread per (edge, category), fluxes to the planes fe / fn, tfe / tfn (the unfused path: EVPK_REMAP_FUSED=0, ntrace > 14)
+template <bool NORTH>
+__global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, RemapTab tb, RemapPlanes P, const double *dxu, const double *dyu, int fdx, int fdy) {
+    // east edges: i = 0 .. nxl, j = 1 .. nyl;  north edges: i = 1 .. nxl, j = 0 .. nyl   (:1823-1826, :1849-1852)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + (NORTH ? 1 : 0);
+    const int j = blockIdx.y * blockDim.y + threadIdx.y + (NORTH ? 0 : 1);
+    const int n = blockIdx.z;
+    if (i > s.nxl || j > s.nyl) return;
+    const size_t km = mcell(s, i, j);
+    rm_flux_edge<NORTH>(s, tb, P, dxu, dyu, fdx, fdy, i, j, n, [&](int nt, double v) {
+        if (nt < 0) (NORTH ? P.fn(n) : P.fe(n))[km] = v;
+        else (NORTH ? P.tfn((n - 1) * tb.ntrace + nt) : P.tfe((n - 1) * tb.ntrace + nt))[km] = v;
+    });
+}
+
+// ---- fluxes and update of one tile in ONE kernel: the transports across the edges of a 16 x 16 tile never leave the LDS ----
+// Thread (tx, ty) of tile (bx, by) stands for cell (i, j) = (15 bx + tx, 15 by + ty): it computes the transports across the EAST
+// and then the NORTH edge of its cell for the mass and every tracer of category blockIdx.z into LDS ([1 + ntrace][256] doubles
+// per direction), and after one barrier the threads with tx, ty >= 1 update their cells (update_fields, :3517-3729) from their
+// own two edges and those of the west and south neighbour threads.  Tiles overlap by one row and one column (15 x 15 of 16 x 16
+// cells are updated per tile; the edges on the rim are computed by both neighbours, same bits).  Against k_remap_flux<E>,
+// k_remap_flux<N>, k_remap_update: fe, fn, tfe, tfn (2 (ncat + 1) + 2 ncat ntrace planes) are neither written nor read, and
+// tc, tx, ty, mm, mx, my are read from HBM once instead of twice.  The new mass goes to the plane of fe(n) (other tiles still
+// read the old one); tm is updated in place (the fluxes read tc, tx, ty, never tm).
+constexpr int RM_TILE = 16;
+__global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_fluxupd(Slab s, RemapTab tb, RemapPlanes P, const double *dxu, const double *dyu, int fdx, int fdy,
+                                                                        unsigned *bad) {
+    extern __shared__ double rl[];                    // FE[1 + ntrace][256], FN[1 + ntrace][256]
+    const int tx = threadIdx.x & (RM_TILE - 1), ty = threadIdx.x >> 4, tid = threadIdx.x;
+    const int i = blockIdx.x * (RM_TILE - 1) + tx, j = blockIdx.y * (RM_TILE - 1) + ty, n = blockIdx.z;
+    const int nf = 1 + tb.ntrace;
+    double *const FE = rl + tid, *const FN = rl + (size_t)nf * 256 + tid;
+    const bool in = (i <= s.nxl && j <= s.nyl);
+    if (in && j >= 1) rm_flux_edge<false>(s, tb, P, dxu, dyu, fdx, fdy, i, j, n, [&](int nt, double v) { FE[(size_t)(nt + 1) * 256] = v; });
+    if (in && i >= 1) rm_flux_edge<true>(s, tb, P, dxu, dyu, fdx, fdy, i, j, n, [&](int nt, double v) { FN[(size_t)(nt + 1) * 256] = v; });
+    __syncthreads();
+    if (!(in && tx >= 1 && ty >= 1 && i >= 1 && j >= 1)) return;
+    // update_fields: as k_remap_update, the four transports from the LDS (west: thread tid - 1, south: tid - 16)
+    const size_t k = mcell(s, i, j);
+    const double tarear = FD(s, F_TAREAR, cell(s, i, j));
+    const double mold = P.mm(n)[k];
+    double w1 = FE[0] - FE[-1] + FN[0] - FN[-RM_TILE];
+    double mnew = mold - w1 * tarear;
+    if (mnew < -RM_PUNY) atomicOr(bad, 2u);
+    else if (mnew < 0.0) mnew = 0.0;
+    P.fe(n)[k] = mnew;                                // (copied over mm(n) when the launch is complete)
+    if (n == 0) return;
+    double o1 = 0.0, n1 = 0.0, o2 = 0.0, n2 = 0.0;
+    for (int q0 = 0; q0 < tb.ntrace; q0++) {
+        const int nt = tb.ord[q0], p = (n - 1) * tb.ntrace + nt, ty_ = tb.type[nt];
+        double *tmp = P.tm(p);
+        double v = 0.0, told = 0.0;
+        if (mnew > 0.0) {
+            told = tmp[k];
+            const size_t o = (size_t)(nt + 1) * 256;
+            w1 = FE[o] - FE[o - 1] + FN[o] - FN[o - RM_TILE];
+        }
+        if (ty_ == 1) {
+            if (mnew > 0.0) v = (mold * told - w1 * tarear) / mnew;
+            o1 = told; n1 = v;
+        } else if (ty_ == 2) {
+            if (mnew > 0.0 && fabs(n1) > 0.0) v = (mold * o1 * told - w1 * tarear) / (mnew * n1);
+            o2 = told; n2 = v;
+        } else {
+            if (mnew > 0.0 && fabs(n2) > 0.0 && fabs(n1) > 0.0) v = (mold * o1 * o2 * told - w1 * tarear) / (mnew * n1 * n2);
+        }
+        tmp[k] = v;
+    }
+}
+
 
 // ---- update_fields (:3517-3729): one thread per physical cell, blockIdx.z = category; tracers in dependency order ----
 __global__ void __launch_bounds__(256) k_remap_update(Slab s, RemapTab tb, RemapPlanes P, unsigned *bad) {
