@@ -2534,7 +2534,8 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     const size_t flux_lds = sizeof(double) * 2 * 256 * (size_t)(1 + ntrace);
     static const bool fused_env = !(getenv("EVPK_REMAP_FUSED") && atoi(getenv("EVPK_REMAP_FUSED")) == 0);
     if (fused_env && flux_lds <= 60 * 1024) {
-        hipLaunchKernelGGL(k_remap_fluxupd, dim3((s.nxl + RM_TILE - 2) / (RM_TILE - 1), (s.nyl + RM_TILE - 2) / (RM_TILE - 1), ncp), dim3(256), flux_lds, c->stream,
+        const long long ntiles = (long long)((s.nxl + RM_TILE - 2) / (RM_TILE - 1)) * ((s.nyl + RM_TILE - 2) / (RM_TILE - 1)) * ncp;
+        hipLaunchKernelGGL(k_remap_fluxupd, dim3((unsigned)(((ntiles + 7) / 8) * 8)), dim3(256), flux_lds, c->stream,
                            s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2, c->rm_bad);
         // the new masses were written beside the old ones (plane fe(n)): in place of mm(n) now that every tile is done
         HIPCHK(c, hipMemcpyAsync(c->rm_pool, c->rm_pool + (size_t)3 * ncp * np, sizeof(double) * (size_t)ncp * np, hipMemcpyDeviceToDevice, c->stream));

@@ -517,7 +517,14 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_fluxupd(Slab s, Re
                                                                         unsigned *bad) {
     extern __shared__ double rl[];                    // FE[1 + ntrace][256], FN[1 + ntrace][256]
     const int tx = threadIdx.x & (RM_TILE - 1), ty = threadIdx.x >> 4, tid = threadIdx.x;
-    const int i = blockIdx.x * (RM_TILE - 1) + tx, j = blockIdx.y * (RM_TILE - 1) + ty, n = blockIdx.z;
+    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD takes a contiguous run of tiles,
+    // x fastest, so that tiles running side by side share the cache lines their 16-cell rows straddle and their rims
+    const int nbx = (s.nxl + RM_TILE - 2) / (RM_TILE - 1), nby = (s.nyl + RM_TILE - 2) / (RM_TILE - 1);
+    const int chunk = gridDim.x >> 3;
+    const int t = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (t >= nbx * nby * (tb.ncat + 1)) return;       // (the whole workgroup: nobody waits at the barrier)
+    const int n = t / (nbx * nby), tile = t - n * (nbx * nby);
+    const int i = (tile % nbx) * (RM_TILE - 1) + tx, j = (tile / nbx) * (RM_TILE - 1) + ty;
     const int nf = 1 + tb.ntrace;
     double *const FE = rl + tid, *const FN = rl + (size_t)nf * 256 + tid;
     const bool in = (i <= s.nxl && j <= s.nyl);
