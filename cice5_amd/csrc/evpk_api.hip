@@ -2459,7 +2459,7 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     HIPCHK(c, hipMemcpyAsync(c->rm_sgn, sg.data(), sg.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->rm_bad, 0, sizeof(unsigned), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab, lst, sg are pageable host vectors)
-    RemapPlanes P{(double *const *)c->rm_tab, ncp, ntp, c->rm_pool, np};
+    RemapPlanes P{(double *const *)c->rm_tab, ncp, ntp};
     // the caller's arrays: in place where their memory is visible to the device, else through a staging copy
     const size_t n_mm = (size_t)c->nblocks * ncp * nblk, n_tm = (size_t)c->nblocks * ntp * nblk;
     const dim3 b(64, 4);

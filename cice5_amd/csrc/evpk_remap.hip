@@ -32,24 +32,20 @@ struct RemapTab {
     signed char ord[RM_MAXT];
 };
 // pointer table: [0 .. ncat] mm, then mx, my, fe, fn (ncat+1 each); then per (n-1)*ntrace+nt: tm, tc, tx, ty, tfe, tfn
-// (the planes lie one after the other in one pool, `np` doubles apart: a plane's address is arithmetic, not a load from the table)
 struct RemapPlanes {
     double *const *tab;
     int ncp, ntp;
-    double *pool;
-    size_t np;
-    __device__ double *pl(int q) const { return pool + (size_t)q * np; }
-    __device__ double *mm(int n) const { return pl(n); }
-    __device__ double *mx(int n) const { return pl(ncp + n); }
-    __device__ double *my(int n) const { return pl(2 * ncp + n); }
-    __device__ double *fe(int n) const { return pl(3 * ncp + n); }
-    __device__ double *fn(int n) const { return pl(4 * ncp + n); }
-    __device__ double *tm(int p) const { return pl(5 * ncp + p); }
-    __device__ double *tc(int p) const { return pl(5 * ncp + ntp + p); }
-    __device__ double *tx(int p) const { return pl(5 * ncp + 2 * ntp + p); }
-    __device__ double *ty(int p) const { return pl(5 * ncp + 3 * ntp + p); }
-    __device__ double *tfe(int p) const { return pl(5 * ncp + 4 * ntp + p); }
-    __device__ double *tfn(int p) const { return pl(5 * ncp + 5 * ntp + p); }
+    __device__ double *mm(int n) const { return tab[n]; }
+    __device__ double *mx(int n) const { return tab[ncp + n]; }
+    __device__ double *my(int n) const { return tab[2 * ncp + n]; }
+    __device__ double *fe(int n) const { return tab[3 * ncp + n]; }
+    __device__ double *fn(int n) const { return tab[4 * ncp + n]; }
+    __device__ double *tm(int p) const { return tab[5 * ncp + p]; }
+    __device__ double *tc(int p) const { return tab[5 * ncp + ntp + p]; }
+    __device__ double *tx(int p) const { return tab[5 * ncp + 2 * ntp + p]; }
+    __device__ double *ty(int p) const { return tab[5 * ncp + 3 * ntp + p]; }
+    __device__ double *tfe(int p) const { return tab[5 * ncp + 4 * ntp + p]; }
+    __device__ double *tfn(int p) const { return tab[5 * ncp + 5 * ntp + p]; }
 };
 
 #define RM_PUNY 1.0e-11
@@ -386,23 +382,16 @@ __device__ __forceinline__ void rm_flux_edge(const Slab &s, const RemapTab &tb, 
         rm_edge_triangles<NORTH>(i, j, dxy, dxu[kl] * dyu[kl], dxu[kr] * dyu[kr], tb.order, t);
         const double p5625m = -9.0 / 16.0, p52083 = 25.0 / 48.0, p333 = 1.0 / 3.0;
         const double *mm = P.mm(n), *mxp = P.mx(n), *myp = P.my(n);
-        // (all loads of the six source cells first, from a valid cell whether the triangle exists or not: eighteen independent
-        //  loads in flight instead of six dependent rounds)
-        double mmq[RM_GROUPS], mxq[RM_GROUPS], myq[RM_GROUPS];
 #pragma unroll
         for (int g = 0; g < RM_GROUPS; g++) {
             area[g] = t.area[g];
             k2[g] = (unsigned)mcell(s, i + t.di[g], j + t.dj[g]);
-            mmq[g] = mm[k2[g]]; mxq[g] = mxp[k2[g]]; myq[g] = myp[k2[g]];
-        }
-#pragma unroll
-        for (int g = 0; g < RM_GROUPS; g++) {
             icg[g] = false;
             if (area[g] == 0.0) continue;
-            const double mmv = mmq[g];
+            const double mmv = mm[k2[g]];
             icg[g] = mmv > RM_PUNY;
             anyice = anyice || icg[g];
-            const double mc = mmv > RM_PUNY ? mmv : 0.0, mx = mxq[g], my = myq[g];
+            const double mc = mmv > RM_PUNY ? mmv : 0.0, mx = mxp[k2[g]], my = myp[k2[g]];
             const double *xp = t.xp[g], *yp = t.yp[g];
             double msum, mxsum, mxxsum, mxysum, mysum, myysum;
             if (tb.order == 1) {
@@ -447,30 +436,22 @@ __device__ __forceinline__ void rm_flux_edge(const Slab &s, const RemapTab &tb, 
     double p1s[RM_GROUPS], p1x[RM_GROUPS], p1y[RM_GROUPS], p2s[RM_GROUPS];        // mtsum, mtxsum, mtysum of the last type-1 tracer; mtsum of the last type-2
 #pragma unroll
     for (int g = 0; g < RM_GROUPS; g++) { p1s[g] = 0.0; p1x[g] = 0.0; p1y[g] = 0.0; p2s[g] = 0.0; }
-    // per tracer: the values of the six source cells are loaded FIRST, all of them and unconditionally (from the triangle's cell,
-    // a valid cell whether the triangle exists or not; cells without ice of the category hold whatever an earlier call left:
-    // selected away below, as construct_fields' zeros) -- up to eighteen independent loads in flight instead of six dependent
-    // rounds; then the sums in the reference's order
+    // the three central triangles (groups 4, 5, 6) usually draw on ONE cell (TC or BC): its tc, tx, ty are then loaded once per tracer
+    const bool cen5 = area[3] != 0.0 && area[4] != 0.0 && k2[4] == k2[3], cen6 = area[3] != 0.0 && area[5] != 0.0 && k2[5] == k2[3];
     for (int q0 = 0; q0 < tb.ntrace; q0++) {
         const int nt = tb.ord[q0], p = (n - 1) * tb.ntrace + nt, ty_ = tb.type[nt];
         const double *tcp = P.tc(p), *txp = P.tx(p), *typ = P.ty(p);
         double flx = 0.0;
-        double tcv[RM_GROUPS], txv[RM_GROUPS], tyv[RM_GROUPS];
-#pragma unroll
-        for (int g = 0; g < RM_GROUPS; g++) tcv[g] = tcp[k2[g]];
-        if (ty_ != 3) {
-#pragma unroll
-            for (int g = 0; g < RM_GROUPS; g++) { txv[g] = txp[k2[g]]; tyv[g] = typ[k2[g]]; }
-        } else {
-#pragma unroll
-            for (int g = 0; g < RM_GROUPS; g++) { txv[g] = 0.0; tyv[g] = 0.0; }
-        }
+        double ctc = 0.0, ctx = 0.0, cty = 0.0;                   // of group 4's cell
         if (ty_ == 1) {                                                               // :3449-3468
             const bool keep = tb.has[nt] != 0;
 #pragma unroll
             for (int g = 0; g < RM_GROUPS; g++) {
                 if (area[g] == 0.0) continue;
-                const double tc = icg[g] ? tcv[g] : 0.0, tx = icg[g] ? txv[g] : 0.0, ty = icg[g] ? tyv[g] : 0.0;
+                double tc, tx, ty;
+                if ((g == 4 && cen5) || (g == 5 && cen6)) { tc = ctc; tx = ctx; ty = cty; }
+                else { tc = icg[g] ? tcp[k2[g]] : 0.0; tx = icg[g] ? txp[k2[g]] : 0.0; ty = icg[g] ? typ[k2[g]] : 0.0; }
+                if (g == 3) { ctc = tc; ctx = tx; cty = ty; }
                 const double mts = ms[g][0] * tc + ms[g][1] * tx + ms[g][4] * ty;
                 flx = flx + area[g] * mts;
                 if (keep) {
@@ -483,7 +464,10 @@ __device__ __forceinline__ void rm_flux_edge(const Slab &s, const RemapTab &tb, 
 #pragma unroll
             for (int g = 0; g < RM_GROUPS; g++) {
                 if (area[g] == 0.0) continue;
-                const double tc = icg[g] ? tcv[g] : 0.0, tx = icg[g] ? txv[g] : 0.0, ty = icg[g] ? tyv[g] : 0.0;
+                double tc, tx, ty;
+                if ((g == 4 && cen5) || (g == 5 && cen6)) { tc = ctc; tx = ctx; ty = cty; }
+                else { tc = icg[g] ? tcp[k2[g]] : 0.0; tx = icg[g] ? txp[k2[g]] : 0.0; ty = icg[g] ? typ[k2[g]] : 0.0; }
+                if (g == 3) { ctc = tc; ctx = tx; cty = ty; }
                 const double mts = p1s[g] * tc + p1x[g] * tx + p1y[g] * ty;
                 flx = flx + area[g] * mts;
                 p2s[g] = mts;
@@ -492,7 +476,10 @@ __device__ __forceinline__ void rm_flux_edge(const Slab &s, const RemapTab &tb, 
 #pragma unroll
             for (int g = 0; g < RM_GROUPS; g++) {
                 if (area[g] == 0.0) continue;
-                const double tc = icg[g] ? tcv[g] : 0.0;
+                double tc;
+                if ((g == 4 && cen5) || (g == 5 && cen6)) tc = ctc;
+                else tc = icg[g] ? tcp[k2[g]] : 0.0;
+                if (g == 3) ctc = tc;
                 const double mts = p2s[g] * tc;
                 flx = flx + area[g] * mts;
             }
