@@ -838,6 +838,121 @@ void orc_halo_i4(const orc_geom *g, int32_t *a, int32_t fill) {
 }
 
 /* ---------------------------------------------------------------------------
+ * compute_tracers (source/ice_itd.F90:1359-1501) on ALL cells of one block (work_to_state's list, ice_transport_driver.F90:
+ * 1571-1580): trcrn from the advected products atrcrn = (aicen | vicen | vsnon [* parent tracer]) * trcrn.
+ * trcrn: (ntrcr_dim, ny, nx) planes of this block and category, atr: (ntrcr, ny, nx); nt_* 1-based, 0 = tracer absent.
+ * ------------------------------------------------------------------------- */
+void orc_compute_tracers(int nx, int ny, int ntrcr, const int32_t *trcr_depend, int nt_Tsfc, int nt_alvl, int nt_apnd, int nt_fbri,
+                         int tr_pond_cesm, int tr_pond_lvl, int tr_pond_topo, double Tocnfrz, const double *atr,
+                         const double *aicen, const double *vicen, const double *vsnon, double *trcrn) {
+    const size_t nn = (size_t)nx * ny;
+    for (int it = 1; it <= ntrcr; it++)
+        for (size_t k = 0; k < nn; k++) trcrn[(size_t)(it - 1) * nn + k] = c0;                       /* :1405 */
+    for (int it = 1; it <= ntrcr; it++) {
+        double *t = trcrn + (size_t)(it - 1) * nn;
+        const double *a = atr + (size_t)(it - 1) * nn;
+        const int dep = trcr_depend[it - 1];
+        for (size_t k = 0; k < nn; k++) {
+            if (it == nt_Tsfc) t[k] = aicen[k] > puny ? a[k] / aicen[k] : Tocnfrz;                     /* :1413-1422 */
+            else if (dep == 0) t[k] = aicen[k] > puny ? a[k] / aicen[k] : c0;
+            else if (dep == 1) {
+                if (vicen[k] > c0) t[k] = a[k] / vicen[k];
+                else { t[k] = c0; if (it == nt_fbri) t[k] = c1; }
+            } else if (dep == 2) t[k] = vsnon[k] > c0 ? a[k] / vsnon[k] : c0;
+            else if (nt_alvl > 0 && dep == 2 + nt_alvl) {
+                const double d = trcrn[(size_t)(nt_alvl - 1) * nn + k] * aicen[k];
+                t[k] = d > c0 ? a[k] / d : c0;
+            } else if (nt_apnd > 0 && dep == 2 + nt_apnd && (tr_pond_cesm || tr_pond_topo)) {
+                const double d = trcrn[(size_t)(nt_apnd - 1) * nn + k] * aicen[k];
+                t[k] = d > c0 ? a[k] / d : c0;
+            } else if (nt_apnd > 0 && dep == 2 + nt_apnd && tr_pond_lvl) {
+                const double d = trcrn[(size_t)(nt_alvl - 1) * nn + k] * trcrn[(size_t)(nt_apnd - 1) * nn + k] * aicen[k];
+                t[k] = d > c0 ? a[k] / d : c0;
+            } else if (nt_fbri > 0 && dep == 2 + nt_fbri) {
+                const double d = trcrn[(size_t)(nt_fbri - 1) * nn + k] * vicen[k];
+                t[k] = d > c0 ? a[k] / d : c0;
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * transport_upwind WHOLE (ice_transport_driver.F90:634-772): state_to_work (:1382-1513) -> upwind_field -> work_to_state
+ * (:1520-1609, compute_tracers) -> bound_state (ice_state.F90:173-238).  aice0 (nb, ny, nx), aicen / vicen / vsnon
+ * (nb, ncat, ny, nx), trcrn (nb, ncat, ntrcr_dim, ny, nx), in place, every cell of every block.  Ghost cells current on entry.
+ * state_to_work's pond branch is written `a .and. tr_pond_cesm .or. tr_pond_topo` (:1480-1481): with topo ponds it takes every
+ * tracer that reaches it -- restated as written.
+ * ------------------------------------------------------------------------- */
+void orc_transport_upwind_state(const orc_geom *g, double dt, int ncat, int ntrcr, int ntrcr_dim, const int32_t *trcr_depend,
+                                int nt_Tsfc, int nt_alvl, int nt_apnd, int nt_fbri, int tr_pond_cesm, int tr_pond_lvl, int tr_pond_topo,
+                                double Tocnfrz, const double *uvel, const double *vvel, const double *HTE, const double *HTN,
+                                const double *tarea, double *aice0, double *aicen, double *vicen, double *vsnon, double *trcrn) {
+    const int nx = g->nx_block, ny = g->ny_block, nb = g->nblocks;
+    const size_t nn = (size_t)nx * ny;
+    const int narr = 1 + ncat * (3 + ntrcr);
+    double *works = (double *)calloc((size_t)nb * narr * nn, sizeof(double));
+    for (int b = 0; b < nb; b++) {
+        double *w = works + (size_t)b * narr * nn;
+        memcpy(w, aice0 + (size_t)b * nn, nn * sizeof(double));
+        int na = 1;
+        for (int n = 0; n < ncat; n++) {
+            const double *a = aicen + ((size_t)b * ncat + n) * nn, *v = vicen + ((size_t)b * ncat + n) * nn, *sn = vsnon + ((size_t)b * ncat + n) * nn;
+            const double *t = trcrn + ((size_t)b * ncat + n) * ntrcr_dim * nn;
+            memcpy(w + (size_t)(na + 0) * nn, a, nn * 8); memcpy(w + (size_t)(na + 1) * nn, v, nn * 8); memcpy(w + (size_t)(na + 2) * nn, sn, nn * 8);
+            na += 3;
+            for (int it = 1; it <= ntrcr; it++) {
+                double *o = w + (size_t)(na + it - 1) * nn;
+                const double *ti = t + (size_t)(it - 1) * nn;
+                const int dep = trcr_depend[it - 1];
+                for (size_t k = 0; k < nn; k++) {
+                    if (dep == 0) o[k] = a[k] * ti[k];
+                    else if (dep == 1) o[k] = v[k] * ti[k];
+                    else if (dep == 2) o[k] = sn[k] * ti[k];
+                    else if (nt_alvl > 0 && dep == 2 + nt_alvl) o[k] = a[k] * t[(size_t)(nt_alvl - 1) * nn + k] * ti[k];
+                    else if ((nt_apnd > 0 && dep == 2 + nt_apnd && tr_pond_cesm) || tr_pond_topo) o[k] = a[k] * t[(size_t)(nt_apnd - 1) * nn + k] * ti[k];
+                    else if (nt_apnd > 0 && dep == 2 + nt_apnd && tr_pond_lvl) o[k] = a[k] * t[(size_t)(nt_alvl - 1) * nn + k] * t[(size_t)(nt_apnd - 1) * nn + k] * ti[k];
+                    else if (nt_fbri > 0 && dep == 2 + nt_fbri) o[k] = v[k] * t[(size_t)(nt_fbri - 1) * nn + k] * ti[k];
+                    /* else: works(:,:,narrays+it) is left as allocated (the reference never reads a tracer without a rule back) */
+                }
+            }
+            na += ntrcr;
+        }
+    }
+    orc_transport_upwind(g, dt, narr, uvel, vvel, HTE, HTN, tarea, works);
+    for (int b = 0; b < nb; b++) {
+        const double *w = works + (size_t)b * narr * nn;
+        memcpy(aice0 + (size_t)b * nn, w, nn * sizeof(double));
+        int na = 1;
+        for (int n = 0; n < ncat; n++) {
+            double *a = aicen + ((size_t)b * ncat + n) * nn, *v = vicen + ((size_t)b * ncat + n) * nn, *sn = vsnon + ((size_t)b * ncat + n) * nn;
+            memcpy(a, w + (size_t)(na + 0) * nn, nn * 8); memcpy(v, w + (size_t)(na + 1) * nn, nn * 8); memcpy(sn, w + (size_t)(na + 2) * nn, nn * 8);
+            na += 3;
+            orc_compute_tracers(nx, ny, ntrcr, trcr_depend, nt_Tsfc, nt_alvl, nt_apnd, nt_fbri, tr_pond_cesm, tr_pond_lvl, tr_pond_topo, Tocnfrz,
+                                w + (size_t)na * nn, a, v, sn, trcrn + ((size_t)b * ncat + n) * ntrcr_dim * nn);
+            na += ntrcr;
+        }
+    }
+    free(works);
+    /* bound_state: aicen, trcrn(1:ntrcr), vicen, vsnon -- centre scalars (aice0 has no halo update of its own) */
+    double *pl = (double *)malloc((size_t)nb * nn * sizeof(double));
+    for (int n = 0; n < ncat; n++)
+        for (int q = 0; q < 3 + ntrcr; q++) {
+            for (int b = 0; b < nb; b++) {
+                const double *src = q == 0 ? aicen + ((size_t)b * ncat + n) * nn : q == 1 ? vicen + ((size_t)b * ncat + n) * nn
+                                  : q == 2 ? vsnon + ((size_t)b * ncat + n) * nn : trcrn + (((size_t)b * ncat + n) * ntrcr_dim + (q - 3)) * nn;
+                memcpy(pl + (size_t)b * nn, src, nn * 8);
+            }
+            orc_halo_r8(g, pl, ORC_LOC_CENTER, ORC_KIND_SCALAR, 0.0);
+            for (int b = 0; b < nb; b++) {
+                double *dst = q == 0 ? aicen + ((size_t)b * ncat + n) * nn : q == 1 ? vicen + ((size_t)b * ncat + n) * nn
+                            : q == 2 ? vsnon + ((size_t)b * ncat + n) * nn : trcrn + (((size_t)b * ncat + n) * ntrcr_dim + (q - 3)) * nn;
+                memcpy(dst, pl + (size_t)b * nn, nn * 8);
+            }
+        }
+    free(pl);
+}
+
+/* ---------------------------------------------------------------------------
  * transport_upwind (source/ice_transport_driver.F90:634-772), see evp_oracle.h
  * ------------------------------------------------------------------------- */
 void orc_transport_upwind(const orc_geom *g, double dt, int narr, const double *uvel, const double *vvel,

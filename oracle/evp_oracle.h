@@ -184,6 +184,15 @@ void orc_halo_stress(const orc_geom *g, double *a1, const double *a2);
  * vectors, :703-708), then upwind_field (:1614-1689) on each of the `narr` arrays of `works` (nx_block, ny_block, narr,
  * nblocks) -- what state_to_work (:1382) hands it -- in place on physical cells.  The ghost cells of `works` must be
  * current on entry (bound_state) and are not updated (the reference calls bound_state afterwards, :763). */
+/* the same with the state transforms around it: state_to_work (:1382-1513), work_to_state (:1520-1609) with compute_tracers
+ * (ice_itd.F90:1359-1501), bound_state; see evp_oracle.c */
+void orc_compute_tracers(int nx, int ny, int ntrcr, const int32_t *trcr_depend, int nt_Tsfc, int nt_alvl, int nt_apnd, int nt_fbri,
+                         int tr_pond_cesm, int tr_pond_lvl, int tr_pond_topo, double Tocnfrz, const double *atr,
+                         const double *aicen, const double *vicen, const double *vsnon, double *trcrn);
+void orc_transport_upwind_state(const orc_geom *g, double dt, int ncat, int ntrcr, int ntrcr_dim, const int32_t *trcr_depend,
+                                int nt_Tsfc, int nt_alvl, int nt_apnd, int nt_fbri, int tr_pond_cesm, int tr_pond_lvl, int tr_pond_topo,
+                                double Tocnfrz, const double *uvel, const double *vvel, const double *HTE, const double *HTN,
+                                const double *tarea, double *aice0, double *aicen, double *vicen, double *vsnon, double *trcrn);
 void orc_transport_upwind(const orc_geom *g, double dt, int narr, const double *uvel, const double *vvel,
                           const double *HTE, const double *HTN, const double *tarea, double *works);
 

@@ -13,6 +13,7 @@
 !   ice_strength (asum_ridging, ridge_itd)          source/ice_mechred.F90:2111
 !   create_distribution('cartesian', nprocs > 1)    source/ice_distribution.F90:535
 !   global_minval (scalar, masked)                  serial/ice_global_reductions.F90 (set_evp_parameters' xmin, ymin)
+!   compute_tracers                                 source/ice_itd.F90:1359 (work_to_state of transport_upwind)
 !
 ! Usage:  ref_harness <in.bin> <out.bin>   with the namelist file cice_in.nml (domain_nml) in the working directory.
 ! Both files are native-endian streams of int32 / real64; the layout is the sequence of reads / writes below.
@@ -27,10 +28,11 @@ program ref_harness
    use ice_distribution, only: distrb, create_distribution, processor_shape
    use ice_domain, only: init_domain_blocks, init_domain_distribution, nblocks, blocks_ice, distrb_info, halo_info
    use ice_boundary, only: ice_HaloUpdate, ice_HaloUpdate_stress
-   use ice_state, only: bound_state, ntrcr
+   use ice_state, only: bound_state, ntrcr, nt_Tsfc, nt_alvl, nt_apnd, nt_fbri, tr_pond_cesm, tr_pond_lvl, tr_pond_topo
+   use ice_itd, only: compute_tracers
    use ice_mechred, only: ice_strength, kstrength, krdg_partic, krdg_redist, mu_rdg, Cf
    use ice_global_reductions, only: global_minval
-   use ice_constants, only: field_loc_center
+   use ice_constants, only: field_loc_center, Tocnfrz
 
    implicit none
 
@@ -44,6 +46,9 @@ program ref_harness
    real (dbl_kind), allocatable :: aicen(:,:,:,:), vicen(:,:,:,:), vsnon(:,:,:,:), trcrn(:,:,:,:,:)
    real (dbl_kind), allocatable :: s_aice(:,:), s_vice(:,:), s_aice0(:,:), s_aicen(:,:,:), s_vicen(:,:,:), s_str(:,:)
    logical (log_kind), allocatable :: lmask(:,:,:)
+   integer (int_kind) :: nt, pond(3)
+   integer (int_kind), allocatable :: tdep(:)
+   real (dbl_kind), allocatable :: atr(:,:), c_a(:,:), c_v(:,:), c_s(:,:), c_t(:,:,:)
    type (block) :: b
    type (distrb) :: d
    character (len=16) :: shape
@@ -182,6 +187,26 @@ program ref_harness
          xmin = global_minval(a2, distrb_info, lmask)
          write (uout) xmin
          deallocate (a2, i2, lmask)
+
+      case (8)          ! compute_tracers (ice_itd.F90:1359) on one block: work_to_state's inverse of state_to_work
+         read (uin) nt
+         allocate (tdep(nt))
+         read (uin) tdep
+         read (uin) nt_Tsfc, nt_alvl, nt_apnd, nt_fbri, pond
+         read (uin) Tocnfrz            ! (AusCOM: a namelist variable, drivers/auscom/ice_constants.F90:103)
+         tr_pond_cesm = pond(1) /= 0; tr_pond_lvl = pond(2) /= 0; tr_pond_topo = pond(3) /= 0
+         read (uin) ic
+         allocate (indxi(nx_block*ny_block), indxj(nx_block*ny_block), atr(ic,nt), c_a(nx_block,ny_block), c_v(nx_block,ny_block), &
+                   c_s(nx_block,ny_block), c_t(nx_block,ny_block,nt))
+         read (uin) indxi
+         read (uin) indxj
+         read (uin) atr
+         read (uin) c_a
+         read (uin) c_v
+         read (uin) c_s
+         call compute_tracers(nx_block, ny_block, ic, indxi, indxj, nt, tdep, atr, c_a, c_v, c_s, c_t)
+         write (uout) c_t
+         deallocate (tdep, indxi, indxj, atr, c_a, c_v, c_s, c_t)
 
       case default
          write (*,*) 'ref_harness: unknown op ', op

@@ -109,6 +109,18 @@ def run_case(exe, cfg, ew, ns, land, with_strength):
                 for k in ("aice", "vice", "aice0", "aicen", "vicen"):
                     w.arr(s[k])
                 plan.append((f"strength/{tag}", np.float64, (nyb, nxb)))
+    if with_strength:
+        for tag, (dep, n_tsfc, n_alvl, n_apnd, n_fbri, pond) in rv.TRACER_CASES.items():
+            nt = len(dep)
+            a, v, sn, atr = rv.tracers_input(cfg, tag, nyb, nxb, nt)
+            idx = np.zeros((2, nxb * nyb), dtype=np.int32)
+            jj, ii = np.meshgrid(np.arange(1, nyb + 1), np.arange(1, nxb + 1), indexing="ij")     # work_to_state's list: every cell, i fastest
+            idx[0], idx[1] = ii.ravel(), jj.ravel()
+            w.i4(8, nt); w.arr(np.asarray(dep, dtype=np.int32)); w.i4(n_tsfc, n_alvl, n_apnd, n_fbri, *pond); w.r8(rv.TOCNFRZ); w.i4(nxb * nyb)
+            w.arr(idx[0]); w.arr(idx[1])
+            w.arr(atr.reshape(nt, nyb * nxb))                   # Fortran atrcrn(icells, ntrcr)
+            w.arr(a); w.arr(v); w.arr(sn)
+            plan.append((f"tracers/{tag}", np.float64, (nt, nyb, nxb)))
     # global_minval over the ocean T cells (set_evp_parameters, ice_dyn_shared.F90:221-222)
     dx = 1000.0 * (1.0 + rv.halo_r8_input(cfg, case, "minval", nblocks, nyb, nxb, 0) ** 2)
     msk = (rv.halo_i4_input(cfg, case, "minval_mask", nblocks, nyb, nxb) % 10 > 3).astype(np.int32)

@@ -137,3 +137,27 @@ def strength_input(cfg, tag, ny_block, nx_block):
 STRENGTH_CASES = [(1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0), (0, 1, 1)]       # (kstrength, krdg_partic, krdg_redist)
 MU_RDG, CF = 3.0, 17.0                                                          # ice_init.F90:273-277 defaults
 DISTRIBUTIONS = [(2, "slenderX1"), (4, "slenderX1"), (3, "slenderX1"), (4, "slenderX2"), (8, "slenderX2")]
+
+
+# compute_tracers (ice_itd.F90:1359): tracer tables (trcr_depend, nt_Tsfc, nt_alvl, nt_apnd, nt_fbri, (cesm, lvl, topo))
+# Tsfc, qice, qsno, alvl, vlvl, apnd (on alvl), hpnd (on apnd), fbri, a brine tracer (on fbri)
+TRACER_CASES = {
+    "lvl_ponds": ([0, 1, 2, 0, 1, 2 + 4, 2 + 6, 1, 2 + 8], 1, 4, 6, 8, (0, 1, 0)),
+    "cesm_ponds": ([0, 1, 2, 0, 1, 0, 2 + 6, 1, 2 + 8], 1, 4, 6, 8, (1, 0, 0)),
+    "plain": ([0, 1, 1, 2, 0], 1, 0, 0, 0, (0, 0, 0)),
+}
+TOCNFRZ = -1.8
+
+
+def tracers_input(cfg, tag, ny_block, nx_block, ntrcr):
+    h = lambda k, shape: hash01(shape, seed_of(cfg, "tracers", tag, k))
+    a = h("a", (ny_block, nx_block)); a[a < 0.3] = 0.0; a[(a > 0.3) & (a < 0.35)] = 0.5e-11
+    v = h("v", (ny_block, nx_block)) * 2.0; v[h("v0", (ny_block, nx_block)) < 0.25] = 0.0
+    sn = h("s", (ny_block, nx_block)) * 0.4; sn[h("s0", (ny_block, nx_block)) < 0.3] = 0.0
+    atr = h("atr", (ntrcr, ny_block, nx_block)) * 2.0 - 0.7
+    atr[3] = np.abs(atr[3]) if ntrcr > 3 else 0        # (alvl, apnd, fbri products: positive where there is ice)
+    if ntrcr > 7:
+        atr[5] = np.abs(atr[5]); atr[7] = np.abs(atr[7])
+        atr[5][h("p0", (ny_block, nx_block)) < 0.2] = 0.0
+    c = np.ascontiguousarray
+    return c(a), c(v), c(sn), c(atr)

@@ -225,3 +225,26 @@ def test_global_minval_equals_reference(cfg):
         for n, b in enumerate(d.local_blocks):
             phys[n, b.jlo - 1:b.jhi, b.ilo - 1:b.ihi] = True
         assert dx[msk & phys].min() == float(z[f"{case}/global_minval"])
+
+
+def test_compute_tracers_equals_reference():
+    """orc_compute_tracers == compute_tracers (ice_itd.F90:1359-1501, the arithmetic of work_to_state in transport_upwind):
+    tracers on the area, the ice and snow volumes, on the level-ice / pond / brine fractions; Tsfc takes Tocnfrz and fbri 1
+    where there is no ice, bit for bit."""
+    import ctypes as ct
+    cfg = "g24x16_b24x16"
+    z = load(cfg)
+    nx, ny, bx, by, _ = rv.CONFIGS[cfg]
+    nxb, nyb = bx + 2, by + 2
+    L = orc.lib()
+    for tag, (dep, n_tsfc, n_alvl, n_apnd, n_fbri, pond) in rv.TRACER_CASES.items():
+        nt = len(dep)
+        a, v, sn, atr = rv.tracers_input(cfg, tag, nyb, nxb, nt)
+        want = z[f"cyclic_open/tracers/{tag}"]
+        got = np.full((nt, nyb, nxb), 7.0)
+        dp = np.asarray(dep, dtype=np.int32)
+        L.orc_compute_tracers.argtypes = [ct.c_int] * 3 + [orc.c_i32p] + [ct.c_int] * 7 + [ct.c_double] + [orc.c_f64p] * 5
+        L.orc_compute_tracers(nxb, nyb, nt, orc._p32(dp), n_tsfc, n_alvl, n_apnd, n_fbri, *pond, rv.TOCNFRZ,
+                              orc._p64(atr), orc._p64(a), orc._p64(v), orc._p64(sn), orc._p64(got))
+        assert np.array_equal(got, want), (tag, np.argwhere(got != want)[:5])
+        assert (want[0] == rv.TOCNFRZ).any() and np.abs(want).max() > 1.0
