@@ -299,6 +299,8 @@ struct evpk_ctx {
     double **rm_tab = nullptr;
     signed char *rm_sgn = nullptr;
     unsigned *rm_bad = nullptr;
+    double *uw_pool = nullptr; size_t uw_pool_n = 0;      // evpk_transport_upwind_state: one input + 3 + ntrcr output planes
+    double **uw_tab = nullptr; signed char *uw_sgn = nullptr;
     size_t rm_pool_n = 0, rm_stage_n = 0, rm_tab_n = 0;
     // EAP (kdyn = 2): set by evpk_eap_init -- the subcycle loop then runs stress_eap / stepu / stepa (evpk_eap.hip)
     bool eap = false;
@@ -835,7 +837,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -2321,6 +2323,119 @@ extern "C" int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, doubl
     }
     HIPCHK(c, hipGetLastError());
     if (staged) HIPCHK(c, hipMemcpyAsync(works, c->tp_stage, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return xp_check(c);
+}
+
+static int planes_halo(evpk_ctx *c, double **d_list, const signed char *d_sgn, int n, bool vector);
+
+// ---- transport_upwind with the state transforms (state_to_work, work_to_state + compute_tracers, bound_state) -----------------
+extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrcr, int32_t ntrcr_dim, const int32_t *trcr_depend,
+                                           int32_t nt_Tsfc, int32_t nt_alvl, int32_t nt_apnd, int32_t nt_fbri, int32_t tr_pond_cesm,
+                                           int32_t tr_pond_lvl, int32_t tr_pond_topo, double Tocnfrz, double *aice0, double *aicen, double *vicen,
+                                           double *vsnon, double *trcrn) {
+    if (!c || !aice0 || !aicen || !vicen || !vsnon || ncat < 1 || ntrcr < 0 || ntrcr_dim < ntrcr || (ntrcr > 0 && (!trcrn || !trcr_depend))) return 1;
+    if (!c->uploaded) FAIL(c, "evpk_transport_upwind_state: no velocities on the device (run evp first)");
+    if (!c->have_lengths) FAIL(c, "evpk_transport_upwind_state needs HTN and HTE in evpk_geom");
+    if (ntrcr > UW_MAXT) FAIL(c, "evpk_transport_upwind_state: ntrcr = %d exceeds %d", ntrcr, UW_MAXT);
+    Slab &s = c->s;
+    HIPCHK(c, hipSetDevice(c->device));
+    UpwState u{};
+    u.ncat = ncat; u.ntrcr = ntrcr; u.ntrcr_dim = ntrcr_dim; u.nt_Tsfc = nt_Tsfc; u.nt_fbri = nt_fbri; u.Tocnfrz = Tocnfrz;
+    for (int it = 1; it <= ntrcr; it++) {
+        const int dep = trcr_depend[it - 1], k = it - 1;
+        // state_to_work (:1435-1497), its branches in the reference's order (the pond branch as written: `a .and. cesm .or. topo`)
+        u.base[k] = -1; u.m1[k] = 0; u.m2[k] = 0;
+        if (dep == 0) u.base[k] = 0;
+        else if (dep == 1) u.base[k] = 1;
+        else if (dep == 2) u.base[k] = 2;
+        else if (nt_alvl > 0 && dep == 2 + nt_alvl) { u.base[k] = 0; u.m1[k] = (signed char)nt_alvl; }
+        else if ((nt_apnd > 0 && dep == 2 + nt_apnd && tr_pond_cesm) || tr_pond_topo) {
+            if (nt_apnd < 1) FAIL(c, "evpk_transport_upwind_state: tr_pond_topo without nt_apnd");
+            u.base[k] = 0; u.m1[k] = (signed char)nt_apnd;
+        }
+        else if (nt_apnd > 0 && dep == 2 + nt_apnd && tr_pond_lvl) {
+            if (nt_alvl < 1) FAIL(c, "evpk_transport_upwind_state: tr_pond_lvl without nt_alvl");
+            u.base[k] = 0; u.m1[k] = (signed char)nt_alvl; u.m2[k] = (signed char)nt_apnd;
+        }
+        else if (nt_fbri > 0 && dep == 2 + nt_fbri) { u.base[k] = 1; u.m1[k] = (signed char)nt_fbri; }
+        // compute_tracers (ice_itd.F90:1411-1497)
+        u.rule[k] = -1; u.d1[k] = 0; u.d2[k] = 0;
+        if (it == nt_Tsfc) u.rule[k] = 0;
+        else if (dep == 0) u.rule[k] = 1;
+        else if (dep == 1) u.rule[k] = 2;
+        else if (dep == 2) u.rule[k] = 3;
+        else if (nt_alvl > 0 && dep == 2 + nt_alvl) { u.rule[k] = 4; u.d1[k] = (signed char)nt_alvl; }
+        else if (nt_apnd > 0 && dep == 2 + nt_apnd && (tr_pond_cesm || tr_pond_topo)) { u.rule[k] = 4; u.d1[k] = (signed char)nt_apnd; }
+        else if (nt_apnd > 0 && dep == 2 + nt_apnd && tr_pond_lvl) { u.rule[k] = 5; u.d1[k] = (signed char)nt_alvl; u.d2[k] = (signed char)nt_apnd; }
+        else if (nt_fbri > 0 && dep == 2 + nt_fbri) { u.rule[k] = 6; u.d1[k] = (signed char)nt_fbri; }
+        for (int m : {(int)u.m1[k], (int)u.m2[k], (int)u.d1[k], (int)u.d2[k]})
+            if (m > ntrcr) FAIL(c, "evpk_transport_upwind_state: tracer %d hangs on tracer %d, beyond ntrcr", it, m);
+    }
+    const size_t np = mask_elems(s), nblk = (size_t)c->nyb * c->nxb, nb = (size_t)c->nblocks;
+    const int nq = 3 + ntrcr;
+    // planes: one input plane, nq output planes of a category
+    if (c->uw_pool_n < (size_t)(nq + 1) * np) {
+        if (c->uw_pool) (void)hipFree(c->uw_pool);
+        c->uw_pool = nullptr; c->uw_pool_n = 0;
+        HIPCHK(c, hipMalloc(&c->uw_pool, sizeof(double) * (size_t)(nq + 1) * np));
+        c->uw_pool_n = (size_t)(nq + 1) * np;
+        HIPCHK(c, hipMemsetAsync(c->uw_pool, 0, sizeof(double) * (size_t)(nq + 1) * np, c->stream));
+    }
+    if (!c->uw_tab) { HIPCHK(c, hipMalloc(&c->uw_tab, sizeof(double *) * (UW_MAXT + 4))); HIPCHK(c, hipMalloc(&c->uw_sgn, UW_MAXT + 4)); }
+    std::vector<double *> tab(nq);
+    for (int q = 0; q < nq; q++) tab[q] = c->uw_pool + (size_t)(q + 1) * np;
+    std::vector<signed char> sg(nq, 1);
+    HIPCHK(c, hipMemcpyAsync(c->uw_tab, tab.data(), sizeof(double *) * nq, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->uw_sgn, sg.data(), nq, hipMemcpyHostToDevice, c->stream));
+    // the caller's arrays: in place where the device sees them, else through a staging copy
+    double *host5[5] = {aice0, aicen, vicen, vsnon, trcrn};
+    const size_t n5[5] = {nb * nblk, nb * ncat * nblk, nb * ncat * nblk, nb * ncat * nblk, ntrcr ? nb * ncat * ntrcr_dim * nblk : 0};
+    double *dev5[5];
+    bool staged[5];
+    size_t need = 0;
+    for (int q = 0; q < 5; q++) {
+        dev5[q] = (host5[q] && n5[q]) ? (double *)mapped_alias(host5[q]) : nullptr;
+        staged[q] = host5[q] && n5[q] && !dev5[q];
+        if (staged[q]) need += n5[q];
+    }
+    if (need) {
+        if (c->rm_stage_n < need) {
+            if (c->rm_stage) (void)hipFree(c->rm_stage);
+            c->rm_stage = nullptr; c->rm_stage_n = 0;
+            HIPCHK(c, hipMalloc(&c->rm_stage, sizeof(double) * need));
+            c->rm_stage_n = need;
+        }
+        double *q2 = c->rm_stage;
+        for (int q = 0; q < 5; q++)
+            if (staged[q]) { HIPCHK(c, hipMemcpyAsync(q2, host5[q], sizeof(double) * n5[q], hipMemcpyHostToDevice, c->stream)); dev5[q] = q2; q2 += n5[q]; }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab, sg are pageable host vectors)
+    u.aicen = dev5[1]; u.vicen = dev5[2]; u.vsnon = dev5[3]; u.trcrn = dev5[4];
+    // edge velocities and their halo updates (:688-708), as evpk_transport_upwind
+    const dim3 g2 = grid2d(s, B2D);
+    const int SB = c->cur ? F_STATE1 : F_STATE0;
+    hipLaunchKernelGGL(k_edge_vel, g2, B2D, 0, c->stream, s, SB, (int)F_SIG1, (int)F_SIG2);
+    if (halo(c, F_SIG1, 1, false, true, 0.0, -1, nullptr, false, -1, 0, 2)) return 1;
+    if (halo(c, F_SIG2, 1, false, true, 0.0, -1, nullptr, false, -1, 0, 3)) return 1;
+    const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks), gu((s.nxl + 63) / 64, (s.nyl + 3) / 4);
+    double *pin = c->uw_pool;
+    // aice0: physical cells only (no halo update in the reference)
+    hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dev5[0], nblk, pin);
+    hipLaunchKernelGGL(k_upwind, gu, B2D, 0, c->stream, s, dt, (int)F_SIG1, (int)F_SIG2, (const double *)pin, tab[0]);
+    hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)tab[0], dev5[0], nblk);
+    for (int n = 0; n < ncat; n++) {
+        for (int q = 0; q < nq; q++) {
+            hipLaunchKernelGGL(k_upw_gather, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, q, pin);
+            hipLaunchKernelGGL(k_upwind, gu, B2D, 0, c->stream, s, dt, (int)F_SIG1, (int)F_SIG2, (const double *)pin, tab[q]);
+        }
+        if (planes_halo(c, c->uw_tab, c->uw_sgn, nq, false)) return 1;             // bound_state
+        hipLaunchKernelGGL(k_upw_scatter, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, (double *const *)c->uw_tab,
+                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0);
+    }
+    HIPCHK(c, hipGetLastError());
+    for (int q = 0; q < 5; q++)
+        if (staged[q]) HIPCHK(c, hipMemcpyAsync(host5[q], dev5[q], sizeof(double) * n5[q], hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return xp_check(c);
 }

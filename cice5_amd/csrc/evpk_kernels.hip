@@ -2322,6 +2322,98 @@ __global__ void k_upwind(Slab s, double dt, int fu, int fv, const double *phi, d
 }
 
 // physical cells of a plain plane -> one (nx_block, ny_block) slice per block, blocks `bstride` doubles apart
+// ---- transport_upwind with its state transforms (ice_transport_driver.F90:634-772): state_to_work (:1382-1513) inside the
+// gather, work_to_state (:1520-1609) with compute_tracers (ice_itd.F90:1359-1501) and bound_state inside the scatter ----
+constexpr int UW_MAXT = 32;
+struct UpwState {
+    double *aicen, *vicen, *vsnon, *trcrn;      // block arrays (nb, ncat, ny, nx) x 3, (nb, ncat, ntrcr_dim, ny, nx)
+    int ncat, ntrcr, ntrcr_dim;
+    int nt_Tsfc, nt_fbri;                       // 1-based, 0 = absent
+    // per tracer: works = base * trcrn(m1) * trcrn(m2) * trcrn(it) in this order (base 0 aicen, 1 vicen, 2 vsnon, -1: no rule --
+    // the reference leaves works as allocated and compute_tracers returns 0); m1, m2 1-based tracers or 0
+    signed char base[UW_MAXT], m1[UW_MAXT], m2[UW_MAXT];
+    // compute_tracers: rule 0 Tsfc, 1 area, 2 ice volume, 3 snow volume, 4 d = trcrn(d1) * aicen, 5 d = trcrn(d1) * trcrn(d2) * aicen,
+    // 6 d = trcrn(d1) * vicen, -1 none
+    signed char rule[UW_MAXT], d1[UW_MAXT], d2[UW_MAXT];
+    double Tocnfrz;
+};
+
+// q = 0, 1, 2: aicen, vicen, vsnon of category n; q = 3 + it - 1: the product of tracer it
+__global__ void k_upw_gather(Slab s, const BlockDesc *bd, int nxb, int nyb, UpwState u, int n, int q, double *dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
+    const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
+    if (!gather_take(s, d, i, j, si, sj)) return;
+    const size_t nn = (size_t)nyb * nxb, o = (size_t)(j - 1) * nxb + (i - 1), bc = ((size_t)b * u.ncat + n) * nn + o;
+    double v;
+    if (q < 3) v = (q == 0 ? u.aicen : q == 1 ? u.vicen : u.vsnon)[bc];
+    else {
+        const int it = q - 3;                                       // 0-based tracer
+        const double *t = u.trcrn + ((size_t)b * u.ncat + n) * u.ntrcr_dim * nn + o;
+        const int bs = u.base[it];
+        if (bs < 0) v = 0.0;
+        else {
+            v = (bs == 0 ? u.aicen : bs == 1 ? u.vicen : u.vsnon)[bc];
+            if (u.m1[it]) v = v * t[(size_t)(u.m1[it] - 1) * nn];
+            if (u.m2[it]) v = v * t[(size_t)(u.m2[it] - 1) * nn];
+            v = v * t[(size_t)it * nn];
+        }
+    }
+    dst[mcell(s, si, sj)] = v;
+}
+
+// planes[0..2] = the new aicen, vicen, vsnon of category n, planes[3 + it - 1] = the new products; ghost ring halo-updated.
+// Every cell of every block with a source is written (physical cells: work_to_state; ghost cells: bound_state, whose values are
+// the neighbour's -- the same arithmetic on the same numbers); a ghost cell without one gets bound_state's fill (0) on the
+// outermost row / column of the array and keeps the caller's value elsewhere (as k_scatter_halo).
+__global__ void k_upw_scatter(Slab s, const BlockDesc *bd, int nxb, int nyb, UpwState u, int n, double *const *planes, int cyclic, int tripole) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    const size_t nn = (size_t)nyb * nxb, o = (size_t)(j - 1) * nxb + (i - 1), bc = ((size_t)b * u.ncat + n) * nn + o;
+    double *t = u.trcrn + ((size_t)b * u.ncat + n) * u.ntrcr_dim * nn + o;
+    const bool edge = (i == 1 || i == nxb || j == 1 || j == nyb);
+    const bool phys = (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1, sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    const int gi = s.i0 + si - 1, gj = s.j0 + sj - 1;
+    const bool padding = (i > d.ihi + 1 || j > d.jhi + 1);
+    const bool has_src = phys || (!padding && ((gi >= 1 && gi <= s.nxg) || cyclic) && ((gj >= 1 && gj <= s.nyg) || (tripole && gj == s.nyg + 1)));
+    if (!has_src) {
+        if (edge) {
+            u.aicen[bc] = 0.0; u.vicen[bc] = 0.0; u.vsnon[bc] = 0.0;
+            for (int it = 0; it < u.ntrcr; it++) t[(size_t)it * nn] = 0.0;
+        }
+        return;
+    }
+    const size_t km = mcell(s, si, sj);
+    const double a = planes[0][km], v = planes[1][km], sn = planes[2][km];
+    u.aicen[bc] = a; u.vicen[bc] = v; u.vsnon[bc] = sn;
+    const double puny = 1.0e-11;
+    for (int it = 0; it < u.ntrcr; it++) t[(size_t)it * nn] = 0.0;                   // trcrn(:,:,:) = c0 (ice_itd.F90:1405)
+    for (int it = 0; it < u.ntrcr; it++) {
+        const double at = planes[3 + it][km];
+        double r = 0.0;
+        switch (u.rule[it]) {
+        case 0: r = a > puny ? at / a : u.Tocnfrz; break;
+        case 1: r = a > puny ? at / a : 0.0; break;
+        case 2: r = v > 0.0 ? at / v : ((it + 1 == u.nt_fbri) ? 1.0 : 0.0); break;
+        case 3: r = sn > 0.0 ? at / sn : 0.0; break;
+        case 4: { const double dd = t[(size_t)(u.d1[it] - 1) * nn] * a; r = dd > 0.0 ? at / dd : 0.0; } break;
+        case 5: { const double dd = t[(size_t)(u.d1[it] - 1) * nn] * t[(size_t)(u.d2[it] - 1) * nn] * a; r = dd > 0.0 ? at / dd : 0.0; } break;
+        case 6: { const double dd = t[(size_t)(u.d1[it] - 1) * nn] * v; r = dd > 0.0 ? at / dd : 0.0; } break;
+        default: r = 0.0;
+        }
+        t[(size_t)it * nn] = r;
+    }
+}
+
 __global__ void k_scatter_plane(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, double *dst, size_t bstride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y + 1;

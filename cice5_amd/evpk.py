@@ -90,7 +90,8 @@ EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "
            "evpk_last_error", "evpk_slab_layout", "evpk_calibrate", "evpk_principal_stress", "evpk_pin_host",
            "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
            "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap", "evpk_transport_remap_state",
-           "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download", "evpk_halo_update", "evpk_halo_update_stress"]
+           "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download", "evpk_halo_update", "evpk_halo_update_stress",
+           "evpk_transport_upwind_state"]
 
 REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS = 11, 12        # include/evpk.h
 
@@ -132,6 +133,7 @@ def lib():
         L.evpk_connect.argtypes = [ctxp, ct.c_void_p]
         L.evpk_device_check.argtypes = [ct.c_int32]
         L.evpk_transport_upwind.argtypes = [ctxp, ct.c_double, ct.c_int32, c_f64p]
+        L.evpk_transport_upwind_state.argtypes = ([ctxp, ct.c_double] + [ct.c_int32] * 3 + [c_i32p] + [ct.c_int32] * 7 + [ct.c_double] + [c_f64p] * 5)
         L.evpk_halo_update.argtypes = [ctxp, c_f64p, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double]
         L.evpk_halo_update_stress.argtypes = [ctxp, c_f64p, c_f64p]
         L.evpk_remap_init.argtypes = [ctxp, c_f64p, c_f64p, c_f64p]
@@ -314,6 +316,14 @@ class Context:
         """evpk_transport_upwind: works is (nblocks, narr, ny_block, nx_block), advected in place"""
         assert works.ndim == 4
         self._chk(self._L.evpk_transport_upwind(self._ctx, float(dt), int(works.shape[1]), _p64(works)), "evpk_transport_upwind")
+
+    def transport_upwind_state(self, dt: float, aice0, aicen, vicen, vsnon, trcrn, ntrcr: int, trcr_depend, nt_Tsfc=1, nt_alvl=0, nt_apnd=0,
+                               nt_fbri=0, ponds=(0, 0, 0), Tocnfrz=-1.8):
+        """evpk_transport_upwind_state: aice0 (nb, ny, nx), aicen / vicen / vsnon (nb, ncat, ny, nx), trcrn (nb, ncat, ntrcr_dim, ny, nx), in place"""
+        dep = np.ascontiguousarray(trcr_depend, dtype=np.int32)
+        self._chk(self._L.evpk_transport_upwind_state(self._ctx, float(dt), int(aicen.shape[1]), int(ntrcr), int(trcrn.shape[2]), _p32(dep),
+                                                      int(nt_Tsfc), int(nt_alvl), int(nt_apnd), int(nt_fbri), *[int(p) for p in ponds], float(Tocnfrz),
+                                                      _p64(aice0), _p64(aicen), _p64(vicen), _p64(vsnon), _p64(trcrn)), "evpk_transport_upwind_state")
 
     def remap_init(self, dxu: np.ndarray, dyu: np.ndarray, hm: np.ndarray):
         """evpk_remap_init: the grid arrays of horizontal_remap beyond the geometry's (block arrays)"""

@@ -99,7 +99,7 @@
                 evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
                 evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
                 evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read, &
-                evpk_halo_update, evpk_halo_update_stress, &
+                evpk_halo_update, evpk_halo_update_stress, evpk_transport_upwind_state, &
                 evpk_transport_upwind, evpk_remap_init, evpk_transport_remap, evpk_transport_remap_state, &
                 EVPK_REMAP_BAD_DEPARTURE, EVPK_REMAP_NEGATIVE_MASS, &
                 evpk_eap_state, evpk_eap_init, evpk_eap_upload, evpk_eap_download
@@ -215,6 +215,15 @@
             real (c_double), value :: dt
             integer (c_int32_t), value :: narr
             type (c_ptr), value :: works
+         end function
+         ! transport_upwind whole (state_to_work, upwind_field, work_to_state, bound_state; include/evpk.h)
+         integer (c_int) function evpk_transport_upwind_state (ctx, dt, ncat, ntrcr, ntrcr_dim, trcr_depend, nt_Tsfc, nt_alvl, nt_apnd, &
+               nt_fbri, tr_pond_cesm, tr_pond_lvl, tr_pond_topo, Tocnfrz, aice0, aicen, vicen, vsnon, trcrn) &
+               bind(C, name='evpk_transport_upwind_state')
+            import :: c_int, c_ptr, c_double, c_int32_t
+            type (c_ptr), value :: ctx, trcr_depend, aice0, aicen, vicen, vsnon, trcrn
+            real (c_double), value :: dt, Tocnfrz
+            integer (c_int32_t), value :: ncat, ntrcr, ntrcr_dim, nt_Tsfc, nt_alvl, nt_apnd, nt_fbri, tr_pond_cesm, tr_pond_lvl, tr_pond_topo
          end function
          ! horizontal_remap (ice_transport_remap.F90:309-850) on the resident velocities: dxu, dyu, hm once, then
          ! mm(nx_block,ny_block,0:ncat,max_blocks), tm(nx_block,ny_block,ntrace,ncat,max_blocks) advanced in place

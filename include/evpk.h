@@ -224,6 +224,20 @@ int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2);
  * compute_tracers stay with the host's tracer bookkeeping.  Needs HTN and HTE in evpk_geom. */
 int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, double *works);
 
+/* transport_upwind WHOLE (ice_transport_driver.F90:634-772): state_to_work (:1382-1513) inside the gather, upwind_field on the
+ * device, work_to_state (:1520-1609) with compute_tracers (ice_itd.F90:1359-1501) and bound_state (ice_state.F90:173-238) inside
+ * the scatter -- the caller hands over its state arrays as they are:
+ *   aice0 (nx_block, ny_block, max_blocks), aicen, vicen, vsnon (nx_block, ny_block, ncat, max_blocks),
+ *   trcrn (nx_block, ny_block, ntrcr_dim, ncat, max_blocks) of which tracers 1 .. ntrcr are in use
+ *   trcr_depend (ntrcr): 0 area, 1 ice volume, 2 snow volume, 2 + nt: tracer nt (ice_state.F90); nt_Tsfc, nt_alvl, nt_apnd,
+ *   nt_fbri: 1-based tracer indices, 0 = not in use; tr_pond_cesm / lvl / topo: the pond scheme flags; Tocnfrz (ice_constants)
+ * In / out, every cell of every block: physical cells advected, ghost cells their neighbours' new values (bound_state; aice0 has
+ * no halo update in the reference and keeps its ghost cells).  Ghost cells must be current on entry.  Up to 32 tracers. */
+int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrcr, int32_t ntrcr_dim, const int32_t *trcr_depend,
+                                int32_t nt_Tsfc, int32_t nt_alvl, int32_t nt_apnd, int32_t nt_fbri, int32_t tr_pond_cesm,
+                                int32_t tr_pond_lvl, int32_t tr_pond_topo, double Tocnfrz, double *aice0, double *aicen, double *vicen,
+                                double *vsnon, double *trcrn);
+
 /* SURVEY S8 row f-3, second step: horizontal_remap (source/ice_transport_remap.F90:309-850), the incremental remapping of
  * transport_remap (ice_transport_driver.F90:258-626), on the velocities the last evp left on the device.
  *

@@ -259,6 +259,19 @@ def transport_upwind(d, dt: float, f: Dict[str, np.ndarray], works: np.ndarray):
     del keep
 
 
+def transport_upwind_state(d, dt: float, f: Dict[str, np.ndarray], aice0, aicen, vicen, vsnon, trcrn, ntrcr: int, trcr_depend, nt_Tsfc=1, nt_alvl=0,
+                           nt_apnd=0, nt_fbri=0, ponds=(0, 0, 0), Tocnfrz=-1.8):
+    """orc_transport_upwind_state: transport_upwind whole (state_to_work, upwind_field, work_to_state, bound_state), in place"""
+    g, keep = make_geom(d)
+    L = lib()
+    L.orc_transport_upwind_state.argtypes = ([ct.POINTER(OrcGeom), ct.c_double] + [ct.c_int] * 3 + [c_i32p] + [ct.c_int] * 7 + [ct.c_double] + [c_f64p] * 10)
+    dep = np.ascontiguousarray(trcr_depend, dtype=np.int32)
+    L.orc_transport_upwind_state(ct.byref(g), float(dt), int(aicen.shape[1]), int(ntrcr), int(trcrn.shape[2]), _p32(dep), int(nt_Tsfc), int(nt_alvl),
+                                 int(nt_apnd), int(nt_fbri), *[int(p) for p in ponds], float(Tocnfrz), _p64(f["uvel"]), _p64(f["vvel"]),
+                                 _p64(f["HTE"]), _p64(f["HTN"]), _p64(f["tarea"]), _p64(aice0), _p64(aicen), _p64(vicen), _p64(vsnon), _p64(trcrn))
+    del keep
+
+
 def remap_tables(trcr_depend):
     """tracer_type / depend / has_dependents of init_transport (ice_transport_driver.F90:88-125) for hice, hsno and the
     tracers whose `trcr_depend` (0 area, 1 ice volume, 2 snow volume, 2 + nt: tracer nt) is given"""

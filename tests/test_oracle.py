@@ -433,6 +433,42 @@ def test_eap_tables_and_one_step():
         assert np.array_equal(a, out[(12, 10)][n]), n
 
 
+def test_transport_upwind_state_conserves():
+    """orc_transport_upwind_state: the advected quantities of state_to_work (area, volumes, area / volume x tracer) are conserved
+    by upwind_field on a periodic domain without land, nothing moves without velocity except last-bit round trips, Tsfc of a
+    cell that lost its ice is Tocnfrz"""
+    from tests.golden import refvec as rv
+    case, d, f = util.make_case(48, 40, 24, 20, land="rows")
+    synth.add_thickness_distribution(f)
+    I, J = blocks.block_index_windows(d)
+    for b in range(d.nblocks):
+        x, y = 2 * np.pi * ((I[b] - 1) % 48 + 1)[None, :] / 48, np.pi * J[b][:, None] / 40
+        f["uvel"][b] = 0.3 * np.sin(2 * x) * np.cos(y) * (np.sin(y) ** 2)
+        f["vvel"][b] = 0.0 * x * y
+    orc.halo_r8(d, f["uvel"], C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+    dep, n_tsfc, n_alvl, n_apnd, n_fbri, pond = rv.TRACER_CASES["plain"]
+    ntrcr = len(dep)
+    aicen = np.ascontiguousarray(f["aicen"]); vicen = np.ascontiguousarray(f["vicen"]); vsnon = 0.2 * vicen
+    trcrn = np.zeros((d.nblocks, aicen.shape[1], ntrcr + 1) + aicen.shape[2:])
+    for it in range(ntrcr):
+        trcrn[:, :, it] = np.where(aicen > 0, -3.0 - it + np.sin(40 * aicen), 0.0)
+    trcrn[:, :, ntrcr] = 55.0
+    aice0 = 1.0 - aicen.sum(axis=1)
+    phys = util.cell_mask(d, "phys")
+    area = f["tarea"]
+    tot0 = [(aicen[:, n] * area)[phys].sum() for n in range(aicen.shape[1])]
+    q0 = (vicen[:, 0] * trcrn[:, 0, 1] * area)[phys].sum()
+    st = [aice0, aicen, vicen, vsnon, trcrn]
+    s1 = [a.copy() for a in st]
+    orc.transport_upwind_state(d, 1800.0, f, *s1, ntrcr, dep, n_tsfc, n_alvl, n_apnd, n_fbri, pond, rv.TOCNFRZ)
+    for n in range(aicen.shape[1]):
+        assert abs((s1[1][:, n] * area)[phys].sum() - tot0[n]) <= 1e-12 * abs(tot0[n]) + 1e-3
+    assert abs((s1[2][:, 0] * s1[4][:, 0, 1] * area)[phys].sum() - q0) <= 1e-11 * abs(q0)
+    assert np.abs(s1[1] - aicen).max() > 1e-4 and (s1[4][:, :, ntrcr] == 55.0).all()
+    gone = phys[:, None] & (s1[1] <= 1e-11)
+    assert (s1[4][:, :, 0][gone] == rv.TOCNFRZ).all()
+
+
 EAP_LIBM_REPORT = {}
 
 

@@ -821,6 +821,60 @@ def test_transport_upwind_on_the_resident_velocities(ns, bs):
     assert np.array_equal(wg, wo)                                       # physical cells advected alike, ghost cells untouched by both
 
 
+def _upwind_state(d, f, ntrcr_dim, tag):
+    """aice0, aicen, vicen, vsnon, trcrn for transport_upwind with every tracer rule of state_to_work / compute_tracers:
+    Tsfc, qice (ice volume), qsno (snow volume), alvl, vlvl, apnd (on alvl), hpnd (on apnd), fbri, a brine tracer; ghost cells current"""
+    from tests.golden import refvec as rv
+    dep, n_tsfc, n_alvl, n_apnd, n_fbri, pond = rv.TRACER_CASES[tag]
+    ntrcr = len(dep)
+    synth.add_thickness_distribution(f)
+    aicen = np.ascontiguousarray(f["aicen"]); vicen = np.ascontiguousarray(f["vicen"])
+    ncat = aicen.shape[1]
+    vsnon = 0.2 * vicen
+    vsnon[:, 1] = 0.0                                                    # a category without snow
+    trcrn = np.zeros((d.nblocks, ncat, ntrcr_dim) + aicen.shape[2:])
+    for n in range(ncat):
+        for it in range(ntrcr):
+            base = (-5.0 - n - 0.3 * it) if it < 3 else (0.2 + 0.1 * it + 0.05 * n)        # fractions for alvl / apnd / fbri, their dependents
+            trcrn[:, n, it] = np.where(aicen[:, n] > 0, base * (1.0 + 0.05 * np.sin(aicen[:, n] * 40.0 + it)), 0.0)
+        trcrn[:, n, ntrcr:] = 777.0
+    aice0 = np.where(f["tmask"] > 0, 1.0 - aicen.sum(axis=1), 0.0)
+    for arr in (aicen, vicen, vsnon, trcrn.reshape(d.nblocks, -1, *aicen.shape[2:])):
+        for k in range(arr.shape[1]):
+            w = np.ascontiguousarray(arr[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); arr[:, k] = w
+    orc.halo_r8(d, aice0, C.LOC_CENTER, C.KIND_SCALAR, 0.0)
+    return [aice0, aicen, vicen, vsnon, trcrn], dict(ntrcr=ntrcr, trcr_depend=dep, nt_Tsfc=n_tsfc, nt_alvl=n_alvl, nt_apnd=n_apnd, nt_fbri=n_fbri, ponds=pond)
+
+
+@pytest.mark.parametrize("ns,bs,tag", [("open", (100, 116), "lvl_ponds"), ("open", (25, 29), "cesm_ponds"), ("tripole", (24, 32), "lvl_ponds"),
+                                       ("tripole", (96, 64), "plain"), ("open", (32, 40), "plain")])
+def test_transport_upwind_with_the_state_transforms(ns, bs, tag):
+    """transport_upwind WHOLE (ice_transport_driver.F90:634-772): state_to_work inside the gather, upwind_field, work_to_state
+    with compute_tracers and bound_state inside the scatter -- the caller's aice0, aicen, vicen, vsnon, trcrn in, the same arrays
+    out, every cell of every block against the oracle (whose compute_tracers is pinned by the reference's own,
+    tests/test_ref_pins.py), after a real evp; all tracer rules; padded blocks; tracer slots beyond ntrcr untouched."""
+    nx, ny = (100, 116) if ns == "open" else (96, 64)
+    case, d, f = util.make_case(nx, ny, *bs, ns=ns, land="continents")
+    xmin = synth.global_min_dx(case)
+    state, kw = _upwind_state(d, f, 11, tag)
+    fo, fg = util.clone(f), util.clone(f)
+    orc.evp(d, orc.make_params(3600.0, 30, xmin), fo)
+    s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    so, sg = [a.copy() for a in state], [a.copy() for a in state]
+    orc.transport_upwind_state(d, 3600.0, fo, *so, **kw)
+    s.ctx.transport_upwind_state(3600.0, *sg, **kw)
+    s.close()
+    every = util.cell_mask(d, "all")
+    for name, a, b_, a0 in zip(("aice0", "aicen", "vicen", "vsnon", "trcrn"), sg, so, state):
+        m = every if a.ndim == 3 else (every[:, None] if a.ndim == 4 else every[:, None, None])
+        m = np.broadcast_to(m, a.shape)
+        assert np.array_equal(a[m], b_[m]), (name, int((a[m] != b_[m]).sum()), np.argwhere((a != b_) & m)[:4])
+        assert np.abs(b_ - a0).max() > 0
+    assert np.array_equal(sg[4][:, :, kw["ntrcr"]:], state[4][:, :, kw["ntrcr"]:])
+
+
 def _remap_on_device(d, f, mm, tm, tables, dt, order, midpt, env=None, monkeypatch=None):
     """horizontal_remap through the C ABI on synthetic velocities uploaded as the resident state"""
     ttype, depend, has = tables
