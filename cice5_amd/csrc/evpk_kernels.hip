@@ -2385,20 +2385,37 @@ __global__ void k_upw_scatter(Slab s, const BlockDesc *bd, int nxb, int nyb, Upw
     const int gi = s.i0 + si - 1, gj = s.j0 + sj - 1;
     const bool padding = (i > d.ihi + 1 || j > d.jhi + 1);
     const bool has_src = phys || (!padding && ((gi >= 1 && gi <= s.nxg) || cyclic) && ((gj >= 1 && gj <= s.nyg) || (tripole && gj == s.nyg + 1)));
-    if (!has_src) {
-        if (edge) {
-            u.aicen[bc] = 0.0; u.vicen[bc] = 0.0; u.vsnon[bc] = 0.0;
-            for (int it = 0; it < u.ntrcr; it++) t[(size_t)it * nn] = 0.0;
-        }
+    if (!has_src && edge) {                             // bound_state's fill on the outermost row / column
+        u.aicen[bc] = 0.0; u.vicen[bc] = 0.0; u.vsnon[bc] = 0.0;
+        for (int it = 0; it < u.ntrcr; it++) t[(size_t)it * nn] = 0.0;
         return;
     }
-    const size_t km = mcell(s, si, sj);
-    const double a = planes[0][km], v = planes[1][km], sn = planes[2][km];
+    // a cell nothing reaches (padding, a ghost cell beyond an open / closed boundary inside the array): upwind_field leaves its
+    // works alone, so work_to_state hands back compute_tracers(state_to_work(old values)) -- evaluated here from the cell itself
+    double a, v, sn, atl[UW_MAXT];
+    if (has_src) {
+        const size_t km = mcell(s, si, sj);
+        a = planes[0][km]; v = planes[1][km]; sn = planes[2][km];
+        for (int it = 0; it < u.ntrcr; it++) atl[it] = planes[3 + it][km];
+    } else {
+        a = u.aicen[bc]; v = u.vicen[bc]; sn = u.vsnon[bc];
+        for (int it = 0; it < u.ntrcr; it++) {
+            const int bs = u.base[it];
+            double w = 0.0;
+            if (bs >= 0) {
+                w = bs == 0 ? a : bs == 1 ? v : sn;
+                if (u.m1[it]) w = w * t[(size_t)(u.m1[it] - 1) * nn];
+                if (u.m2[it]) w = w * t[(size_t)(u.m2[it] - 1) * nn];
+                w = w * t[(size_t)it * nn];
+            }
+            atl[it] = w;
+        }
+    }
     u.aicen[bc] = a; u.vicen[bc] = v; u.vsnon[bc] = sn;
     const double puny = 1.0e-11;
     for (int it = 0; it < u.ntrcr; it++) t[(size_t)it * nn] = 0.0;                   // trcrn(:,:,:) = c0 (ice_itd.F90:1405)
     for (int it = 0; it < u.ntrcr; it++) {
-        const double at = planes[3 + it][km];
+        const double at = atl[it];
         double r = 0.0;
         switch (u.rule[it]) {
         case 0: r = a > puny ? at / a : u.Tocnfrz; break;
