@@ -122,6 +122,19 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
                 bad.append(("transport_upwind", int((wl != w1[loc]).sum())))
             if not np.abs(w1[loc] - np.stack(planes, axis=1)[loc]).max() > 0:
                 bad.append(("transport_upwind did nothing", 0))
+        if env.get("TEST_UPWIND_STATE"):
+            # transport_upwind whole: bound_state's ghost cells of the new state come through the exchange machinery
+            from tests.test_parity_gpu import _upwind_state
+            st1, kw = _upwind_state(d1, f1, 11, "lvl_ponds")
+            loc = [next(k for k, bb in enumerate(d1.local_blocks) if bb.block_id == b.block_id) for b in d.local_blocks]
+            stl = [np.ascontiguousarray(a[loc]) for a in st1]
+            orc.transport_upwind_state(d1, 3600.0, f1, *st1, **kw)
+            s.ctx.transport_upwind_state(3600.0, *stl, **kw)
+            every = util.cell_mask(d, "all")
+            for name, a, r in zip(("aice0", "aicen", "vicen", "vsnon", "trcrn"), stl, st1):
+                m = np.broadcast_to(every if a.ndim == 3 else (every[:, None] if a.ndim == 4 else every[:, None, None]), a.shape)
+                if not np.array_equal(a[m], r[loc][m]):
+                    bad.append(("transport_upwind_state " + name, int((a[m] != r[loc][m]).sum())))
         if env.get("TEST_REMAP"):
             # transport_remap (row f-3): the ghost-cell updates of its centre fields go through the exchange machinery in
             # groups of planes (E-W ring, tripole fold with the mirror ranks), dpx / dpy as NE-corner vectors
@@ -305,6 +318,11 @@ def test_x_slabs_tripole(xp):
 @pytest.mark.parametrize("ns,world", [("open", 3), ("tripole", 2), ("tripole", 4)])
 def test_transport_upwind_across_slabs(ns, world):
     _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_UPWIND": "1"}, xp="ipc")
+
+
+@pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 2, "shm"), ("tripole", 4, "ipc")])
+def test_transport_upwind_state_across_slabs(ns, world, xp):
+    _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_UPWIND_STATE": "1"}, xp=xp)
 
 
 @pytest.mark.parametrize("ns,world,xp", [("open", 3, "ipc"), ("tripole", 2, "ipc"), ("tripole", 4, "shm"), ("tripole", 3, "ipc")])
