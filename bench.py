@@ -318,7 +318,7 @@ def roofline(r, icellt, icellu, revp):
             "effective_vs_reference_accounting": {"bytes_per_cell_update": ALG_BYTES_STRESS + ALG_BYTES_STEPU,
                                                   "GBps": ref / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
                                                   "frac_of_peak": ref / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0},
-            "other_kernel": {"name": "k_subcycle on the main stream (odd remainder; the tripole band launches run beside the main kernel on the second stream and are not in this count)", "launches": int(r["k1_n"]),
+            "other_kernel": {"name": "k_subcycle on the main stream (odd remainder; one rank: the tripole top band of a pair runs as workgroups of the pair's own launch, band_pair -- x-slab ranks: band launches on the second stream, not in this count)", "launches": int(r["k1_n"]),
                              "launches_timed": int(r["k1_timed"]), "avg_launch_ms": r["k1_ms"] / max(r["k1_n"], 1)}}
 
 
@@ -433,18 +433,35 @@ def next_rows(a, case, d, f, xmin, device, ncat=5, trcr_depend=(0, 1, 1, 1, 1, 2
     ncp, ntp = ncat + 1, ncat * ntrace
     icefrac = float((m0[:, 1:] > 1.0e-11).double().mean())
     # (what is only touched where a category has ice -- tc, tx, ty, the tracer reads of the update -- counted with the ice fraction)
+    fused = os.environ.get("EVPK_REMAP_FUSED", "1") != "0" and ntrace <= 14
     planes = (4 * nfield                                             # gather + scatter: block arrays <-> planes
-              + (nfield + 1 + 2 * ncp + 3 * ntp * icefrac)           # construct: mm, tm, hm in; mx, my out; tc, tx, ty out where ice
-              + 2 * (3 * ncp + 3 * ntp * icefrac + nfield + 2)       # flux E, N: mm, mx, my, (tc, tx, ty), dp in; fluxes out
-              + (4 * ncp + ntp + 3 * ntp * icefrac))                 # update: mm in / out, mass fluxes; tm out, tm + tracer fluxes in where ice
+              + (nfield + 1 + 2 * ncp + 3 * ntp * icefrac))          # construct: mm, tm, hm in; mx, my out; tc, tx, ty out where ice
+    if fused:   # k_remap_fluxupd: mm, mx, my, (tc, tx, ty), dp, (tm) in; new mm, tm out; the new mm copied over the old one
+        planes += 3 * ncp + 3 * ntp * icefrac + 2 + ntp * icefrac + ncp + ntp + 2 * ncp
+    else:
+        planes += (2 * (3 * ncp + 3 * ntp * icefrac + nfield + 2)    # flux E, N: mm, mx, my, (tc, tx, ty), dp in; fluxes out
+                   + (4 * ncp + ntp + 3 * ntp * icefrac))            # update: mm in / out, mass fluxes; tm out, tm + tracer fluxes in where ice
     moved = planes * cells * 8.0
+    # counter-backed bytes of the same call (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/prof_remap.sh), if they were
+    # measured on this build of the kernels
+    pmc = None
+    try:
+        db = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        e = [x for x in db.get("remap", []) if x.get("source_sha") == source_sha() and x.get("cells") == cells and x.get("fields") == nfield]
+        if e:
+            pmc = {"hbm_bytes_per_call": e[-1]["hbm_bytes_per_call"], "GBps": e[-1]["hbm_bytes_per_call"] / min(t[1:]) / 1e9,
+                   "frac_of_peak": e[-1]["hbm_bytes_per_call"] / min(t[1:]) / 1e9 / HBM_PEAK_GBS, "over_compulsory": e[-1]["hbm_bytes_per_call"] / (2 * 8 * cells * nfield),
+                   "profile": e[-1].get("profile")}
+    except (OSError, ValueError, KeyError):
+        pmc = None
     res["transport_remap"] = {"what": "horizontal_remap (ice_transport_remap.F90:309), ncat = %d, ntrace = %d, ice state resident in HBM (device arrays), "
                                       "velocities as eap left them" % (ncat, ntrace), "ms_per_call": 1e3 * min(t[1:]),
                               "value": cells * nfield / min(t[1:]), "unit": "field-cell-updates/s", "fields": nfield,
                               "compulsory_GBps": 2 * 8 * cells * nfield / min(t[1:]) / 1e9,
                               "roofline": {"bound": "hbm", "achieved": moved / min(t[1:]) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": moved / min(t[1:]) / 1e9 / HBM_PEAK_GBS, "bytes_per_call": moved,
-                                           "note": "whole call (six kernels); every plane a kernel reads or writes counted once per kernel"},
+                                           "note": "whole call; every plane a kernel reads or writes counted once per kernel (hand count)",
+                                           "traffic_pmc": pmc},
                               "max_area_change": float((mm - m0).abs().max())}
     s.close()
     return res

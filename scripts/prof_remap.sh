@@ -21,3 +21,21 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write
 python3 scripts/pmc_kernels.py "$(find "$out/pmc_fetch" -name "*counter_collection.csv" | tail -1)" "$(find "$out/pmc_write" -name "*counter_collection.csv" | tail -1)" \
     "k_remap|k_gather_planes|k_scatter_planes|k_state_|k_planes_" "$out/pmc_traffic.json" 8
 rm -rf "$out/pmc_fetch" "$out/pmc_write"
+
+# the whole call's bytes into profiles/traffic.json (bench.py: next_rows.transport_remap.roofline.traffic_pmc), keyed by the kernel sources
+python3 - "$out/pmc_traffic.json" "profiles/${1:-remap_prof}" <<'PY'
+import hashlib, json, os, sys
+pmc = json.load(open(sys.argv[1]))
+h = hashlib.sha256()
+for n in ("evpk_kernels.hip", "evpk_api.hip", "evpk_internal.h", "evpk_remap.hip", "evpk_eap.hip", "evpk_fmath.h"):
+    h.update(open(os.path.join("cice5_amd", "csrc", n), "rb").read())
+calls = 2.0      # --reps 1 = one warm-up + one timed call
+tot = sum(v["hbm_bytes_all_launches"] for k, v in pmc.items() if isinstance(v, dict) and "hbm_bytes_all_launches" in v) / calls
+path = "profiles/traffic.json"
+db = json.load(open(path)) if os.path.exists(path) else {"entries": []}
+e = {"source_sha": h.hexdigest()[:16], "cells": 3600 * 2700, "fields": 66, "hbm_bytes_per_call": tot, "profile": sys.argv[2],
+     "factors": pmc.get("factors_used")}
+db["remap"] = [x for x in db.get("remap", []) if x.get("source_sha") != e["source_sha"]] + [e]
+json.dump(db, open(path, "w"), indent=1)
+print("remap: %.2f GB per call, sha %s" % (tot / 1e9, e["source_sha"]))
+PY
