@@ -941,10 +941,14 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
                 const char *e = getenv("EVPK_IPC_MEM");
                 const bool coarse = e && strcmp(e, "coarse") == 0;
                 void *p = nullptr;
-                if (coarse || (hipExtMallocWithFlags(&p, x.box_bytes, hipDeviceMallocUncached) != hipSuccess &&
-                               hipExtMallocWithFlags(&p, x.box_bytes, hipDeviceMallocFinegrained) != hipSuccess)) {
-                    (void)hipGetLastError();
+                if (coarse) {
                     HIPCHK(c, hipMalloc(&p, x.box_bytes));
+                } else if (hipExtMallocWithFlags(&p, x.box_bytes, hipDeviceMallocUncached) != hipSuccess &&
+                           hipExtMallocWithFlags(&p, x.box_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                    // no silent fall-back to cached memory: peers would store into lines this device's L2s may hold
+                    (void)hipGetLastError();
+                    FAIL(c, "ipc transport: neither uncached nor fine-grained device memory for the receive buffers (%zu bytes); "
+                            "EVPK_IPC_MEM=coarse takes plain hipMalloc memory and relies on the kernel-boundary invalidates", x.box_bytes);
                 }
                 x.mybox = (char *)p;
             }
