@@ -261,6 +261,13 @@ struct evpk_ctx {
     BlockDesc *d_bd = nullptr;
     bool full_cover = true;
     bool band_fused = true;       // EVPK_BAND_FUSED (default 1): see subcycle_impl
+    // strip list of the pair kernels compacted on the device (one rank, no ghost zones; EVPK_DEVICE_STRIPS=0: on the host):
+    // evpk_prep then never waits for the GPU -- the kernels read the list's length from d_ns2, the host reads it (and the cell
+    // counts) from page-locked memory once the loop's final event has completed
+    bool dev_strips_env = true, dev_strips = false;
+    int *d_ns2 = nullptr;
+    unsigned long long *h_counts = nullptr;      // page-locked: [0] icellt, [1] icellu, [2] number of strips (as written by the copies)
+    int ns_tot2_cur = 0;
     int ew = 0, ns = 0, rank = 0, nranks = 1, west = -1, east = -1, device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // interior strips of k_subcycle2 while `stream` exchanges the edge columns
@@ -831,13 +838,14 @@ static PairList state_pairs(int SB) {
 }
 
 static void destroy_impl(evpk_ctx *c) {
+    if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1262,6 +1270,11 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (const char *bf = getenv("EVPK_BAND_FUSED")) c->band_fused = atoi(bf) != 0;
+    if (const char *ds = getenv("EVPK_DEVICE_STRIPS")) c->dev_strips_env = atoi(ds) != 0;
+    HIPCHK(c, hipMalloc(&c->d_ns2, sizeof(int) * 2));
+    HIPCHK(c, hipMemset(c->d_ns2, 0, sizeof(int) * 2));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_counts, sizeof(unsigned long long) * 4, hipHostMallocDefault));
+    memset(c->h_counts, 0, sizeof(unsigned long long) * 4);
     const char *tk = getenv("EVPK_TIME_KERNELS");
     c->time_kernels = tk ? std::max(0, std::min(atoi(tk), 2)) : 1;
     // a multi-rank context without a unique id stays unconnected until evpk_connect (two-phase start)
@@ -1548,6 +1561,23 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     if (!c->use_double && strips1(c)) return 1;
     if (c->use_double && tune_R2(c)) return 1;
     const int ns_tot2 = c->ncx2 * c->nry2;
+    c->dev_strips = c->dev_strips_env && c->use_double && !c->zone_mode && c->nranks == 1 && !c->force_exchange;
+    if (c->dev_strips) {
+        // flags, ordered compaction and counts on the device; nothing comes back before the loop has run (subcycle_impl)
+        hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry2, c->R2,
+                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, G, c->d_flags2, (unsigned int *)nullptr, c->d_counts);
+        hipLaunchKernelGGL(k_compact_strips, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)c->d_flags2, ns_tot2, c->d_strips2, c->d_ns2);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_counts + 2, c->d_ns2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        c->ns_tot2_cur = ns_tot2;
+        c->nstrips2 = ns_tot2;            // the launches cover the upper bound; the true number replaces it after the loop
+        c->nstrips2e = c->nstrips2i = 0;
+        c->ksub = 0;
+        c->prepped = true;
+        c->evp_count++;
+        return 0;
+    }
     std::vector<unsigned char> flags2(c->use_double ? ns_tot2 : 0);
     unsigned long long cnt[2] = {0, 0};
     if (c->use_double) {
@@ -1800,7 +1830,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0;
+        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nsdev = nullptr;
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
@@ -1817,7 +1847,8 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         // the LAST variant of k_subcycle)
         const bool pair_ends_evp = pairs && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte);
         if (pair_inside || pair_ends_evp) {
-            a.strips = c->d_strips2; a.nstrips = c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
+            a.strips = c->d_strips2; a.nstrips = c->dev_strips ? c->ns_tot2_cur : c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
+            a.nsdev = c->dev_strips ? c->d_ns2 : nullptr;
             a.wrap = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;      // in-kernel cyclic wrap, or ghost-zone mode
             // tripole: rows next to the fold are redone one subcycle at a time with the fold in between
             //   band 1: T rows nyl-2..nyl+1, U rows nyl-2..nyl   state `sr` -> scratch;  fold(scratch)
@@ -1964,6 +1995,12 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
+    if (c->dev_strips) {          // what evpk_prep left in flight has arrived with the loop's last event
+        c->icellt = (long long)c->h_counts[0];
+        c->icellu = (long long)c->h_counts[1];
+        c->nstrips2 = (int)(c->h_counts[2] & 0xffffffffull);
+        if (c->tuned_icellt == -2) c->tuned_icellt = c->icellt;
+    }
     if (xp_check(c)) return 1;
     if (ov_trying) {
         if (c->ov_trial >= 1) c->ov_ms[c->ov_trial - 1] = c->loop_ms;

@@ -968,6 +968,8 @@ struct SubArgs {
     int jb0;           // > 0: band launch -- every strip starts at row jb0 (tripole top band), strips[] holds cx only
     int jmax;          // k_subcycle2: rows above are not stored (tripole, single rank: the band launches own rows >= nyl-1)
     int G;             // k_subcycle2 in ghost-zone mode: columns 1-G .. nxl+G are advanced (zones of G+2 columns per side)
+    const int *nsdev;  // != nullptr: the number of entries of strips[] lives on the device (k_compact_strips wrote list and count; the
+                       // host launches for the upper bound nstrips and never waits for the count): one rank, the pair kernels
     int nband;         // > 0 (tripole, one rank, cyclic E-W): the first nband8 = 8*ceil(nband/8) workgroups of the launch are the
                        // tripole top band (band_pair); the strips follow
 };
@@ -1384,14 +1386,22 @@ template __global__ void k_subcycle_t<true, true>(SubArgs);
 // ------------------------------------------------------------------------------------
 constexpr int STRIP2_W = 61;
 
+// number of strips of a pair launch: from the launch (the host knows the list) or from the count k_compact_strips left on the
+// device (the launch then covers the upper bound and the blockIdx -> strip map takes its chunk from the count)
+__device__ __forceinline__ int pair_nstrips(const SubArgs &a) {
+    return a.nsdev ? __builtin_amdgcn_readfirstlane(*a.nsdev) : a.nstrips;
+}
+
 template <bool REVP, bool LAST2>
 __global__ __launch_bounds__(256) void k_subcycle2(SubArgs a) {
     const Slab &s = a.s;
     const int lane = threadIdx.x & 63;
-    const int chunk = gridDim.x >> 3;
+    const int ns = pair_nstrips(a);
+    const int chunk = a.nsdev ? (((ns + 3) >> 2) + 7) >> 3 : (int)(gridDim.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk) return;
     const int wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
-    if (sid >= a.nstrips) return;
+    if (sid >= ns) return;
     const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
@@ -1831,10 +1841,12 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         return;
     }
     const int bidx = (int)blockIdx.x - nband8;
-    const int chunk = ((int)gridDim.x - nband8) >> 3;
+    const int ns = pair_nstrips(a);
+    const int chunk = a.nsdev ? (((ns + 3) >> 2) + 7) >> 3 : ((int)gridDim.x - nband8) >> 3;
+    if ((bidx >> 3) >= chunk) return;
     const int wg = (bidx & 7) * chunk + (bidx >> 3);
     const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
-    if (sid >= a.nstrips) return;
+    if (sid >= ns) return;
     const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
@@ -2109,9 +2121,10 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
         return;
     }
     const int bidx = (int)blockIdx.x - nband8;
-    const int chunk = ((int)gridDim.x - nband8) >> 3;
+    const int ns = pair_nstrips(a);
+    const int chunk = a.nsdev ? (ns + 7) >> 3 : ((int)gridDim.x - nband8) >> 3;
     const int wg = (bidx & 7) * chunk + (bidx >> 3);
-    if (wg >= a.nstrips) return;                      // (the whole workgroup leaves: no barrier is left waiting)
+    if ((bidx >> 3) >= chunk || wg >= ns) return;     // (the whole workgroup leaves: no barrier is left waiting)
     const int st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
@@ -2288,6 +2301,30 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
         if (flags) flags[sid] = b ? 1 : 0;
         if (count && b) atomicAdd(count, 1u);
     }
+}
+
+// the list of flagged strips, in order, and its length -- on the device, so that evpk_prep need not wait for the flags, compact
+// them on the host and send the list back: one workgroup of 1024 threads walks the flags 1024 at a time (ballot + wave offsets)
+__global__ __launch_bounds__(1024) void k_compact_strips(const unsigned char *flags, int n, int *list, int *count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += 1024) {
+        const int k = k0 + (int)threadIdx.x;
+        const bool f = k < n && flags[k] != 0;
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) wsum[w] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int q = 0; q < w; q++) off += wsum[q];
+        if (f) list[off + __popcll(b & ((1ull << lane) - 1ull))] = k;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < 16; q++) t += wsum[q]; base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
 }
 
 // ------------------------------------------------------------------------------------
