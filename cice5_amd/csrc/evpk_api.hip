@@ -306,6 +306,7 @@ struct evpk_ctx {
     double **rm_tab = nullptr;
     signed char *rm_sgn = nullptr;
     unsigned *rm_bad = nullptr;
+    int *d_bmap = nullptr; int bmap_nbx = 0;              // remap_block_map
     double *uw_pool = nullptr; size_t uw_pool_n = 0;      // evpk_transport_upwind_state: one input + 3 + ntrcr output planes
     double **uw_tab = nullptr; signed char *uw_sgn = nullptr;
     size_t rm_pool_n = 0, rm_stage_n = 0, rm_tab_n = 0;
@@ -845,7 +846,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -2533,6 +2534,21 @@ static int planes_halo(evpk_ctx *c, double **d_list, const signed char *d_sgn, i
 }
 
 // st == nullptr: mm / tm are the caller's aim / trm; else the caller's state arrays (host pointers in *st) through the fused transforms
+// block column / row of the global grid -> local block index (-1: not here), for kernels that write a slab cell into the
+// caller's block arrays themselves
+static int remap_block_map(evpk_ctx *c) {
+    if (c->d_bmap) return 0;
+    const int bsx = c->nxb - 2, bsy = c->nyb - 2;
+    const int nbx = (c->s.nxg - 1) / bsx + 1, nby = (c->s.nyg - 1) / bsy + 1;
+    std::vector<int> m((size_t)nbx * nby, -1);
+    for (int b = 0; b < c->nblocks; b++)
+        m[(size_t)((c->bd[b].jglob_lo - 1) / bsy) * nbx + (c->bd[b].iglob_lo - 1) / bsx] = b;
+    HIPCHK(c, hipMalloc(&c->d_bmap, sizeof(int) * m.size()));
+    HIPCHK(c, hipMemcpy(c->d_bmap, m.data(), sizeof(int) * m.size(), hipMemcpyHostToDevice));
+    c->bmap_nbx = nbx;
+    return 0;
+}
+
 static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, double *mm, double *tm, const int32_t *tracer_type,
                       const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
                       int32_t l_fixed_area, const RemapState *st) {
@@ -2687,14 +2703,28 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     if (halo(c, F_SIG1, 2, true, true, 0.0)) return 1;
     // fluxes + update: one tiled kernel whose edge transports stay in the LDS (EVPK_REMAP_FUSED=0 or more than 14 tracers: the
     // three kernels that hand fe, fn, tfe, tfn over through HBM)
+    bool remap_direct = false;
     const size_t flux_lds = sizeof(double) * 2 * 256 * (size_t)(1 + ntrace);
     static const bool fused_env = !(getenv("EVPK_REMAP_FUSED") && atoi(getenv("EVPK_REMAP_FUSED")) == 0);
     if (fused_env && flux_lds <= 60 * 1024) {
         const long long ntiles = (long long)((s.nxl + RM_TILE - 2) / (RM_TILE - 1)) * ((s.nyl + RM_TILE - 2) / (RM_TILE - 1)) * ncp;
+        // without the state transforms the update delivers straight into the caller's arrays (device-visible, or the staged copy
+        // that is sent back below): no scatter pass.  A bad departure point leaves them untouched (the kernel looks at the flag
+        // k_remap_dp set); a negative mass is found while they are being written -- the reference aborts the run there
+        // (:3622-3640), the arrays are then undefined (include/evpk.h).  EVPK_REMAP_DIRECT=0: planes + scatter as before.
+        static const bool direct_env = !(getenv("EVPK_REMAP_DIRECT") && atoi(getenv("EVPK_REMAP_DIRECT")) == 0);
+        remap_direct = !st && direct_env;
+        RmOut O{};
+        if (remap_direct) {
+            if (remap_block_map(c)) return 1;
+            O.mm = dmm; O.tm = dtm; O.bmap = c->d_bmap; O.bd = c->d_bd; O.direct = 1; O.nbxg = c->bmap_nbx; O.bsx = c->nxb - 2; O.bsy = c->nyb - 2;
+            O.nxb = c->nxb; O.nyb = c->nyb;
+        }
         hipLaunchKernelGGL(k_remap_fluxupd, dim3((unsigned)(((ntiles + 7) / 8) * 8)), dim3(256), flux_lds, c->stream,
-                           s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2, c->rm_bad);
+                           s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2, c->rm_bad, O);
         // the new masses were written beside the old ones (plane fe(n)): in place of mm(n) now that every tile is done
-        HIPCHK(c, hipMemcpyAsync(c->rm_pool, c->rm_pool + (size_t)3 * ncp * np, sizeof(double) * (size_t)ncp * np, hipMemcpyDeviceToDevice, c->stream));
+        if (!remap_direct)
+            HIPCHK(c, hipMemcpyAsync(c->rm_pool, c->rm_pool + (size_t)3 * ncp * np, sizeof(double) * (size_t)ncp * np, hipMemcpyDeviceToDevice, c->stream));
     } else {
     hipLaunchKernelGGL(k_remap_flux<false>, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
     hipLaunchKernelGGL(k_remap_flux<true>, dim3((s.nxl + 63) / 64, (s.nyl + 1 + 3) / 4, ncp), B2D, 0, c->stream, s, tb, P, dxu, dyu, (int)F_SIG1, (int)F_SIG2);
@@ -2713,11 +2743,13 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     else if (bad & 2u) { c->err = "evpk_transport_remap: negative area / mass after the update (ice_transport_remap.F90:3622-3640)"; badrc = EVPK_REMAP_NEGATIVE_MASS; }
     if (badrc && !(st && c->nranks > 1)) return badrc;
     if (!st) {
+        if (!remap_direct) {
         hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ncp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
                            (double *const *)c->rm_tab, dmm, nblk, (size_t)ncp * nblk, nrg);
         if (ntp)
             hipLaunchKernelGGL(k_scatter_planes, dim3((c->nxb + 63) / 64, nrg * c->nblocks, ntp), b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb,
                                (double *const *)(c->rm_tab + o_tm), dtm, nblk, (size_t)ntp * nblk, nrg);
+        }
         HIPCHK(c, hipGetLastError());
         if (st_mm) HIPCHK(c, hipMemcpyAsync(mm, dmm, sizeof(double) * n_mm, hipMemcpyDeviceToHost, c->stream));
         if (st_tm) HIPCHK(c, hipMemcpyAsync(tm, dtm, sizeof(double) * n_tm, hipMemcpyDeviceToHost, c->stream));

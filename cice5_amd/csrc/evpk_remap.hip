@@ -513,9 +513,15 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_flux(Slab s, Remap
 // tc, tx, ty, mm, mx, my are read from HBM once instead of twice.  The new mass goes to the plane of fe(n) (other tiles still
 // read the old one); tm is updated in place (the fluxes read tc, tx, ty, never tm).
 constexpr int RM_TILE = 16;
+// RmOut (direct != 0): the new mm, tm go straight into the caller's block arrays mm(nx_block, ny_block, 0:ncat, nblocks),
+// tm(nx_block, ny_block, ntrace, ncat, nblocks) -- physical cells, what k_scatter_planes would deliver -- instead of into planes
+// that a scatter pass then copies: one HBM round trip of every field less.  bmap: block column / row -> local block (-1: none).
+struct RmOut { double *mm, *tm; const int *bmap; const BlockDesc *bd; int direct, nbxg, bsx, bsy, nxb, nyb; };
+
 __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_fluxupd(Slab s, RemapTab tb, RemapPlanes P, const double *dxu, const double *dyu, int fdx, int fdy,
-                                                                        unsigned *bad) {
+                                                                        unsigned *bad, RmOut O) {
     extern __shared__ double rl[];                    // FE[1 + ntrace][256], FN[1 + ntrace][256]
+    if (O.direct && (*bad & 1u)) return;              // a departure point out of bounds (k_remap_dp): the caller's arrays stay as they are
     const int tx = threadIdx.x & (RM_TILE - 1), ty = threadIdx.x >> 4, tid = threadIdx.x;
     // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD takes a contiguous run of tiles,
     // x fastest, so that tiles running side by side share the cache lines their 16-cell rows straddle and their rims
@@ -540,7 +546,18 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_fluxupd(Slab s, Re
     double mnew = mold - w1 * tarear;
     if (mnew < -RM_PUNY) atomicOr(bad, 2u);
     else if (mnew < 0.0) mnew = 0.0;
-    P.fe(n)[k] = mnew;                                // (copied over mm(n) when the launch is complete)
+    size_t oc = 0;                                    // offset of this cell inside a (ny_block, nx_block) plane of its block
+    int ob = -1;                                      // its local block
+    if (O.direct) {
+        const int gi = s.i0 + i - 1, gj = s.j0 + j - 1;
+        ob = O.bmap[((gj - 1) / O.bsy) * O.nbxg + (gi - 1) / O.bsx];
+        if (ob >= 0) {
+            const BlockDesc d = O.bd[ob];
+            oc = (size_t)(d.jlo + (gj - d.jglob_lo) - 1) * O.nxb + (d.ilo + (gi - d.iglob_lo) - 1);
+            O.mm[((size_t)ob * (tb.ncat + 1) + n) * O.nyb * O.nxb + oc] = mnew;
+        }
+    } else
+        P.fe(n)[k] = mnew;                            // (copied over mm(n) when the launch is complete)
     if (n == 0) return;
     double o1 = 0.0, n1 = 0.0, o2 = 0.0, n2 = 0.0;
     for (int q0 = 0; q0 < tb.ntrace; q0++) {
@@ -561,7 +578,10 @@ __global__ void __launch_bounds__(256, RM_FLUX_WAVES) k_remap_fluxupd(Slab s, Re
         } else {
             if (mnew > 0.0 && fabs(n2) > 0.0 && fabs(n1) > 0.0) v = (mold * o1 * o2 * told - w1 * tarear) / (mnew * n1 * n2);
         }
-        tmp[k] = v;
+        if (O.direct) {
+            if (ob >= 0) O.tm[(((size_t)ob * tb.ncat + (n - 1)) * tb.ntrace + nt) * O.nyb * O.nxb + oc] = v;
+        } else
+            tmp[k] = v;
     }
 }
 

@@ -257,8 +257,8 @@ int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat, int32_t nt
  * transport_integrals and update_fields run on the GPU in the Fortran's operation order; state_to_tracers /
  * tracers_to_state and the conservation / monotonicity diagnostics stay with the host's tracer bookkeeping.
  * Returns 0, EVPK_REMAP_BAD_DEPARTURE (a departure point left the neighbouring cells, :1583-1607: the time step is too
- * long), EVPK_REMAP_NEGATIVE_MASS (:3622-3640) -- mm, tm untouched in both cases, the reference aborts there -- or 1 with
- * evpk_last_error.  Needs HTN and HTE in evpk_geom. */
+ * long; mm, tm untouched), EVPK_REMAP_NEGATIVE_MASS (:3622-3640; mm, tm undefined: the update writes them as it goes) -- the
+ * reference aborts the run in both cases -- or 1 with evpk_last_error.  Needs HTN and HTE in evpk_geom. */
 #define EVPK_REMAP_MAX_TRACERS 32
 #define EVPK_REMAP_BAD_DEPARTURE 11
 #define EVPK_REMAP_NEGATIVE_MASS 12
