@@ -2705,14 +2705,14 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     // three kernels that hand fe, fn, tfe, tfn over through HBM)
     bool remap_direct = false;
     const size_t flux_lds = sizeof(double) * 2 * 256 * (size_t)(1 + ntrace);
-    static const bool fused_env = !(getenv("EVPK_REMAP_FUSED") && atoi(getenv("EVPK_REMAP_FUSED")) == 0);
+    const bool fused_env = !(getenv("EVPK_REMAP_FUSED") && atoi(getenv("EVPK_REMAP_FUSED")) == 0);
     if (fused_env && flux_lds <= 60 * 1024) {
         const long long ntiles = (long long)((s.nxl + RM_TILE - 2) / (RM_TILE - 1)) * ((s.nyl + RM_TILE - 2) / (RM_TILE - 1)) * ncp;
         // without the state transforms the update delivers straight into the caller's arrays (device-visible, or the staged copy
         // that is sent back below): no scatter pass.  A bad departure point leaves them untouched (the kernel looks at the flag
         // k_remap_dp set); a negative mass is found while they are being written -- the reference aborts the run there
         // (:3622-3640), the arrays are then undefined (include/evpk.h).  EVPK_REMAP_DIRECT=0: planes + scatter as before.
-        static const bool direct_env = !(getenv("EVPK_REMAP_DIRECT") && atoi(getenv("EVPK_REMAP_DIRECT")) == 0);
+        const bool direct_env = !(getenv("EVPK_REMAP_DIRECT") && atoi(getenv("EVPK_REMAP_DIRECT")) == 0);
         remap_direct = !st && direct_env;
         RmOut O{};
         if (remap_direct) {

@@ -731,6 +731,18 @@ def test_tripole_band_launches_on_the_second_stream(shape, tile, monkeypatch):
     _both(nx, ny, bsx, bsy, ns="tripole", land="continents", ndte=ndte)
 
 
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_strip_list_compacted_on_the_host(ns, monkeypatch):
+    """EVPK_DEVICE_STRIPS=0: the strip list of the pair kernels built on the host from the flags (the path of x-slab ranks and of
+    rounds 1-2) against the default, where flags, ordered compaction and counts stay on the device and evpk_prep never waits;
+    three calls with changing ice, the counts of active cells included"""
+    monkeypatch.setenv("EVPK_DEVICE_STRIPS", "0")
+    _both(100, 116, 25, 29, ns=ns, land="continents", ndte=30, ncalls=3)
+    monkeypatch.delenv("EVPK_DEVICE_STRIPS")
+    _both(100, 116, 25, 29, ns=ns, land="continents", ndte=30, ncalls=3)
+    _both(320, 384, 320, 384, ns=ns, ndte=12, ncalls=2)
+
+
 def test_bound_time_is_reported():
     """evpk_stats.bound_ms: the halo / fold updates of the subcycle loop (timer_bound in the reference) are timed with
     sampled HIP events: none on a cyclic one-rank open grid (the kernel wraps in place) nor on a one-rank tripole grid whose
@@ -938,6 +950,26 @@ def test_transport_remap_stale_ghost_cells_and_no_tracers():
     m1 = mm.copy()
     assert _remap_on_device(d, f, m1, None, ([], [], []), 3600.0, 3, True) == 0
     assert np.array_equal(m1, mo)
+
+
+def test_transport_remap_through_planes_and_a_scatter_pass(monkeypatch):
+    """EVPK_REMAP_DIRECT=0 (the update writes planes, a scatter pass delivers them) and EVPK_REMAP_FUSED=0 (transports and update as
+    three kernels through HBM) stay bit-identical with the default, where the fused tile kernel writes the caller's arrays itself"""
+    case, d, f, mm, tm, tables = util.remap_case(100, 116, 25, 29, ns="tripole", ncat=3)
+    mo, to = mm.copy(), tm.copy()
+    dt = 3600.0
+    assert orc.horizontal_remap(d, dt, f, mo, to, *tables) == 0
+    for env in ({}, {"EVPK_REMAP_DIRECT": "0"}, {"EVPK_REMAP_FUSED": "0"}):
+        mg, tg = mm.copy(), tm.copy()
+        assert _remap_on_device(d, f, mg, tg, tables, dt, 3, True, env=env, monkeypatch=monkeypatch) == 0
+        for k in env:
+            monkeypatch.delenv(k)
+        phys = util.cell_mask(d, "phys")
+        assert np.array_equal(mg[:, :, phys[0]] if d.nblocks == 1 else mg[np.broadcast_to(phys[:, None], mg.shape)],
+                              mo[:, :, phys[0]] if d.nblocks == 1 else mo[np.broadcast_to(phys[:, None], mo.shape)]), env
+        assert np.array_equal(tg[np.broadcast_to(phys[:, None, None], tg.shape)], to[np.broadcast_to(phys[:, None, None], to.shape)]), env
+        ghost = ~phys
+        assert np.array_equal(mg[np.broadcast_to(ghost[:, None], mg.shape)], mm[np.broadcast_to(ghost[:, None], mm.shape)]), env     # ghost cells left alone
 
 
 def test_transport_remap_reports_the_two_abort_cases():
