@@ -219,7 +219,7 @@ def main():
                    "strips_per_launch_rank0": int(st.nstrips2 or st.nstrips),
                    "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows),
                    "transport": evpk.XP_NAMES.get(int(st.transport), "?") if world > 1 else "none",
-                   "ghost_zone_cols": int(st.zone_cols), "zone_exchanges_per_evp": int(st.zone_exchanges),
+                   "ghost_zone_cols": int(st.zone_cols), "zone_exchanges_per_evp": int(st.zone_exchanges), "band_row_exchanges_per_evp": int(st.band_row_exchanges),
                    "zone_bytes_sent_rank0": int(st.zone_bytes), "overlap_split_rank0": int(st.overlap_split),
                    "step": "prep + ndte x (stress+stepu, halo / fold) + stress folds + finish"},
         "roofline": roof,

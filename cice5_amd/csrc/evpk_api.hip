@@ -261,6 +261,15 @@ struct evpk_ctx {
     BlockDesc *d_bd = nullptr;
     bool full_cover = true;
     bool band_fused = true;       // EVPK_BAND_FUSED (default 1): see subcycle_impl
+    // x-slab ranks on a tripole grid (even number of ranks, equal slab widths; EVPK_XBAND=0: band launches on the second stream):
+    // the mirror slab M of band_pair -- a copy of rows N-3 .. N+1 of the mirror rank P-1-r (its ghost zones included), kept
+    // current by one row message per pair (rows N-3, N-2; all five after a ghost-zone exchange or a one-subcycle launch)
+    bool xband = false;
+    Slab m{};
+    Slab *d_mslab = nullptr;
+    double2 *xb_send = nullptr, *xb_recv = nullptr;
+    size_t xb_cap = 0;
+    int xb_partner = -1, m_need = 5, xb_swaps = 0;
     // strip list of the pair kernels compacted on the device (one rank, no ghost zones; EVPK_DEVICE_STRIPS=0: on the host):
     // evpk_prep then never waits for the GPU -- the kernels read the list's length from d_ns2, the host reads it (and the cell
     // counts) from page-locked memory once the loop's final event has completed
@@ -659,6 +668,48 @@ static int xp_check(evpk_ctx *c) {
     return 0;
 }
 
+// ---- rows r0 .. r0+nr-1 of the pair planes L (+ the mask bytes) of MY slab to the mirror rank, the mirror rank's into rows
+// m0 .. of the mirror slab M (band_pair): one swap with rank P-1-r over the context's transport ----
+static int xband_swap(evpk_ctx *c, const XbList &L, int r0, int m0, int nr, int mask, hipStream_t st) {
+    Slab &s = c->s;
+    const int q = c->xb_partner, ch = xp_channel(c, st), tx = 128;
+    const size_t ncol = (size_t)s.nxl + 2 * ZW_MAX;
+    const size_t bytes = ((size_t)L.np * nr * ncol * sizeof(double2) + (mask ? (size_t)nr * ncol : 0) + 15) & ~(size_t)15;
+    if (bytes > c->xb_cap) FAIL(c, "xband_swap: message larger than its buffer");
+    double2 *snd = c->xb_send, *rcv = c->xb_recv;
+    if (c->ipc) {
+        if (bytes > c->ipc->slot[ch] / 2) FAIL(c, "ipc transport: band rows message larger than its slot");
+        snd = reinterpret_cast<double2 *>(ipc_send_ptr(c, ch, q, 0));
+        rcv = reinterpret_cast<double2 *>(ipc_recv_ptr(c, ch, q, 0));
+    }
+    const dim3 g((unsigned)((ncol + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
+    hipLaunchKernelGGL(k_xband_pack, g, dim3(tx), 0, st, s, L, r0, nr, mask, snd);
+    HIPCHK(c, hipGetLastError());
+    if (c->ipc) {
+        if (ipc_signal(c, ch, q, st)) return 1;
+        if (ipc_wait(c, ch, q, st)) return 1;
+    } else if (c->relay) {
+        int rc = c->relay->send(q, snd, bytes, st);
+        rc |= c->relay->recv(q, rcv, bytes, st);
+        if (rc) FAIL(c, "shared-memory relay: band rows exchange failed");
+    } else {
+        NCCLCHK(c, ncclGroupStart());
+        const ncclResult_t r1 = ncclSend(snd, bytes, ncclChar, q, c->comm, st);
+        const ncclResult_t r2 = ncclRecv(rcv, bytes, ncclChar, q, c->comm, st);
+        const ncclResult_t r3 = ncclGroupEnd();
+        if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) FAIL(c, "band rows exchange: ncclSend / ncclRecv failed");
+    }
+    hipLaunchKernelGGL(k_xband_unpack, g, dim3(tx), 0, st, c->m, L, m0, nr, mask, (const double2 *)rcv);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+// the state rows of buffer SB (u, v and the twelve stresses): the top `nr` of the five rows N-3 .. N+1 start at N-3
+static int xband_state(evpk_ctx *c, int SB, int nr, hipStream_t st) {
+    XbList L{};
+    for (int q = 0; q < NSTATE / 2; q++) L.f[L.np++] = SB + 2 * q;
+    return xband_swap(c, L, c->s.nyl - 3, 1, nr, 0, st);
+}
+
 // ---- halo update of nf consecutive planes starting at f ---------------------------------
 // fsrc_fold >= 0: ice_HaloUpdate_stress variant (only the tripole north ghost row of the
 // destination planes is written, from the top physical row of the source planes).
@@ -846,7 +897,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1009,8 +1060,33 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
         const char *zm = getenv("EVPK_ZONE_M");
         int m = zm ? atoi(zm) : ZW_MAX / 2;
         m = std::max(1, std::min(m, std::min(ZW_MAX / 2, minw / 2)));
-        if (c->band_mode) m = 1;          // the fold is all-gathered after every subcycle anyway
+        {   // tripole between ranks without a per-subcycle exchange: see band_pair (every rank decides alike)
+            const char *xe = getenv("EVPK_XBAND");
+            bool eq = true;
+            for (int r = 0; r < c->nranks; r++) eq = eq && (c->slab_i0[r + 1] - c->slab_i0[r] == s.nxl);
+            c->xband = c->band_mode && c->nranks > 1 && (c->nranks % 2 == 0) && eq && c->prefetch && c->band_fused && !(xe && atoi(xe) == 0) &&
+                       s.nxl >= 2 * ZW_MAX && s.nyl >= 8;
+        }
+        if (c->band_mode && !c->xband) m = 1;          // the fold is exchanged after every subcycle anyway
         c->zM = m; c->zW = 2 * m;
+        if (c->xband) {
+            c->xb_partner = c->nranks - 1 - c->rank;
+            c->m = s;
+            c->m.nyl = 4;                                          // rows 1 .. 4 <-> N-3 .. N of the partner, row 5 its north ghost row
+            c->m.i0 = c->slab_i0[c->xb_partner];
+            c->m.tmask = c->m.umask = c->m.iceumask = nullptr;
+            c->m.tmphm = c->m.tile_ice = c->m.tile_dat = c->m.act_ice = c->m.act_any = nullptr;
+            HIPCHK(c, hipMalloc(&c->m.F, sizeof(double) * slab_doubles(c->m)));
+            HIPCHK(c, hipMemset(c->m.F, 0, sizeof(double) * slab_doubles(c->m)));
+            HIPCHK(c, hipMalloc(&c->m.cmask, mask_elems(c->m)));
+            HIPCHK(c, hipMemset(c->m.cmask, 0, mask_elems(c->m)));
+            HIPCHK(c, hipMalloc(&c->d_mslab, sizeof(Slab)));
+            HIPCHK(c, hipMemcpy(c->d_mslab, &c->m, sizeof(Slab), hipMemcpyHostToDevice));
+            const size_t ncol = (size_t)s.nxl + 2 * ZW_MAX;
+            c->xb_cap = (12 * 5 * ncol * sizeof(double2) + 5 * ncol + 64) & ~(size_t)15;
+            HIPCHK(c, hipMalloc(&c->xb_send, c->xb_cap));
+            HIPCHK(c, hipMalloc(&c->xb_recv, c->xb_cap));
+        }
         std::vector<int> band(c->ncx);
         for (int k = 0; k < c->ncx; k++) band[k] = k;
         HIPCHK(c, hipMalloc(&c->d_band, sizeof(int) * c->ncx));
@@ -1554,6 +1630,17 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         }
         c->zone_left = c->zM;
         c->inner_ok = true;
+        if (c->xband) {
+            // the mirror slab: what band_pair reads of the mirror rank's rows N-3 .. N+1 -- metrics, strength, the stepu inputs,
+            // the masks (once per evp) and the state
+            XbList L{};
+            for (int f : {(int)F_CXP, (int)F_CXM, (int)F_DXT, (int)F_DXHY, (int)F_TINYAREA, (int)F_VRELC, (int)F_UOCN, (int)F_FORCEX, (int)F_UMASSDTI,
+                          (int)F_UVEL_INIT, (int)F_TAREAR})
+                L.f[L.np++] = f;
+            if (xband_swap(c, L, s.nyl - 3, 1, 5, 1, c->stream)) return 1;
+            if (xband_state(c, SA, 5, c->stream)) return 1;
+            c->m_need = 0;
+        }
     }
     // active strips.  The list of the one-subcycle kernel is only built when that kernel is going to run (odd ndte, EVPK_DOUBLE=0,
     // a partial evpk_subcycle call): strips1() below; the cell counts then come from the two-subcycle kernel's flag pass.
@@ -1805,6 +1892,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     if (ov_trying) c->overlap = (c->ov_trial != 2);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->double_launches = 0;
+    c->xb_swaps = 0;
     c->zone_exchanges = 0;
     c->zone_bytes = 0;
     bool pendingI = false;      // an interior launch on stream2 that `stream` has not waited for yet
@@ -1825,13 +1913,14 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                          ((c->west >= 0 ? (c->zcompact ? c->zn[0] : s.nyl + 2) : 0) + (c->east >= 0 ? (c->zcompact ? c->zn[1] : s.nyl + 2) : 0));
         c->zone_left = c->zM;
         c->inner_ok = true;
+        c->m_need = 5;              // (x-slab tripole: the mirror rank's zone columns were refreshed too)
         return 0;
     };
     for (int n = 0; n < nsub;) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nsdev = nullptr;
+        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nsdev = nullptr; a.xm = nullptr;
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
@@ -1842,6 +1931,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         // and its mirror image in one workgroup, the fold between the subcycles in its LDS) -- no band launches, no second
         // stream, no hand-overs; EVPK_BAND_FUSED=0 brings the launches on stream2 back
         const bool fused_band = c->band_mode && c->band_fused && wrap && (c->prefetch || c->tile_mode) && s.nyl >= 4;
+        const bool xb = c->xband && !fused_band;
         const bool pairs = c->use_double && (fused_band || !(c->band_mode && c->tile_mode && c->nranks == 1 && !c->force_exchange));
         const bool pair_inside = pairs && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
         // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
@@ -1874,6 +1964,23 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
             if (fused_band) {
                 a.nband = (s.nxl / 2 + 1 + 60) / 61;          // strips A cover columns 0 .. nx/2, their mirror images the rest
                 a.jmax = s.nyl - 2;
+            } else if (xb) {
+                // x-slab ranks: strip A of every band workgroup is mine, strip B the mirror rank's, read from the mirror slab M,
+                // which one row message keeps current (rows N-3, N-2: the mirror rank's main strips wrote them; rows N-1 .. N+1
+                // were computed here as well) -- all five rows after a ghost-zone exchange or a one-subcycle launch
+                if (join()) FAIL(c, "hipStreamWaitEvent failed");
+                if (c->m_need) {
+                    bound_begin(c->stream);
+                    if (xband_state(c, a.sr, c->m_need, c->stream)) return 1;
+                    bound_end(c->stream);
+                    c->xb_swaps++;
+                }
+                // (cells no lane stores are alike in both state buffers: the band rows of M's write buffer start from its read buffer)
+                hipLaunchKernelGGL(k_xband_rows_copy, dim3((s.nxl + 2 * ZW_MAX + 127) / 128, 3), dim3(128), 0, c->stream, c->m, a.sr, a.sw, (int)NSTATE, 3, 5);
+                a.xm = c->d_mslab;
+                a.nband = (s.nxl + 2 * G + 60) / 61;
+                a.jmax = s.nyl - 2;
+                c->m_need = 2;
             } else if (c->band_mode) {
                 b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0; b1.G = 0;
                 b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
@@ -1935,7 +2042,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 HIPCHK(c, hipEventRecord(c->evE, c->stream));
                 evE_valid = true;
             }
-            if (c->band_mode && !fused_band) {
+            if (c->band_mode && !fused_band && !xb) {
                 if (c->handover_value) HIPCHK(c, hipStreamWaitValue32(c->stream, c->sigB1, c->sig_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
                 else HIPCHK(c, hipStreamWaitEvent(c->stream, c->evB1, 0));
             }
@@ -1988,6 +2095,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
             bound_end(c->stream);
         }
         if (c->zone_mode) { c->zone_left = 0; c->inner_ok = true; }     // one ghost column is current, the deeper zone is not
+        c->m_need = 5;
     }
     if (join()) FAIL(c, "hipStreamWaitEvent failed");
     // leave the ghost columns 0 / nxl+1 of the state current (download, finish, a later one-subcycle launch)
@@ -2831,6 +2939,6 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->bound_ms = c->bound_ms; o->bound_updates = c->bound_updates;
     o->compact_metrics = c->compact ? 1 : 0;
     o->transport = c->ipc ? EVPK_XP_IPC : c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
-    o->reserved_ = 0;
+    o->band_row_exchanges = c->xb_swaps;
     return 0;
 }

@@ -968,6 +968,8 @@ struct SubArgs {
     int jb0;           // > 0: band launch -- every strip starts at row jb0 (tripole top band), strips[] holds cx only
     int jmax;          // k_subcycle2: rows above are not stored (tripole, single rank: the band launches own rows >= nyl-1)
     int G;             // k_subcycle2 in ghost-zone mode: columns 1-G .. nxl+G are advanced (zones of G+2 columns per side)
+    const Slab *xm;    // != nullptr (x-slab ranks on a tripole grid): the mirror slab M of band_pair, a Slab struct in device memory
+    __device__ const Slab *xm_slab() const { return xm; }
     const int *nsdev;  // != nullptr: the number of entries of strips[] lives on the device (k_compact_strips wrote list and count; the
                        // host launches for the upper bound nstrips and never waits for the count): one rank, the pair kernels
     int nband;         // > 0 (tripole, one rank, cyclic E-W): the first nband8 = 8*ceil(nband/8) workgroups of the launch are the
@@ -1624,33 +1626,63 @@ __global__ void k_verify_metrics(Slab s, unsigned int *mismatch) {
 // ------------------------------------------------------------------------------------
 constexpr int BAND_LDS_DOUBLES = 2048 + 1024 + 4608 + 512;      // X, U1, S1, V2 = 64 KiB
 
+// Two forms, one code:
+//  * ONE RANK (a.xm == nullptr): strip A and strip B are both strips of the rank's own slab (cyclic wrap), A covering columns
+//    0 .. nx/2 over the band workgroups and B their mirror images -- lane l of A <-> column 61 k - 1 + l, of B <-> nx - 61 k - 61 + l.
+//  * X-SLAB RANKS (a.xm = the mirror slab M, round 3): strip A is a strip of MY slab (ghost-zone mode: columns 1-G .. w+G), strip
+//    B the mirror strip of the MIRROR RANK P-1-r, read from and written to M -- a copy of that rank's rows N-3 .. N+1 (its ghost
+//    zones included) with the same column numbering as its own slab.  With equal slab widths w the image of my local column i
+//    is the partner's local column w - i, whatever the rank: lane l of A <-> column cA + l, of B <-> w - cA - 62 + l.  Both
+//    ranks compute both strips (the same bits); rows N-1 .. N+1 of M are therefore kept current HERE, rows N-3, N-2 come with
+//    one message per pair (xband_swap) -- instead of four exchanges per pair around band launches on a second stream.
 template <bool REVP, bool LAST2>
 __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) {
-    const Slab &s = a.s;
+    const Slab &sA = a.s;
+    const Slab &sB = a.xm ? *a.xm_slab() : a.s;
+    const bool cross = a.xm != nullptr;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nx = s.nxl, N = s.nyl, h = nx >> 1;
-    const size_t pp = (size_t)s.pitch * 16;
-    const size_t rowb = (size_t)s.rstride * 16;
-    char *const base = reinterpret_cast<char *>(s.F);
-    const int SR = a.sr, SW = a.sw;
+    const int nxg = sA.nxg, h = nxg >> 1;
+    const int wloc = sA.nxl;                                       // one rank: nx; x-slabs: the slab width w
     const double sgn = -1.0;                                       // (u, v): a vector
+    const int SR = a.sr, SW = a.sw;
     double *const X = lds;                                         // [strip][row 0..3][4][64]
     double *const U1 = X + 2048;                                   // [strip][row 0..3][u, v][64]     rows N-2 .. N+1
     double *const S1 = U1 + 1024;                                  // [strip][row 1..3][12][64]
     double *const V2 = S1 + 4608;                                  // [strip][row 1..2][u, v][64]
     const bool rw = (w < 4);
-    const int r = N - 2 + (rw ? w : 0);                            // this wave's row
-    char *const rb = base + (size_t)r * rowb;
-    auto wrapc = [&](int c) { int q = (c - 1) % nx; if (q < 0) q += nx; return q + 1; };
-    int ci[2];
+    const int wr = rw ? w : 0;
+    // per strip: slab, rows, addresses
+    const Slab *ss[2] = {&sA, &sB};
+    size_t pp[2], rowb[2];
+    char *base[2], *rb[2];
+    int r[2], Nn[2], ci[2], cl[2];
     unsigned lo[2];
+    bool okc[2], okm[2], own[2];
     unsigned char m[2] = {0, 0};
     double uc[2] = {0, 0}, vc[2] = {0, 0}, k1[2] = {0, 0}, k2[2] = {0, 0}, k5[2] = {0, 0}, k7[2] = {0, 0};
+    auto wrapc = [&](int c, int n) { int q = (c - 1) % n; if (q < 0) q += n; return q + 1; };
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        const int c = (t ? nx - 61 * k - 61 : 61 * k - 1) + lane;
-        ci[t] = wrapc(c);
+        const Slab &S = *ss[t];
+        pp[t] = (size_t)S.pitch * 16; rowb[t] = (size_t)S.rstride * 16;
+        base[t] = reinterpret_cast<char *>(S.F);
+        Nn[t] = S.nyl;
+        r[t] = Nn[t] - 2 + wr;
+        rb[t] = base[t] + (size_t)r[t] * rowb[t];
+        const int cA = cross ? 61 * k - a.G : 61 * k - 1;           // lane 0 of strip A (lane 1 = first stored column)
+        const int c = (t ? wloc - cA - 62 : cA) + lane;
+        cl[t] = c;
+        if (cross) {
+            okc[t] = (c >= 1 - ZW_MAX && c <= wloc + ZW_MAX);
+            okm[t] = (c - 1 >= 1 - ZW_MAX && c - 1 <= wloc + ZW_MAX);
+            ci[t] = okc[t] ? c : 1;
+            own[t] = (lane >= 1 && lane <= 61 && c >= 1 - a.G && c <= wloc + a.G);
+        } else {
+            okc[t] = okm[t] = true;
+            ci[t] = wrapc(c, wloc);
+            own[t] = (lane >= 1 && lane <= 61);
+        }
         lo[t] = (unsigned)(C0 + ci[t]) * 16u;
     }
 
@@ -1658,19 +1690,24 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
     if (rw) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const unsigned lom = (unsigned)(C0 + wrapc(ci[t] - 1)) * 16u;
-            m[t] = s.cmask[(size_t)r * s.pitch + C0 + ci[t]];
-            const double2 q0 = ldp(rb, pp, SR + S_U, lo[t]), q1 = ldp(rb, pp, SR + S_U, lom);
-            const char *rs = rb - rowb;
-            const double2 q2 = ldp(rs, pp, SR + S_U, lo[t]), q3 = ldp(rs, pp, SR + S_U, lom);
+            const Slab &S = *ss[t];
+            const int cm = cross ? (okm[t] ? cl[t] - 1 : 1) : wrapc(ci[t] - 1, wloc);
+            const unsigned lom = (unsigned)(C0 + cm) * 16u;
+            double2 q0 = make_double2(0, 0), q1 = q0, q2 = q0, q3 = q0;
+            const char *rs = rb[t] - rowb[t];
+            if (okc[t]) {
+                m[t] = S.cmask[(size_t)r[t] * S.pitch + C0 + ci[t]];
+                q0 = ldp(rb[t], pp[t], SR + S_U, lo[t]); q2 = ldp(rs, pp[t], SR + S_U, lo[t]);
+            }
+            if (okm[t]) { q1 = ldp(rb[t], pp[t], SR + S_U, lom); q3 = ldp(rs, pp[t], SR + S_U, lom); }
             uc[t] = q0.x; vc[t] = q0.y;
             const bool tact = (m[t] & CM_T) != 0;
             Str8 o{0, 0, 0, 0, 0, 0, 0, 0};
             Sig g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (__any(tact)) {
                 if (tact) {
-                    const TMet mt = load_tmet(rb, pp, lo[t]);
-                    g = load_sig(rb, pp, SR, lo[t]);
+                    const TMet mt = load_tmet(rb[t], pp[t], lo[t]);
+                    g = load_sig(rb[t], pp[t], SR, lo[t]);
                     Diag dg;
                     stress_cell<false>(mt, q0.x, q1.x, q2.x, q3.x, q0.y, q1.y, q2.y, q3.y, a.ecci, a.arlx1i, a.denom1, 0.0, g, o, dg);
                 }
@@ -1693,12 +1730,12 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             double u1 = uc[t], v1 = vc[t];                          // an inactive cell keeps its velocity
-            const bool uact = (m[t] & CM_U) != 0 && r >= 1 && r <= N;
+            const bool uact = (m[t] & CM_U) != 0 && r[t] >= 1 && r[t] <= Nn[t];
             if (__any(uact)) {
                 if (uact) {
-                    const UStat q = load_ustat(rb, pp, lo[t]);
+                    const UStat q = load_ustat(rb[t], pp[t], lo[t]);
                     double ui = 0.0, vi = 0.0, sxi, syi;
-                    if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo[t]); ui = iv.x; vi = iv.y; }
+                    if (REVP) { const double2 iv = ldp(rb[t], pp[t], F_UVEL_INIT, lo[t]); ui = iv.x; vi = iv.y; }
                     const double *Xn = X + (size_t)((t * 4 + w + 1) * 4) * 64 + lane;      // the T row above
                     stepu_cell(q, uc[t], vc[t], ui, vi, ((k1[t] + k2[t]) + Xn[0]) + Xn[128], ((k5[t] + Xn[64]) + k7[t]) + Xn[192],
                                a.brlx, a.revp, a.cosw, a.sinw, u1, v1, sxi, syi);
@@ -1710,17 +1747,20 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
     }
     __syncthreads();
 
+    // global column of this lane in strip t (for the roles in the fold)
+    auto gcol = [&](int t) { return wrapc(ss[t]->i0 + cl[t] - 1, nxg); };
+
     // ---------------- fold 1 (k_halo_tripole_ne1's arithmetic): waves 0, 1 <-> strips A, B; lanes 0 .. 62 ----------------
     {
         double tu = 0, tv = 0, gu = 0, gv = 0;
         const bool f1 = (w < 2) && lane <= 62;
         if (f1) {
-            const int t = w, g = ci[t];
+            const int t = w, g = gcol(t);
             const double *Ut = U1 + (size_t)((t * 4 + 2) * 2) * 64 + lane;                  // my top row
             const double *Um = U1 + (size_t)(((1 - t) * 4 + 2) * 2) * 64 + (62 - lane);     // the mirror column's top row
             const double *Rm = U1 + (size_t)(((1 - t) * 4 + 1) * 2) * 64 + (62 - lane);     // ... and its row N-1
             const double Tu = Ut[0], Tv = Ut[64], Mu = Um[0], Mv = Um[64];
-            if (g == nx || g == h) { tu = sgn * Tu; tv = sgn * Tv; }
+            if (g == nxg || g == h) { tu = sgn * Tu; tv = sgn * Tv; }
             else if (g < h) { tu = sgn * (sgn * (0.5 * (Tu + sgn * Mu))); tv = sgn * (sgn * (0.5 * (Tv + sgn * Mv))); }
             else { tu = sgn * (0.5 * (Mu + sgn * Tu)); tv = sgn * (0.5 * (Mv + sgn * Tv)); }
             gu = sgn * Rm[0]; gv = sgn * Rm[64];
@@ -1746,18 +1786,18 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
                     const double *Uq = U1 + (size_t)((t * 4 + w) * 2) * 64 + lane, *Us = Uq - 128;
                     const double *Sq = S1 + (size_t)((t * 3 + (w - 1)) * 12) * 64 + lane;
                     Sig g{Sq[0], Sq[64], Sq[128], Sq[192], Sq[256], Sq[320], Sq[384], Sq[448], Sq[512], Sq[576], Sq[640], Sq[704]};
-                    const TMet mt = load_tmet(rb, pp, lo[t]);
+                    const TMet mt = load_tmet(rb[t], pp[t], lo[t]);
                     double tarear = 0.0;
-                    if (LAST2) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo[t] + (F_TAREAR & 1) * 8);
+                    if (LAST2) tarear = *reinterpret_cast<const double *>(rb[t] + (size_t)(F_TAREAR >> 1) * pp[t] + lo[t] + (F_TAREAR & 1) * 8);
                     Diag dg;
                     stress_cell<LAST2>(mt, Uq[0], Uq[-1], Us[0], Us[-1], Uq[64], Uq[63], Us[64], Us[63], a.ecci, a.arlx1i, a.denom1, tarear, g, o, dg);
-                    if (lane <= 61) {
-                        store_sig(rb, pp, SW, lo[t], g);
-                        if (ci[t] == 1) store_sig(rb, pp, SW, lo[t] + (unsigned)nx * 16u, g);     // east ghost T column = image of column 1
+                    if (own[t]) {
+                        store_sig(rb[t], pp[t], SW, lo[t], g);
+                        if (!cross && ci[t] == 1) store_sig(rb[t], pp[t], SW, lo[t] + (unsigned)wloc * 16u, g);     // east ghost T column = image of column 1
                         if (LAST2) {
-                            st1(rb, pp, F_DIVU, lo[t], dg.divu);       st1(rb, pp, F_RDGCONV, lo[t], dg.rdg_conv);
-                            st1(rb, pp, F_RDGSHEAR, lo[t], dg.rdg_shear); st1(rb, pp, F_SHEAR, lo[t], dg.shear);
-                            st1(rb, pp, F_PRSSIG, lo[t], dg.prs);
+                            st1(rb[t], pp[t], F_DIVU, lo[t], dg.divu);       st1(rb[t], pp[t], F_RDGCONV, lo[t], dg.rdg_conv);
+                            st1(rb[t], pp[t], F_RDGSHEAR, lo[t], dg.rdg_shear); st1(rb[t], pp[t], F_SHEAR, lo[t], dg.shear);
+                            st1(rb[t], pp[t], F_PRSSIG, lo[t], dg.prs);
                         }
                     }
                 }
@@ -1780,18 +1820,20 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
             const bool uact = (m[t] & CM_U) != 0 && lane >= 1 && lane <= 61;       // (r <= N)
             if (__any(uact)) {
                 if (uact) {
-                    const UStat q = load_ustat(rb, pp, lo[t]);
+                    const UStat q = load_ustat(rb[t], pp[t], lo[t]);
                     double ui = 0.0, vi = 0.0, sxi, syi;
-                    if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo[t]); ui = iv.x; vi = iv.y; }
+                    if (REVP) { const double2 iv = ldp(rb[t], pp[t], F_UVEL_INIT, lo[t]); ui = iv.x; vi = iv.y; }
                     const double *Xn = X + (size_t)((t * 4 + w + 1) * 4) * 64 + lane;
                     stepu_cell(q, u1, v1, ui, vi, ((k1[t] + k2[t]) + Xn[0]) + Xn[128], ((k5[t] + Xn[64]) + k7[t]) + Xn[192],
                                a.brlx, a.revp, a.cosw, a.sinw, u2, v2, sxi, syi);
-                    if (w == 1) {                                   // row N-1 is final; row N goes through the fold below
-                        stp(rb, pp, SW + S_U, lo[t], u2, v2);
-                        if (ci[t] == 1) stp(rb, pp, SW + S_U, lo[t] + (unsigned)nx * 16u, u2, v2);
-                        if (ci[t] == nx) stp(rb, pp, SW + S_U, lo[t] - (unsigned)nx * 16u, u2, v2);
+                    if (w == 1 && own[t]) {                         // row N-1 is final; row N goes through the fold below
+                        stp(rb[t], pp[t], SW + S_U, lo[t], u2, v2);
+                        if (!cross) {
+                            if (ci[t] == 1) stp(rb[t], pp[t], SW + S_U, lo[t] + (unsigned)wloc * 16u, u2, v2);
+                            if (ci[t] == wloc) stp(rb[t], pp[t], SW + S_U, lo[t] - (unsigned)wloc * 16u, u2, v2);
+                        }
                     }
-                    if (LAST2) { st1(rb, pp, F_STRINTX, lo[t], sxi); st1(rb, pp, F_STRINTY, lo[t], syi); }
+                    if (LAST2 && own[t]) { st1(rb[t], pp[t], F_STRINTX, lo[t], sxi); st1(rb[t], pp[t], F_STRINTY, lo[t], syi); }
                 }
             }
             double *const Vq = V2 + (size_t)((t * 2 + (w - 1)) * 2) * 64 + lane;
@@ -1802,21 +1844,25 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
 
     // ---------------- fold 2: rows N and N+1 of the new state, lanes 1 .. 61 ----------------
     if (w < 2 && lane >= 1 && lane <= 61) {
-        const int t = w, g = ci[t];
+        const int t = w, g = gcol(t);
         const double *Vt = V2 + (size_t)((t * 2 + 1) * 2) * 64 + lane;
         const double *Vm = V2 + (size_t)(((1 - t) * 2 + 1) * 2) * 64 + (62 - lane);
         const double *Rm = V2 + (size_t)(((1 - t) * 2 + 0) * 2) * 64 + (62 - lane);
         const double Tu = Vt[0], Tv = Vt[64], Mu = Vm[0], Mv = Vm[64];
         double tu, tv;
-        if (g == nx || g == h) { tu = sgn * Tu; tv = sgn * Tv; }
+        if (g == nxg || g == h) { tu = sgn * Tu; tv = sgn * Tv; }
         else if (g < h) { tu = sgn * (sgn * (0.5 * (Tu + sgn * Mu))); tv = sgn * (sgn * (0.5 * (Tv + sgn * Mv))); }
         else { tu = sgn * (0.5 * (Mu + sgn * Tu)); tv = sgn * (0.5 * (Mv + sgn * Tv)); }
         const double gu = sgn * Rm[0], gv = sgn * Rm[64];
-        char *const rN = base + (size_t)N * rowb, *const rG = rN + rowb;
-        stp(rN, pp, SW + S_U, lo[t], tu, tv);
-        stp(rG, pp, SW + S_U, lo[t], gu, gv);
-        if (g == 1) { stp(rN, pp, SW + S_U, lo[t] + (unsigned)nx * 16u, tu, tv); stp(rG, pp, SW + S_U, lo[t] + (unsigned)nx * 16u, gu, gv); }
-        if (g == nx) { stp(rN, pp, SW + S_U, lo[t] - (unsigned)nx * 16u, tu, tv); stp(rG, pp, SW + S_U, lo[t] - (unsigned)nx * 16u, gu, gv); }
+        if (own[t]) {
+            char *const rN = base[t] + (size_t)Nn[t] * rowb[t], *const rG = rN + rowb[t];
+            stp(rN, pp[t], SW + S_U, lo[t], tu, tv);
+            stp(rG, pp[t], SW + S_U, lo[t], gu, gv);
+            if (!cross) {
+                if (ci[t] == 1) { stp(rN, pp[t], SW + S_U, lo[t] + (unsigned)wloc * 16u, tu, tv); stp(rG, pp[t], SW + S_U, lo[t] + (unsigned)wloc * 16u, gu, gv); }
+                if (ci[t] == wloc) { stp(rN, pp[t], SW + S_U, lo[t] - (unsigned)wloc * 16u, tu, tv); stp(rG, pp[t], SW + S_U, lo[t] - (unsigned)wloc * 16u, gu, gv); }
+            }
+        }
     }
 }
 
@@ -2301,6 +2347,44 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
         if (flags) flags[sid] = b ? 1 : 0;
         if (count && b) atomicAdd(count, 1u);
     }
+}
+
+// ---- rows of pair planes <-> a message, for the mirror slab M of band_pair (x-slab ranks, tripole): pair planes L.f[0 .. np)
+// (even field ids), rows r0 .. r0+nr-1, columns 1-ZW_MAX .. nxl+ZW_MAX (ncol of them), then (mask != 0) the cmask bytes of the
+// same rows and columns.  Message layout: double2 [np][nr][ncol], bytes [nr][ncol]. ----
+struct XbList { int f[16]; int np; };
+__global__ void k_xband_pack(Slab s, XbList L, int r0, int nr, int mask, double2 *msg) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ncol = s.nxl + 2 * ZW_MAX;
+    if (x >= ncol) return;
+    const int y = blockIdx.y, c = 1 - ZW_MAX + x;
+    if (y < L.np * nr) {
+        const int p = y / nr, k = y - p * nr;
+        msg[(size_t)y * ncol + x] = *reinterpret_cast<const double2 *>(&FD(s, L.f[p], cell(s, c, r0 + k)));
+    } else if (mask) {
+        const int k = y - L.np * nr;
+        reinterpret_cast<unsigned char *>(msg + (size_t)L.np * nr * ncol)[(size_t)k * ncol + x] = s.cmask[mcell(s, c, r0 + k)];
+    }
+}
+__global__ void k_xband_unpack(Slab m, XbList L, int r0, int nr, int mask, const double2 *msg) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ncol = m.nxl + 2 * ZW_MAX;
+    if (x >= ncol) return;
+    const int y = blockIdx.y, c = 1 - ZW_MAX + x;
+    if (y < L.np * nr) {
+        const int p = y / nr, k = y - p * nr;
+        *reinterpret_cast<double2 *>(&FD(m, L.f[p], cell(m, c, r0 + k))) = msg[(size_t)y * ncol + x];
+    } else if (mask) {
+        const int k = y - L.np * nr;
+        m.cmask[mcell(m, c, r0 + k)] = reinterpret_cast<const unsigned char *>(msg + (size_t)L.np * nr * ncol)[(size_t)k * ncol + x];
+    }
+}
+
+// rows j0 .. j1 of nf fields of the mirror slab, every column it has (ghost zones included): fdst <- fsrc
+__global__ void k_xband_rows_copy(Slab m, int fsrc, int fdst, int nf, int j0, int j1) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ncol = m.nxl + 2 * ZW_MAX;
+    const int j = j0 + blockIdx.y;
+    if (x >= ncol || j > j1) return;
+    const size_t k = cell(m, 1 - ZW_MAX + x, j);
+    for (int q = 0; q < nf; q++) FD(m, fdst + q, k) = FD(m, fsrc + q, k);
 }
 
 // the list of flagged strips, in order, and its length -- on the device, so that evpk_prep need not wait for the flags, compact

@@ -82,7 +82,7 @@
          integer (c_int64_t) :: zone_bytes
          integer (c_int32_t) :: overlap_split, tile_kernel, kernel_timed, kernel2_timed
          real (c_float) :: bound_ms
-         integer (c_int32_t) :: bound_updates, compact_metrics, transport, reserved_
+         integer (c_int32_t) :: bound_updates, compact_metrics, transport, band_row_exchanges
       end type evpk_stats
 
       ! evpk_eap_state (include/evpk.h): the structure tensor at the four corners, its cell means, the EAP history fields

@@ -159,7 +159,8 @@ typedef struct {
     int32_t bound_updates;             /* ... and their number */
     int32_t compact_metrics;           /* 1: the kernels rebuild the eight metric planes from HTN / HTE (evpk_geom) */
     int32_t transport;                 /* EVPK_XP_*: what carries the exchanges between ranks */
-    int32_t reserved_;
+    int32_t band_row_exchanges;        /* x-slab ranks on a tripole grid: row messages with the mirror rank in the last evpk_subcycle call
+                                          (the fold itself runs inside the pair launches, band_pair) */
 } evpk_stats;
 
 enum { EVPK_XP_NONE = 0, EVPK_XP_RCCL = 1, EVPK_XP_SHM_RELAY = 2, EVPK_XP_IPC = 3, EVPK_XP_SELF = 4 };

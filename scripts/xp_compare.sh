@@ -12,5 +12,5 @@ import json,sys
 l=[x for x in sys.stdin.readlines() if x.startswith('{')]
 if not l: print('$ns $n ranks $xp: no result'); sys.exit(0)
 o=json.loads(l[-1]); c=o['config']
-print('%-8s %d ranks %-4s ms/evp=%.3f loop=%.3f transport=%s zone_cols=%d exchanges/evp=%d value=%.3e'%('$ns',$n,'$xp',o['ms_per_step'],o['roofline']['loop_ms_per_step'],c['transport'],c['ghost_zone_cols'],c['zone_exchanges_per_evp'],o['value'] or 0))"
+print('%-8s %d ranks %-4s ms/evp=%.3f loop=%.3f transport=%s zone_cols=%d exchanges/evp=%d+%d value=%.3e'%('$ns',$n,'$xp',o['ms_per_step'],o['roofline']['loop_ms_per_step'],c['transport'],c['ghost_zone_cols'],c['zone_exchanges_per_evp'],c.get('band_row_exchanges_per_evp',0),o['value'] or 0))"
 done; done; done
