@@ -230,7 +230,7 @@ struct evpk_ctx {
     unsigned char *tile_buf = nullptr;   // 6 tile-flag arrays: ice/dat x {A, B} (new / previous evp, swapped) + act_ice, act_any
     int tile_cur = 0;
     bool zone_mode = false;     // k_subcycle2 reads ghost zones filled by exchange_cols (x-slabs / forced exchange)
-    // Ghost zones are zW = 2*zM columns wide: a two-subcycle launch consumes two columns of validity per side, the zone
+    // Ghost zones are zW = 2*zM columns wide (2*zM + 1 when the tripole band runs between ranks: evpk_connect): a two-subcycle launch consumes two columns of validity per side, the zone
     // columns themselves are advanced redundantly, so the neighbours exchange once per zM launches (communication avoiding).
     int zW = 2, zM = 1;
     int zone_left = 0;          // launches the zones of the current state buffer are still good for
@@ -676,6 +676,7 @@ static int xband_swap(evpk_ctx *c, const XbList &L, int r0, int m0, int nr, int 
     const size_t ncol = (size_t)s.nxl + 2 * ZW_MAX;
     const size_t bytes = ((size_t)L.np * nr * ncol * sizeof(double2) + (mask ? (size_t)nr * ncol : 0) + 15) & ~(size_t)15;
     if (bytes > c->xb_cap) FAIL(c, "xband_swap: message larger than its buffer");
+    if (c->relay && bytes > c->relay->slot) FAIL(c, "shared-memory relay: band rows message larger than its slot");
     double2 *snd = c->xb_send, *rcv = c->xb_recv;
     if (c->ipc) {
         if (bytes > c->ipc->slot[ch] / 2) FAIL(c, "ipc transport: band rows message larger than its slot");
@@ -931,7 +932,9 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
         if (strncmp((const char *)unique_id, "EVPKSHM:", 8) == 0) {
             // test transport: host-staged relay through POSIX shared memory (several ranks on one GPU)
             const size_t slot = std::max<size_t>((size_t)2 * c->cslot * sizeof(double2),
-                                                 (size_t)c->max_nf * 2 * (size_t)s.nxg * sizeof(double)) + 4096;
+                                                 (size_t)c->max_nf * 2 * (size_t)s.nxg * sizeof(double)) + 4096 +
+                                (c->ns == EVPK_BND_TRIPOLE      // the band rows of xband_swap (equal slab widths, or no such message)
+                                     ? (size_t)(12 * 5 * sizeof(double2) + 5) * ((size_t)s.nxg / c->nranks + 1 + 2 * ZW_MAX) : 0);
             c->relay = new ShmRelay();
             std::string err;
             if (c->relay->open(nm, c->rank, c->nranks, slot, err)) FAIL(c, "%s", err.c_str());
@@ -989,7 +992,9 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             // stage 2: receive buffers of identical layout on every rank -- per channel [2 parities][nranks sources][slot]
             IpcXp &x = *c->ipc;
             const size_t fold_msg = (size_t)c->max_nf * 2 * c->wmax * sizeof(double);
-            x.slot[0] = 2 * std::max<size_t>(c->cslot * sizeof(double2), fold_msg);
+            // (tripole: the band rows of xband_swap -- up to 12 pair planes x 5 rows + the mask bytes of a slab's columns and zones)
+            const size_t xb_msg = c->ns == EVPK_BND_TRIPOLE ? ((size_t)(12 * 5 * sizeof(double2) + 5) * ((size_t)c->wmax + 2 * ZW_MAX) + 64) & ~(size_t)15 : 0;
+            x.slot[0] = 2 * std::max<size_t>(std::max<size_t>(c->cslot * sizeof(double2), fold_msg), xb_msg);
             x.slot[1] = 2 * std::max<size_t>((size_t)c->max_nf * (s.nyl + 2) * sizeof(double), fold_msg);
             x.chan_off[0] = 0;
             x.chan_off[1] = 2 * (size_t)c->nranks * x.slot[0];
@@ -1070,6 +1075,12 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
         if (c->band_mode && !c->xband) m = 1;          // the fold is exchanged after every subcycle anyway
         c->zM = m; c->zW = 2 * m;
         if (c->xband) {
+            // the NE-corner fold maps my U column c to the partner's column w - c: the image of the zone [1-zW, w+zW] is
+            // [-zW, w+zW-1], one column short of the partner's zone on its west side, so the band rows lose ONE more column
+            // of validity on the east side than the rows below them (U valid up to w+zW-2k-1 after k pairs instead of
+            // w+zW-2k) -- zones of 2m+1 columns pay for it
+            m = std::min(m, (ZW_MAX - 1) / 2);
+            c->zM = m; c->zW = 2 * m + 1;
             c->xb_partner = c->nranks - 1 - c->rank;
             c->m = s;
             c->m.nyl = 4;                                          // rows 1 .. 4 <-> N-3 .. N of the partner, row 5 its north ghost row

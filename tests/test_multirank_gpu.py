@@ -100,6 +100,11 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
                 for name in util.ALL_CELLS + util.NE_CELLS + util.PHYS_CELLS:
                     ref.setdefault(name, np.zeros_like(f[name]))[n] = f1[name][n1]
             bad += [(call,) + x for x in util.compare(d, f, ref)]
+            if env.get("TEST_DEBUG_LOC") and bad:
+                for name in ("uvel", "stressp_1"):
+                    k = np.argwhere(f[name] != ref[name])
+                    loc = [(int(d.local_blocks[b].iglob_lo + i - (d.local_blocks[b].ilo - 1)), int(d.local_blocks[b].jglob_lo + j - (d.local_blocks[b].jlo - 1))) for b, j, i in k[:40]]
+                    print(f"rank {rank} call {call} {name}: {len(k)} cells differ at global (i, j): {sorted(set(loc))[:40]}", flush=True)
             if eap:
                 ne = util.cell_mask(d, "ne")
                 for name in synth.EAP_STATE + synth.EAP_HISTORY:
