@@ -1739,35 +1739,45 @@ extern "C" int evpk_eap_init(evpk_ctx *c, int32_t nx_yield, int32_t ny_yield, in
     const size_t nt = (size_t)nx_yield * ny_yield * na_yield, np = mask_elems(s);
     if (c->eap_tab) (void)hipFree(c->eap_tab);
     c->eap_tab = nullptr;
-    HIPCHK(c, hipMalloc(&c->eap_tab, sizeof(double) * 6 * nt));
-    const double *src[6] = {s11r, s12r, s22r, s11s, s12s, s22s};
-    for (int q = 0; q < 6; q++) {
-        HIPCHK(c, hipMemcpy(c->eap_tab + q * nt, src[q], sizeof(double) * nt, hipMemcpyHostToDevice));
-        c->E.tab[q] = c->eap_tab + q * nt;
+    HIPCHK(c, hipMalloc(&c->eap_tab, sizeof(double) * 8 * nt));
+    {   // entry q = {s11r, s12r, s22r, s11s, s12s, s22s, 0, 0}[q]: see EapDev
+        const double *src[6] = {s11r, s12r, s22r, s11s, s12s, s22s};
+        std::vector<double> inter(8 * nt, 0.0);
+        for (size_t q = 0; q < nt; q++)
+            for (int t = 0; t < 6; t++) inter[8 * q + t] = src[t][q];
+        HIPCHK(c, hipMemcpy(c->eap_tab, inter.data(), sizeof(double) * 8 * nt, hipMemcpyHostToDevice));
     }
+    c->E.tabs = c->eap_tab; c->E.nt = nt;
     c->E.nxy = nx_yield; c->E.nyy = ny_yield; c->E.nay = na_yield;
     c->E.invsin = eap_invsin();
+    eap_set_steps(c->E);
     if (!c->eap_pool) {
         HIPCHK(c, hipMalloc(&c->eap_pool, sizeof(double) * EAP_NPLANES * np));
         HIPCHK(c, hipMemsetAsync(c->eap_pool, 0, sizeof(double) * EAP_NPLANES * np, c->stream));
-        double *q = c->eap_pool;
-        for (int k = 0; k < 4; k++) { c->E.a11[k] = q; q += np; }
-        for (int k = 0; k < 4; k++) { c->E.a12[k] = q; q += np; }
-        for (int k = 0; k < 11; k++) { c->E.hist[k] = q; q += np; }
-        for (int k = 0; k < 8; k++) { c->E.str[k] = q; q += np; }
-        for (int k = 0; k < 4; k++) { c->E.ang[k] = (double4 *)q; q += 4 * np; }
+        c->E.pool = c->eap_pool; c->E.np = np;
         for (int k = 0; k < 4; k++)      // init_eap (:529-551): isotropic structure tensor
-            hipLaunchKernelGGL(k_fill_mplane, grid2d(s, B2D), B2D, 0, c->stream, s, c->E.a11[k], 0.5);
+            hipLaunchKernelGGL(k_fill_mplane, grid2d(s, B2D), B2D, 0, c->stream, s, c->E.a11(k), 0.5);
         hipLaunchKernelGGL(k_eap_angles, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->R > 8 && !getenv("EVPK_STRIP_ROWS")) {
+        // k_eap_sub is arithmetic-heavy and runs two waves per SIMD: strips of 8 rows give it three times the waves of the
+        // 16-row strips of evp's one-subcycle kernel (54.8 against 58.6 ms per eap at 3600x2700; 4 rows: 65 -- one redundant row each)
+        c->R = 8;
+        c->nry = (s.nyl + 1 + c->R - 1) / c->R;
+        (void)hipFree(c->d_flags); (void)hipFree(c->d_strips);
+        c->d_flags = nullptr; c->d_strips = nullptr;
+        HIPCHK(c, hipMalloc(&c->d_flags, (size_t)c->ncx * c->nry));
+        HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * (size_t)c->ncx * c->nry));
+        c->strips1_valid = false;
     }
     c->eap = true;
     return 0;
 }
 
 static double *eap_member(evpk_ctx *c, int q) {       // the planes in the order of evpk_eap_state's members
-    return q < 4 ? c->E.a11[q] : q < 8 ? c->E.a12[q - 4] : c->E.hist[q - 8];
+    return q < 4 ? c->E.a11(q) : q < 8 ? c->E.a12(q - 4) : c->E.hist(q - 8);
 }
 
 extern "C" int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st) {
@@ -1833,8 +1843,9 @@ static int eap_subcycle(evpk_ctx *c, int32_t nsub) {
     if (c->ksub == 0) hipLaunchKernelGGL(k_eap_reset, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);
     for (int n = 0; n < nsub; n++) {
         const int ksub = c->ksub + 1;
-        if (ksub == c->p.ndte) hipLaunchKernelGGL(k_eap_stress<true>, gT, B2D, 0, c->stream, s, c->E, SB, c->p.arlx1i, c->p.denom1);
-        else hipLaunchKernelGGL(k_eap_stress<false>, gT, B2D, 0, c->stream, s, c->E, SB, c->p.arlx1i, c->p.denom1);
+        const int hist = (ksub == c->p.ndte || n == nsub - 1) ? 1 : 0;      // the history fields of the call's last subcycle are the ones that can be seen
+        if (ksub == c->p.ndte) hipLaunchKernelGGL(k_eap_stress<true>, gT, B2D, 0, c->stream, s, c->E, SB, c->p.arlx1i, c->p.denom1, hist);
+        else hipLaunchKernelGGL(k_eap_stress<false>, gT, B2D, 0, c->stream, s, c->E, SB, c->p.arlx1i, c->p.denom1, hist);
         hipLaunchKernelGGL(k_eap_stepu, gU, B2D, 0, c->stream, s, c->E, c->p, SB);
         if (ksub % 10 == 1) hipLaunchKernelGGL(k_eap_stepa, gT, B2D, 0, c->stream, s, c->E, SB, dtei);     // :411-426
         if (halo(c, SB + S_U, 2, true, true, 0.0)) return 1;                                               // :431-439
@@ -1855,7 +1866,10 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     if (nsub < 0) FAIL(c, "nsub < 0");
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->eap) return eap_subcycle(c, nsub);
+    if (c->eap) {       // EVPK_EAP_FUSED=0: stress_eap and stepu as two launches with str(8) through memory, in place
+        const char *e = getenv("EVPK_EAP_FUSED");
+        if (e && atoi(e) == 0) return eap_subcycle(c, nsub);
+    }
     const bool wrap = (c->nranks == 1 && c->ew == EVPK_BND_CYCLIC && !c->force_exchange);
     const bool need_halo = (c->nranks > 1) || (c->ns == EVPK_BND_TRIPOLE) || c->force_exchange;
     c->kernel_ms = 0.f;
@@ -1902,6 +1916,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     const bool ov_trying = c->zone_mode && !c->band_mode && !c->ov_fixed && c->ksub == 0 && nsub == c->p.ndte;
     if (ov_trying) c->overlap = (c->ov_trial != 2);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->eap && c->ksub == 0) hipLaunchKernelGGL(k_eap_reset, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);   // ice_dyn_eap.F90:171-180, :284-298
     c->double_launches = 0;
     c->xb_swaps = 0;
     c->zone_exchanges = 0;
@@ -1943,7 +1958,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         // stream, no hand-overs; EVPK_BAND_FUSED=0 brings the launches on stream2 back
         const bool fused_band = c->band_mode && c->band_fused && wrap && (c->prefetch || c->tile_mode) && s.nyl >= 4;
         const bool xb = c->xband && !fused_band;
-        const bool pairs = c->use_double && (fused_band || !(c->band_mode && c->tile_mode && c->nranks == 1 && !c->force_exchange));
+        const bool pairs = c->use_double && !c->eap && (fused_band || !(c->band_mode && c->tile_mode && c->nranks == 1 && !c->force_exchange));
         const bool pair_inside = pairs && nsub - n >= 2 && c->ksub + 2 < c->p.ndte;
         // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
         // the LAST variant of k_subcycle)
@@ -2085,7 +2100,16 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
             const dim3 gt(c->nstrips), bt((c->R + 1) * 64);
             const size_t lds = (size_t)(c->R + 1) * 2048;
             if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
-            if (t1) {
+            if (c->eap) {       // eap(dt): stress_eap + stepu in one launch (k_eap_sub), stepa every tenth subcycle (ice_dyn_eap.F90:345-447)
+                EapSubArgs x{c->E, (last || n == nsub) ? 1 : 0};
+                if (last) hipLaunchKernelGGL(k_eap_sub<true>, g, b, 0, c->stream, a, x);
+                else hipLaunchKernelGGL(k_eap_sub<false>, g, b, 0, c->stream, a, x);
+                if (c->ksub % 10 == 1) {                                                    // :411-426
+                    const double dtei = 1.0 / (c->p.dt / (double)c->p.ndte);              // ice_dyn_shared.F90:209-210
+                    hipLaunchKernelGGL(k_eap_stepa, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 1 + 3) / 4), B2D, 0, c->stream, s, c->E, a.sw, dtei);
+                }
+            }
+            else if (t1) {
                 if (last && revp) hipLaunchKernelGGL((k_subcycle_t<true, true>), gt, bt, lds, c->stream, a);
                 else if (last) hipLaunchKernelGGL((k_subcycle_t<true, false>), gt, bt, lds, c->stream, a);
                 else if (revp) hipLaunchKernelGGL((k_subcycle_t<false, true>), gt, bt, lds, c->stream, a);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--xblocks", type=int, default=8)
     ap.add_argument("--yblocks", type=int, default=10)
     ap.add_argument("--cpu-grid", default="360x300", help="CPU sample (0 = skip)")
+    ap.add_argument("--calib", type=int, default=0, help="untimed calibration copies (1 GiB each way) for rocprofv3 --pmc runs")
     a = ap.parse_args()
     import torch
     from cice5_amd import blocks, constants as C, dyn, synth
@@ -49,6 +50,8 @@ def main():
     out = {"what": "eap(dt), state resident in HBM", "grid": a.grid, "ns": a.ns, "ndte": a.ndte, "ms_per_eap": round(ms, 3),
            "loop_ms": round(float(st.loop_ms), 3), "icellt": int(st.icellt), "icellu": int(st.icellu),
            "cell_updates_per_s": n_active * a.ndte / (ms * 1e-3)}
+    if a.calib:
+        ctx.calibrate(a.calib)
     s.close()
     if a.cpu_grid != "0":
         from oracle import orc

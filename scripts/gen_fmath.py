@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Constants of cice5_amd/csrc/evpk_fmath.h, derived with exact rational arithmetic (no libm): the three-part split of pi/2
-for the argument reduction of sin / cos, pi and pi/2 as hi + lo pairs, atan(k/8) as hi + lo pairs, Taylor coefficients.
+for the argument reduction of sin / cos, pi and pi/2 as hi + lo pairs, atan(k/16) as hi + lo pairs, Taylor coefficients.
 
     python scripts/gen_fmath.py          # prints the C initialisers
 """
@@ -83,13 +83,13 @@ def main():
     for name, v in (("PI", PI), ("PIO2", pio2)):
         hi, lo = hilo(v)
         print(f"#define EVPK_{name}_HI {hi!r}\n#define EVPK_{name}_LO {lo!r}")
-    print("/* atan(k/8), k = 0..8, hi + lo */")
-    his, los = [], []
-    for k in range(9):
-        hi, lo = hilo(atan_rat(F(k, 8)))
-        his.append(hi); los.append(lo)
-    print("static const double evpk_atan_hi[9] = {" + ", ".join(repr(v) for v in his) + "};")
-    print("static const double evpk_atan_lo[9] = {" + ", ".join(repr(v) for v in los) + "};")
+    print("/* atan(k/16), k = 0..16, {hi, lo} */")
+    rows = []
+    for k in range(17):
+        hi, lo = hilo(atan_rat(F(k, 16)))
+        rows.append((hi, lo))
+    his = [r[0] for r in rows]
+    print("static const double evpk_atan_tab[34] = {" + ", ".join(f"{hi!r}, {lo!r}" for hi, lo in rows) + "};")
     print("/* Taylor coefficients: sin r = r + r^3 (S[0] + r^2 (S[1] + ...)), cos r = 1 - r^2/2 + r^4 (C[0] + r^2 (C[1] + ...)), atan t = t + t^3 (A[0] + ...) */")
     S = [to_double(F((-1) ** (k + 1), math.factorial(2 * k + 3))) for k in range(8)]       # r^3 .. r^17
     C = [to_double(F((-1) ** k, math.factorial(2 * k + 4))) for k in range(8)]             # r^4 .. r^18
@@ -97,7 +97,7 @@ def main():
     for n, v in (("S", S), ("C", C), ("A", A)):
         print(f"static const double evpk_{n}[8] = {{" + ", ".join(repr(x) for x in v) + "};")
     # sanity against libm (not used for the constants)
-    assert abs(his[8] - math.atan(1.0)) < 1e-16 and abs(his[4] - math.atan(0.5)) < 1e-16
+    assert abs(his[16] - math.atan(1.0)) < 1e-16 and abs(his[8] - math.atan(0.5)) < 1e-16
     assert abs(float(p1) + float(p2) + p3 - math.pi / 2) < 1e-16
 
 

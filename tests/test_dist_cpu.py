@@ -303,3 +303,33 @@ def test_two_rank_ghost_zones_gloo(m):
             p.terminate()
     for rank, bad in res:
         assert not bad, f"rank {rank}: {bad}"
+
+
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_band_validity_between_mirror_ranks_needs_one_more_zone_column(m):
+    """Dependency model of band_pair between x-slab ranks (evpk_kernels.hip): which top-row U columns of a slab of width w
+    are still correct after m two-subcycle launches without a ghost-zone exchange, when the NE-corner fold takes column c
+    from the mirror rank's column w - c (serial/ice_boundary.F90:801-888).  T(c) reads U(c-1), U(c); U(c) reads T(c),
+    T(c+1); the fold after each subcycle reads the partner's column w - c.  With zones of 2m columns the slab's own
+    column w is lost (the image of the zone [1-zW, w+zW] is [-zW, w+zW-1]); 2m+1 columns keep 0 .. w (evpk_connect)."""
+    w = 40
+
+    def run(zW):
+        lo = 1 - zW
+        n = w + 2 * zW
+        ok = np.ones(n, bool)                       # U columns lo .. w+zW, both ranks alike (equal widths)
+
+        def sub(u):
+            t = np.zeros(n, bool); t[1:] = u[1:] & u[:-1]
+            un = np.zeros(n, bool); un[:-1] = t[:-1] & t[1:]
+            f = np.zeros(n, bool)
+            for k in range(n):
+                q = (w - (lo + k)) - lo             # index of the partner's column w - c
+                f[k] = un[k] and 0 <= q < n and un[q]
+            return f
+        for _ in range(2 * m):
+            ok = sub(ok)
+        return [lo + k for k in range(n) if ok[k]]
+    good = run(2 * m + 1)
+    assert set(range(0, w + 1)) <= set(good)
+    assert w not in run(2 * m)
