@@ -269,7 +269,9 @@ struct evpk_ctx {
     Slab *d_mslab = nullptr;
     double2 *xb_send = nullptr, *xb_recv = nullptr;
     size_t xb_cap = 0;
-    int xb_partner = -1, m_need = 5, xb_swaps = 0;
+    int xb_partner = -1, m_need = 1, xb_swaps = 0;     // m_need: the mirror slab's state must be fetched before the next pair launch
+    int *d_mstrips = nullptr;        // every strip of the mirror slab (its own advance between two refreshes), for (ms_R, ms_ncx)
+    int ms_R = 0, ms_ncx = 0, ms_n = 0;
     // strip list of the pair kernels compacted on the device (one rank, no ghost zones; EVPK_DEVICE_STRIPS=0: on the host):
     // evpk_prep then never waits for the GPU -- the kernels read the list's length from d_ns2, the host reads it (and the cell
     // counts) from page-locked memory once the loop's final event has completed
@@ -668,6 +670,10 @@ static int xp_check(evpk_ctx *c) {
     return 0;
 }
 
+// the mirror slab M of band_pair holds the mirror rank's top XB rows: nylM = max(4, 2 zM + 1) rows + its two ghost rows
+constexpr int XB_PLANES = 13;                                       // pair planes of the widest message (static fields of evpk_prep)
+constexpr int XB_ROWS_MAX = 2 * ((ZW_MAX - 1) / 2) + 1 + 2;         // nylM + 2 at the deepest zones
+
 // ---- rows r0 .. r0+nr-1 of the pair planes L (+ the mask bytes) of MY slab to the mirror rank, the mirror rank's into rows
 // m0 .. of the mirror slab M (band_pair): one swap with rank P-1-r over the context's transport ----
 static int xband_swap(evpk_ctx *c, const XbList &L, int r0, int m0, int nr, int mask, hipStream_t st) {
@@ -704,11 +710,11 @@ static int xband_swap(evpk_ctx *c, const XbList &L, int r0, int m0, int nr, int 
     HIPCHK(c, hipGetLastError());
     return 0;
 }
-// the state rows of buffer SB (u, v and the twelve stresses): the top `nr` of the five rows N-3 .. N+1 start at N-3
-static int xband_state(evpk_ctx *c, int SB, int nr, hipStream_t st) {
+// the state (u, v and the twelve stresses) of buffer SB: every row of M, ghost rows included <- the mirror rank's rows N-nylM .. N+1
+static int xband_state(evpk_ctx *c, int SB, hipStream_t st) {
     XbList L{};
     for (int q = 0; q < NSTATE / 2; q++) L.f[L.np++] = SB + 2 * q;
-    return xband_swap(c, L, c->s.nyl - 3, 1, nr, 0, st);
+    return xband_swap(c, L, c->s.nyl - c->m.nyl, 0, c->m.nyl + 2, 0, st);
 }
 
 // ---- halo update of nf consecutive planes starting at f ---------------------------------
@@ -898,7 +904,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->d_mstrips, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -934,7 +940,7 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             const size_t slot = std::max<size_t>((size_t)2 * c->cslot * sizeof(double2),
                                                  (size_t)c->max_nf * 2 * (size_t)s.nxg * sizeof(double)) + 4096 +
                                 (c->ns == EVPK_BND_TRIPOLE      // the band rows of xband_swap (equal slab widths, or no such message)
-                                     ? (size_t)(12 * 5 * sizeof(double2) + 5) * ((size_t)s.nxg / c->nranks + 1 + 2 * ZW_MAX) : 0);
+                                     ? (size_t)(XB_PLANES * XB_ROWS_MAX * sizeof(double2) + XB_ROWS_MAX) * ((size_t)s.nxg / c->nranks + 1 + 2 * ZW_MAX) : 0);
             c->relay = new ShmRelay();
             std::string err;
             if (c->relay->open(nm, c->rank, c->nranks, slot, err)) FAIL(c, "%s", err.c_str());
@@ -993,7 +999,7 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             IpcXp &x = *c->ipc;
             const size_t fold_msg = (size_t)c->max_nf * 2 * c->wmax * sizeof(double);
             // (tripole: the band rows of xband_swap -- up to 12 pair planes x 5 rows + the mask bytes of a slab's columns and zones)
-            const size_t xb_msg = c->ns == EVPK_BND_TRIPOLE ? ((size_t)(12 * 5 * sizeof(double2) + 5) * ((size_t)c->wmax + 2 * ZW_MAX) + 64) & ~(size_t)15 : 0;
+            const size_t xb_msg = c->ns == EVPK_BND_TRIPOLE ? ((size_t)(XB_PLANES * XB_ROWS_MAX * sizeof(double2) + XB_ROWS_MAX) * ((size_t)c->wmax + 2 * ZW_MAX) + 64) & ~(size_t)15 : 0;
             x.slot[0] = 2 * std::max<size_t>(std::max<size_t>(c->cslot * sizeof(double2), fold_msg), xb_msg);
             x.slot[1] = 2 * std::max<size_t>((size_t)c->max_nf * (s.nyl + 2) * sizeof(double), fold_msg);
             x.chan_off[0] = 0;
@@ -1070,7 +1076,7 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             bool eq = true;
             for (int r = 0; r < c->nranks; r++) eq = eq && (c->slab_i0[r + 1] - c->slab_i0[r] == s.nxl);
             c->xband = c->band_mode && c->nranks > 1 && (c->nranks % 2 == 0) && eq && c->prefetch && c->band_fused && !(xe && atoi(xe) == 0) &&
-                       s.nxl >= 2 * ZW_MAX && s.nyl >= 8;
+                       s.nxl >= 2 * ZW_MAX && s.nyl >= XB_ROWS_MAX + 1;
         }
         if (c->band_mode && !c->xband) m = 1;          // the fold is exchanged after every subcycle anyway
         c->zM = m; c->zW = 2 * m;
@@ -1083,7 +1089,12 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             c->zM = m; c->zW = 2 * m + 1;
             c->xb_partner = c->nranks - 1 - c->rank;
             c->m = s;
-            c->m.nyl = 4;                                          // rows 1 .. 4 <-> N-3 .. N of the partner, row 5 its north ghost row
+            // rows 1 .. nylM <-> the partner's rows N-nylM+1 .. N, rows 0 and nylM+1 the rows below / its north ghost row.  band_pair
+            // needs rows N-3 .. N+1; the rows below them are the ghost zone of the mirror slab IN Y: between two refreshes M is
+            // advanced here like a slab of its own (the pair kernel over its strips), every pair of subcycles costing two rows of
+            // validity from the bottom, so that one message per zM pairs -- sent together with the ghost-zone exchange --
+            // replaces the message per pair that the four-row M of the first version needed
+            c->m.nyl = std::max(4, 2 * m + 1);
             c->m.i0 = c->slab_i0[c->xb_partner];
             c->m.tmask = c->m.umask = c->m.iceumask = nullptr;
             c->m.tmphm = c->m.tile_ice = c->m.tile_dat = c->m.act_ice = c->m.act_any = nullptr;
@@ -1094,7 +1105,7 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             HIPCHK(c, hipMalloc(&c->d_mslab, sizeof(Slab)));
             HIPCHK(c, hipMemcpy(c->d_mslab, &c->m, sizeof(Slab), hipMemcpyHostToDevice));
             const size_t ncol = (size_t)s.nxl + 2 * ZW_MAX;
-            c->xb_cap = (12 * 5 * ncol * sizeof(double2) + 5 * ncol + 64) & ~(size_t)15;
+            c->xb_cap = ((size_t)XB_PLANES * (c->m.nyl + 2) * ncol * sizeof(double2) + (size_t)(c->m.nyl + 2) * ncol + 64) & ~(size_t)15;
             HIPCHK(c, hipMalloc(&c->xb_send, c->xb_cap));
             HIPCHK(c, hipMalloc(&c->xb_recv, c->xb_cap));
         }
@@ -1646,10 +1657,10 @@ extern "C" int evpk_prep(evpk_ctx *c) {
             // the masks (once per evp) and the state
             XbList L{};
             for (int f : {(int)F_CXP, (int)F_CXM, (int)F_DXT, (int)F_DXHY, (int)F_TINYAREA, (int)F_VRELC, (int)F_UOCN, (int)F_FORCEX, (int)F_UMASSDTI,
-                          (int)F_UVEL_INIT, (int)F_TAREAR})
-                L.f[L.np++] = f;
-            if (xband_swap(c, L, s.nyl - 3, 1, 5, 1, c->stream)) return 1;
-            if (xband_state(c, SA, 5, c->stream)) return 1;
+                          (int)F_UVEL_INIT, (int)F_TAREAR, (int)F_HTN})
+                L.f[L.np++] = f & ~1;
+            if (xband_swap(c, L, s.nyl - c->m.nyl, 0, c->m.nyl + 2, 1, c->stream)) return 1;
+            if (xband_state(c, SA, c->stream)) return 1;
             c->m_need = 0;
         }
     }
@@ -1939,7 +1950,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                          ((c->west >= 0 ? (c->zcompact ? c->zn[0] : s.nyl + 2) : 0) + (c->east >= 0 ? (c->zcompact ? c->zn[1] : s.nyl + 2) : 0));
         c->zone_left = c->zM;
         c->inner_ok = true;
-        c->m_need = 5;              // (x-slab tripole: the mirror rank's zone columns were refreshed too)
+        c->m_need = 1;              // (x-slab tripole: the mirror slab is due as well)
         return 0;
     };
     for (int n = 0; n < nsub;) {
@@ -1991,22 +2002,39 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 a.nband = (s.nxl / 2 + 1 + 60) / 61;          // strips A cover columns 0 .. nx/2, their mirror images the rest
                 a.jmax = s.nyl - 2;
             } else if (xb) {
-                // x-slab ranks: strip A of every band workgroup is mine, strip B the mirror rank's, read from the mirror slab M,
-                // which one row message keeps current (rows N-3, N-2: the mirror rank's main strips wrote them; rows N-1 .. N+1
-                // were computed here as well) -- all five rows after a ghost-zone exchange or a one-subcycle launch
+                // x-slab ranks: strip A of every band workgroup is mine, strip B the mirror rank's, read from the mirror slab M.
+                // M comes whole after a ghost-zone exchange or a one-subcycle launch (one message, m_need); between two such
+                // refreshes its rows below the band are advanced HERE by the pair kernel over M's own strips (two rows of
+                // validity less per pair, see evpk_connect) and the band rows by band_pair, on both ranks alike
                 if (join()) FAIL(c, "hipStreamWaitEvent failed");
                 if (c->m_need) {
                     bound_begin(c->stream);
-                    if (xband_state(c, a.sr, c->m_need, c->stream)) return 1;
+                    if (xband_state(c, a.sr, c->stream)) return 1;
                     bound_end(c->stream);
                     c->xb_swaps++;
+                    c->m_need = 0;
                 }
-                // (cells no lane stores are alike in both state buffers: the band rows of M's write buffer start from its read buffer)
-                hipLaunchKernelGGL(k_xband_rows_copy, dim3((s.nxl + 2 * ZW_MAX + 127) / 128, 3), dim3(128), 0, c->stream, c->m, a.sr, a.sw, (int)NSTATE, 3, 5);
+                // (cells no lane stores are alike in both state buffers: M's write buffer starts from its read buffer)
+                hipLaunchKernelGGL(k_xband_rows_copy, dim3((s.nxl + 2 * ZW_MAX + 127) / 128, c->m.nyl + 2), dim3(128), 0, c->stream, c->m, a.sr, a.sw,
+                                   (int)NSTATE, 0, c->m.nyl + 1);
+                if (c->zone_left > 1 && !pair_ends_evp) {      // another pair follows before the next refresh
+                    if (c->ms_R != c->R2 || c->ms_ncx != c->ncx2) {
+                        const int nry = (c->m.nyl + c->R2 - 1) / c->R2;
+                        std::vector<int> ms((size_t)c->ncx2 * nry);
+                        for (int k = 0; k < (int)ms.size(); k++) ms[k] = k;
+                        if (c->d_mstrips) (void)hipFree(c->d_mstrips);
+                        c->d_mstrips = nullptr;
+                        HIPCHK(c, hipMalloc(&c->d_mstrips, sizeof(int) * ms.size()));
+                        HIPCHK(c, hipMemcpy(c->d_mstrips, ms.data(), sizeof(int) * ms.size(), hipMemcpyHostToDevice));
+                        c->ms_R = c->R2; c->ms_ncx = c->ncx2; c->ms_n = (int)ms.size();
+                    }
+                    SubArgs bm = a;
+                    bm.s = c->m; bm.strips = c->d_mstrips; bm.nstrips = c->ms_n; bm.nsdev = nullptr; bm.jmax = c->m.nyl - 2;
+                    launch_sub2(c, bm, c->stream, revp, false);
+                }
                 a.xm = c->d_mslab;
                 a.nband = (s.nxl + 2 * G + 60) / 61;
                 a.jmax = s.nyl - 2;
-                c->m_need = 2;
             } else if (c->band_mode) {
                 b1.strips = c->d_band; b1.nstrips = c->ncx; b1.ncx = c->ncx; b1.wrap = wrap ? 1 : 0; b1.G = 0;
                 b1.R = 4; b1.jb0 = s.nyl - 2; b1.sw = F_STATE2;
@@ -2130,7 +2158,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
             bound_end(c->stream);
         }
         if (c->zone_mode) { c->zone_left = 0; c->inner_ok = true; }     // one ghost column is current, the deeper zone is not
-        c->m_need = 5;
+        c->m_need = 1;
     }
     if (join()) FAIL(c, "hipStreamWaitEvent failed");
     // leave the ghost columns 0 / nxl+1 of the state current (download, finish, a later one-subcycle launch)

@@ -333,3 +333,27 @@ def test_band_validity_between_mirror_ranks_needs_one_more_zone_column(m):
     good = run(2 * m + 1)
     assert set(range(0, w + 1)) <= set(good)
     assert w not in run(2 * m)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_mirror_slab_depth_for_m_pairs_without_a_refresh(m):
+    """Dependency model in y of the mirror slab M of band_pair (evpk_connect): M holds the mirror rank's rows N-nylM .. N+1
+    (local rows 0 .. nylM+1) and is advanced here between two refreshes.  T(j) reads U(j-1), U(j); U(j) reads T(j), T(j+1);
+    the top rows are kept by the band.  Every pair of subcycles costs two rows from the bottom, and the band of pair k+1 needs
+    the rows nylM-3 .. nylM+1 the pair k left: nylM = 2m+1 rows carry m pairs, 2m do not."""
+    def pairs_supported(nylM):
+        ok = np.ones(nylM + 2, bool)                                 # rows 0 .. nylM+1 after a refresh
+        n = 0
+        while ok[max(nylM - 3, 0):].all():                           # the band can run this pair
+            n += 1
+            for _ in range(2):
+                t = np.zeros_like(ok); t[1:] = ok[1:] & ok[:-1]
+                u = np.zeros_like(ok); u[:-1] = t[:-1] & t[1:]
+                u[nylM - 1:] = True                                  # rows N-1 .. N+1: band_pair (both ranks compute them)
+                ok = u
+            if n > 10:
+                break
+        return n
+    assert pairs_supported(max(4, 2 * m + 1)) >= m
+    if m >= 2:
+        assert pairs_supported(2 * m) < m
