@@ -1772,17 +1772,6 @@ extern "C" int evpk_eap_init(evpk_ctx *c, int32_t nx_yield, int32_t ny_yield, in
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    if (c->R > 8 && !getenv("EVPK_STRIP_ROWS")) {
-        // k_eap_sub is arithmetic-heavy and runs two waves per SIMD: strips of 8 rows give it three times the waves of the
-        // 16-row strips of evp's one-subcycle kernel (54.8 against 58.6 ms per eap at 3600x2700; 4 rows: 65 -- one redundant row each)
-        c->R = 8;
-        c->nry = (s.nyl + 1 + c->R - 1) / c->R;
-        (void)hipFree(c->d_flags); (void)hipFree(c->d_strips);
-        c->d_flags = nullptr; c->d_strips = nullptr;
-        HIPCHK(c, hipMalloc(&c->d_flags, (size_t)c->ncx * c->nry));
-        HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * (size_t)c->ncx * c->nry));
-        c->strips1_valid = false;
-    }
     c->eap = true;
     return 0;
 }

@@ -18,13 +18,13 @@
 
 namespace evpk {
 
-constexpr int EAP_NPLANES = 8 + 11 + 8 + 16;      // a11_c, a12_c; history; str; the angles (4 double4 planes)
+constexpr int EAP_NPLANES = 8 + 11 + 8 + 8;       // a11_c, a12_c; history; str; the angles (4 double2 planes)
 struct EapDev {
     // the yield-curve tables s11r, s12r, s22r, s11s, s12s, s22s interleaved: entry [na][ny][nx] = eight doubles (six values + two of
     // padding, 64 bytes) -- a lookup of update_stress_rdg is a gather over a 2.3 MB table, and one cache line per lane and
     // corner instead of six is what the L2 -> L1 path can carry; the planes of the
     // extra state, np elements each (mask-plane indexing), one after the other: a11_1..4, a12_1..4, the eleven history fields,
-    // str(8), then per corner a double4 plane of angles.  One base pointer each: forty plane pointers as kernel arguments
+    // str(8), then per corner a double2 plane of angles.  One base pointer each: forty plane pointers as kernel arguments
     // would not fit the scalar registers.
     const double *tabs;
     double *pool;
@@ -37,9 +37,10 @@ struct EapDev {
     // a11, a12, e11, e12, e22, yieldstress11, yieldstress12, yieldstress22, s11, s12, s22
     __host__ __device__ double *hist(int h) const { return pool + (size_t)(8 + h) * np; }
     __host__ __device__ double *str(int k) const { return pool + (size_t)(19 + k) * np; }
-    // per corner {gamma, cos gamma, sin gamma, a'}: functions of (a11, a12) only, which change every tenth subcycle (stepa) --
-    // kept instead of recomputed in every stress_eap (eap_tensor_angles)
-    __host__ __device__ double4 *ang(int c) const { return reinterpret_cast<double4 *>(pool + (size_t)(27 + 4 * c) * np); }
+    // per corner {gamma, a'}: functions of (a11, a12) only, which change every tenth subcycle (stepa) -- kept instead of recomputed
+    // in every stress_eap (eap_tensor_angles: an atan2 and the tensor rotation); cos gamma, sin gamma are NOT kept: one sincos per
+    // corner is cheaper than the 64 B per cell they cost now that the kernel is bound by its loads, and gives the same bits
+    __host__ __device__ double2 *ang(int c) const { return reinterpret_cast<double2 *>(pool + (size_t)(27 + 2 * c) * np); }
 };
 enum { EH_A11 = 0, EH_A12, EH_E11, EH_E12, EH_E22, EH_Y11, EH_Y12, EH_Y22, EH_S11, EH_S12, EH_S22 };
 
@@ -64,7 +65,7 @@ static inline void eap_set_steps(EapDev &E) {
 }
 
 // ---- update_stress_rdg (:1474-1658), first part (:1528-1545): the principal axis of the structure tensor ----
-__device__ __forceinline__ double4 eap_tensor_angles(double a11, double a12) {
+__device__ __forceinline__ double2 eap_tensor_angles(double a11, double a12) {
     const double a22 = 1.0 - a11;
     const double gamma = 0.5 * evpk_atan2((2.0 * a12), (a11 - a22));
     double Q11, Q12;
@@ -72,16 +73,18 @@ __device__ __forceinline__ double4 eap_tensor_angles(double a11, double a12) {
     const double Q11Q11 = Q11 * Q11, Q11Q12 = Q11 * Q12, Q12Q12 = Q12 * Q12;
     double atempprime = Q11Q11 * a11 + 2.0 * Q11Q12 * a12 + Q12Q12 * a22;
     atempprime = fmax(atempprime, 1.0 - atempprime);
-    return make_double4(gamma, Q11, Q12, atempprime);
+    return make_double2(gamma, atempprime);
 }
 
 // ---- update_stress_rdg (:1474-1658), the rest ----
 template <bool LAST>
-__device__ __forceinline__ void eap_update_stress_rdg(const EapDev &E, double divu, double tension, double shear, double4 ang, double strength,
+__device__ __forceinline__ void eap_update_stress_rdg(const EapDev &E, double divu, double tension, double shear, double2 ang, double strength,
                                                       double &stressp, double &stressm, double &stress12, double &alphar) {
     const double kfriction = 0.45;
     const double invsin = E.invsin;
-    const double gamma = ang.x, Q11 = ang.y, Q12 = ang.z, atempprime = ang.w;
+    const double gamma = ang.x, atempprime = ang.y;
+    double Q11, Q12;
+    evpk_sincos(gamma, &Q12, &Q11);                                                   // :1533-1534
     const double Q11Q11 = Q11 * Q11, Q11Q12 = Q11 * Q12, Q12Q12 = Q12 * Q12;
     const double dtemp11 = 0.5 * (divu + tension), dtemp12 = shear * 0.5, dtemp22 = 0.5 * (divu - tension);
     double alpha = 0.5 * evpk_atan2((2.0 * dtemp12), (dtemp11 - dtemp22));
@@ -92,13 +95,13 @@ __device__ __forceinline__ void eap_update_stress_rdg(const EapDev &E, double di
     evpk_sincos(alpha, &Qd12, &Qd11);
     double dtemp1 = Qd11 * (Qd11 * dtemp11 + 2.0 * Qd12 * dtemp12) + Qd12 * Qd12 * dtemp22;
     double dtemp2 = Qd12 * (Qd12 * dtemp11 - 2.0 * Qd11 * dtemp12) + Qd11 * Qd11 * dtemp22;
-    double x = 0.0;
-    if (fabs(dtemp1) > EAP_PUNY || fabs(dtemp2) > EAP_PUNY) {
-        const double invleng = 1.0 / sqrt(dtemp1 * dtemp1 + dtemp2 * dtemp2);
-        dtemp1 = dtemp1 * invleng;
-        dtemp2 = dtemp2 * invleng;
-        x = evpk_atan2(dtemp2, dtemp1);
-    }
+    // (:1561-1569, as straight-line code: the branch not taken computes with 1/0 at worst and is dropped by the select)
+    const bool nz = fabs(dtemp1) > EAP_PUNY || fabs(dtemp2) > EAP_PUNY;
+    const double invleng = 1.0 / sqrt(dtemp1 * dtemp1 + dtemp2 * dtemp2);
+    dtemp1 = nz ? dtemp1 * invleng : dtemp1;
+    dtemp2 = nz ? dtemp2 * invleng : dtemp2;
+    const double xa = evpk_atan2(dtemp2, dtemp1);
+    double x = nz ? xa : 0.0;
     if (x < EAP_PIQ) x = x + EAP_PI2;
     const double invdx = E.invdx, invdy = E.invdy, invda = E.invda;      // (:1580-1585, wave-uniform: evaluated once on the host, eap_set_steps)
     int kx = (int)((x - EAP_PIQ - EAP_PI) * invdx) + 1;
@@ -137,7 +140,7 @@ __global__ void k_eap_reset(Slab s, EapDev E) {
     (void)k;
     const bool tact = (s.cmask[km] & CM_T) != 0;
     if (!tact) {
-        const double4 iso = eap_tensor_angles(0.5, 0.0);
+        const double2 iso = eap_tensor_angles(0.5, 0.0);
 #pragma unroll
         for (int c = 0; c < 4; c++) { E.a11(c)[km] = 0.5; E.a12(c)[km] = 0.0; E.ang(c)[km] = iso; }
 #pragma unroll
@@ -344,14 +347,16 @@ __global__ void __launch_bounds__(256) k_eap_stepa(Slab s, EapDev E, int SB, dou
 // of four U cells that other waves update in the same launch.  The history fields (strain rates, yield stresses, mean
 // stresses: nine planes, 72 B per cell) and prs_sig are overwritten by every subcycle in the reference; only the values of the
 // last subcycle of a call can be observed, so they are stored when a.hist says so (evpk_subcycle's last subcycle).
-// Measured at 3600x2700 (profiles/r03_v5/eap_fused): 0.40 ms per launch at R = 8 against 0.33 + 0.10 for the two kernels, 39 % VALU,
-// 45 % of the HBM peak, 196 VGPRs = two waves per SIMD (forcing three costs 22 spilled registers and 14 % more time).
+// Measured at 3600x2700 (profiles/r03_v5): with sin / cos / atan2 and the normalisation of update_stress_rdg written as
+// straight-line code (selects instead of branches: 50 -> 18 branches in the loop body, the four corners of a cell interleave)
+// the kernel needs 160 VGPRs instead of 196; compiled for four waves per SIMD (128 VGPRs, 10 spilled) it runs 46.6-48.3 ms per
+// eap against 48.4-51.0 at three waves and 54.8 before (same box, strips of 8 or 16 rows alike).
 // stepa (every tenth subcycle) stays a launch of its own after this one: it rewrites the angles that the redundant row and
 // column of the neighbouring strips read in the same launch.
 // ------------------------------------------------------------------------------------
 struct EapSubArgs { EapDev E; int hist; };
 template <bool LAST>
-__global__ __launch_bounds__(256) void k_eap_sub(SubArgs a, EapSubArgs x) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_eap_sub(SubArgs a, EapSubArgs x) {
     const Slab &s = a.s;
     const EapDev &E = x.E;
     const int lane = threadIdx.x & 63;

@@ -42,12 +42,10 @@ EVPK_HD void evpk_sincos(double x, double *sn, double *cs) {
     const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1), C0);
     const double s = fma(r * z, ps, r);
     const double c = 1.0 - fma(-(z * z), pc, 0.5 * z);
-    switch (n & 3) {
-    case 0: *sn = s; *cs = c; break;
-    case 1: *sn = c; *cs = -s; break;
-    case 2: *sn = -s; *cs = -c; break;
-    default: *sn = -c; *cs = s; break;
-    }
+    /* quadrant n & 3: (s, c), (c, -s), (-s, -c), (-c, s) -- by selects */
+    const double sv = (n & 1) ? c : s, cv = (n & 1) ? s : c;
+    *sn = (n & 2) ? -sv : sv;
+    *cs = ((n + 1) & 2) ? -cv : cv;
 }
 
 /* atan2(y, x) for finite arguments; the signed zeros as IEEE 754 / C99 Annex F have them */
@@ -64,22 +62,23 @@ EVPK_HD double evpk_atan2(double y, double x) {
     const double A0 = -0.3333333333333333, A1 = 0.2, A2 = -0.14285714285714285, A3 = 0.1111111111111111, A4 = -0.09090909090909091,
                  A5 = 0.07692307692307693;
     const double ax = fabs(x), ay = fabs(y);
-    double a;
-    if (ay == 0.0) {
-        a = 0.0;                                      /* (also x = y = 0) */
-    } else {
-        const int swap = ay > ax;
-        const double t = swap ? ax / ay : ay / ax;   /* in [0, 1] */
-        const double fk = floor(t * 16.0);            /* the breakpoint below t: u >= 0, nothing cancels in hi + (atan u + lo) */
-        const int k = (int)fk;
-        const double cpt = fk * 0.0625;
-        const double u = (t - cpt) / fma(t, cpt, 1.0);
-        const double z = u * u;
-        const double p = fma(z, fma(z, fma(z, fma(z, fma(z, A5, A4), A3), A2), A1), A0);
-        a = tab[2 * k] + (fma(u * z, p, u) + tab[2 * k + 1]);
-        if (swap) a = EVPK_PIO2_HI - (a - EVPK_PIO2_LO);
-    }
-    if (ay == 0.0 ? signbit(x) : (x < 0.0)) a = EVPK_PI_HI - (a - EVPK_PI_LO);
+    /* straight-line code (selects, no branches): the four corners of a cell are four independent chains the compiler can
+     * interleave.  ay = 0 (also x = y = 0) takes a = 0 at the end; what the main path computes then (0/0 at worst) is dropped. */
+    const int swap = ay > ax;
+    const double t = (swap ? ax : ay) / (swap ? ay : ax);       /* min / max, in [0, 1] */
+    const double fk0 = floor(t * 16.0);               /* the breakpoint below t: u >= 0, nothing cancels in hi + (atan u + lo) */
+    const double fk = (fk0 >= 0.0 && fk0 <= 16.0) ? fk0 : 0.0;      /* (t is NaN only on the dropped path: keep the index in the table) */
+    const int k = (int)fk;
+    const double cpt = fk * 0.0625;
+    const double u = (t - cpt) / fma(t, cpt, 1.0);
+    const double z = u * u;
+    const double p = fma(z, fma(z, fma(z, fma(z, fma(z, A5, A4), A3), A2), A1), A0);
+    double a = tab[2 * k] + (fma(u * z, p, u) + tab[2 * k + 1]);
+    a = swap ? EVPK_PIO2_HI - (a - EVPK_PIO2_LO) : a;
+    a = (ay == 0.0) ? 0.0 : a;
+    const double ar = EVPK_PI_HI - (a - EVPK_PI_LO);
+    const int xneg = (signbit(x) != 0) & ((ay == 0.0) | (x < 0.0));      /* ay = 0: the sign bit of x (-0 too); else x < 0 */
+    a = xneg ? ar : a;
     return copysign(a, y);
 }
 
