@@ -1072,6 +1072,37 @@ def test_eap_matches_the_oracle(ns, bs, ndte):
     assert np.abs(fo["yieldstress12"]).max() > 0 and np.abs(fo["rdg_conv"]).max() > 0
 
 
+def test_eap_two_launch_form_and_partial_subcycle_calls(monkeypatch):
+    """EVPK_EAP_FUSED=0 (k_eap_stress -> k_eap_stepu with str(8) through memory, in place) gives the same bits as the fused
+    launch; and the history planes, which only a call's last subcycle stores, are current after evpk_subcycle calls that
+    stop in the middle of the loop"""
+    monkeypatch.setenv("EVPK_EAP_FUSED", "0")
+    fo, fg, bad = _eap_both("tripole", (25, 29), 22)
+    assert not bad, bad[:8]
+    monkeypatch.delenv("EVPK_EAP_FUSED")
+    from cice5_amd.eap_tables import eap_tables
+    T = eap_tables()
+    case, d, f = util.make_case(100, 116, 50, 58, ns="tripole", land="continents")
+    synth.add_eap_state(f)
+    xmin = synth.global_min_dx(case)
+    fo, fg = util.clone(f), util.clone(f)
+    orc.eap(d, orc.make_params(3600.0, 23, xmin), fo, T)
+    s = dyn.EvpDynamics(d, fg, ndte=23, xmin=xmin)
+    s.init_eap(3600.0, T)
+    s.ctx.upload(fg)
+    s.ctx.prep()
+    for n in (1, 9, 2, 11):                       # 23 subcycles in four calls: odd and even counts, stepa at ksub = 1, 11, 21
+        s.ctx.subcycle(n)
+    s.ctx.finish()
+    s.ctx.download(fg)
+    s.ctx.eap_download(fg)
+    s.close()
+    ne = util.cell_mask(d, "ne")
+    assert not util.compare(d, fg, fo)
+    for n in EAP_NE:
+        assert np.array_equal(fg[n][ne], fo[n][ne]), n
+
+
 def test_eap_three_calls_with_ice_that_disappears():
     """the structure tensor stays on the device between calls and is reset to isotropic where icetmask = 0 (:284-298)"""
     fo, fg, bad = _eap_both("tripole", (25, 29), 22, calls=3)
