@@ -666,6 +666,7 @@ static int xp_check(evpk_ctx *c) {
     if (!c->ipc || !c->ipc->d_err) return 0;
     unsigned e = 0;
     HIPCHK(c, hipMemcpy(&e, c->ipc->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e >> 16) FAIL(c, "ipc transport: a partner rank was more than one message ahead %u time(s) -- the ranks posted different exchanges; the results of this call are invalid", e >> 16);
     if (e) FAIL(c, "ipc transport: %u wait(s) on a partner rank timed out; the results of this call are invalid", e);
     return 0;
 }
@@ -1671,11 +1672,13 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     if (!c->use_double && strips1(c)) return 1;
     if (c->use_double && tune_R2(c)) return 1;
     const int ns_tot2 = c->ncx2 * c->nry2;
-    c->dev_strips = c->dev_strips_env && c->use_double && !c->zone_mode && c->nranks == 1 && !c->force_exchange;
+    // one rank, or x-slab ranks on a tripole grid (no edge / interior lists, no row lists of the zone windows to make on the host)
+    c->dev_strips = c->dev_strips_env && c->use_double &&
+                    ((!c->zone_mode && c->nranks == 1 && !c->force_exchange) || (c->zone_mode && c->band_mode));
     if (c->dev_strips) {
         // flags, ordered compaction and counts on the device; nothing comes back before the loop has run (subcycle_impl)
         hipLaunchKernelGGL(k_strip_flags2, dim3((ns_tot2 + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, c->nry2, c->R2,
-                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, G, c->d_flags2, (unsigned int *)nullptr, c->d_counts);
+                           (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, G, c->d_flags2, (unsigned int *)nullptr, c->d_counts);
         hipLaunchKernelGGL(k_compact_strips, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)c->d_flags2, ns_tot2, c->d_strips2, c->d_ns2);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, c->stream));

@@ -688,8 +688,13 @@ __global__ void k_ipc_wait(const unsigned *flag, unsigned seq, unsigned *err, un
     const unsigned long long t0 = wall_clock64();
     for (unsigned it = 0; it < (1u << 26); it++) {
         // (sequence numbers wrap: compare as a signed distance)
-        if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0) {
+        const int ahead = (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq);
+        if (ahead >= 0) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            // every exchange is a swap: the partner can be ONE message ahead (it has mine and went on), never two -- it would
+            // need my next one for that.  More means the two ranks disagree about the exchanges they post, and the slot read
+            // next (parity of the sequence number) may hold another message: report it like a wait that gave up
+            if (ahead > 1) atomicAdd(err, 1u << 16);
             return;
         }
         __builtin_amdgcn_s_sleep(20);
@@ -1747,15 +1752,24 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
     }
     __syncthreads();
 
-    // global column of this lane in strip t (for the roles in the fold)
-    auto gcol = [&](int t) { return wrapc(ss[t]->i0 + cl[t] - 1, nxg); };
+    // global column of this lane in either strip (for the roles in the fold).  The folds pick their strip by the WAVE index: every
+    // per-strip quantity they use is selected here from two scalars -- an array indexed by a run-time value would live in
+    // scratch memory and drag the whole kernel (the main strips included) into spilling
+    const int gcolA = wrapc(sA.i0 + cl[0] - 1, nxg), gcolB = wrapc(sB.i0 + cl[1] - 1, nxg);
+    const bool w1 = (w == 1);
+    const int gcolW = w1 ? gcolB : gcolA;
+    const bool ownW = w1 ? own[1] : own[0];
+    char *const baseW = w1 ? base[1] : base[0];
+    const size_t rowbW = w1 ? rowb[1] : rowb[0], ppW = w1 ? pp[1] : pp[0];
+    const int NnW = w1 ? Nn[1] : Nn[0], ciW = w1 ? ci[1] : ci[0];
+    const unsigned loW = w1 ? lo[1] : lo[0];
 
     // ---------------- fold 1 (k_halo_tripole_ne1's arithmetic): waves 0, 1 <-> strips A, B; lanes 0 .. 62 ----------------
     {
         double tu = 0, tv = 0, gu = 0, gv = 0;
         const bool f1 = (w < 2) && lane <= 62;
         if (f1) {
-            const int t = w, g = gcol(t);
+            const int t = w, g = gcolW;
             const double *Ut = U1 + (size_t)((t * 4 + 2) * 2) * 64 + lane;                  // my top row
             const double *Um = U1 + (size_t)(((1 - t) * 4 + 2) * 2) * 64 + (62 - lane);     // the mirror column's top row
             const double *Rm = U1 + (size_t)(((1 - t) * 4 + 1) * 2) * 64 + (62 - lane);     // ... and its row N-1
@@ -1844,7 +1858,7 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
 
     // ---------------- fold 2: rows N and N+1 of the new state, lanes 1 .. 61 ----------------
     if (w < 2 && lane >= 1 && lane <= 61) {
-        const int t = w, g = gcol(t);
+        const int t = w, g = gcolW;
         const double *Vt = V2 + (size_t)((t * 2 + 1) * 2) * 64 + lane;
         const double *Vm = V2 + (size_t)(((1 - t) * 2 + 1) * 2) * 64 + (62 - lane);
         const double *Rm = V2 + (size_t)(((1 - t) * 2 + 0) * 2) * 64 + (62 - lane);
@@ -1854,13 +1868,13 @@ __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) 
         else if (g < h) { tu = sgn * (sgn * (0.5 * (Tu + sgn * Mu))); tv = sgn * (sgn * (0.5 * (Tv + sgn * Mv))); }
         else { tu = sgn * (0.5 * (Mu + sgn * Tu)); tv = sgn * (0.5 * (Mv + sgn * Tv)); }
         const double gu = sgn * Rm[0], gv = sgn * Rm[64];
-        if (own[t]) {
-            char *const rN = base[t] + (size_t)Nn[t] * rowb[t], *const rG = rN + rowb[t];
-            stp(rN, pp[t], SW + S_U, lo[t], tu, tv);
-            stp(rG, pp[t], SW + S_U, lo[t], gu, gv);
+        if (ownW) {
+            char *const rN = baseW + (size_t)NnW * rowbW, *const rG = rN + rowbW;
+            stp(rN, ppW, SW + S_U, loW, tu, tv);
+            stp(rG, ppW, SW + S_U, loW, gu, gv);
             if (!cross) {
-                if (ci[t] == 1) { stp(rN, pp[t], SW + S_U, lo[t] + (unsigned)wloc * 16u, tu, tv); stp(rG, pp[t], SW + S_U, lo[t] + (unsigned)wloc * 16u, gu, gv); }
-                if (ci[t] == wloc) { stp(rN, pp[t], SW + S_U, lo[t] - (unsigned)wloc * 16u, tu, tv); stp(rG, pp[t], SW + S_U, lo[t] - (unsigned)wloc * 16u, gu, gv); }
+                if (ciW == 1) { stp(rN, ppW, SW + S_U, loW + (unsigned)wloc * 16u, tu, tv); stp(rG, ppW, SW + S_U, loW + (unsigned)wloc * 16u, gu, gv); }
+                if (ciW == wloc) { stp(rN, ppW, SW + S_U, loW - (unsigned)wloc * 16u, tu, tv); stp(rG, ppW, SW + S_U, loW - (unsigned)wloc * 16u, gu, gv); }
             }
         }
     }

@@ -357,3 +357,135 @@ def test_mirror_slab_depth_for_m_pairs_without_a_refresh(m):
     assert pairs_supported(max(4, 2 * m + 1)) >= m
     if m >= 2:
         assert pairs_supported(2 * m) < m
+
+
+def _xband_worker(rank, world, port, m, q):
+    """The tripole protocol of two x-slab ranks (evpk_connect / subcycle_impl with xband), restated with the oracle over gloo:
+    every rank advances ONE composite domain [ my strip with its zones | the mirror rank's strip with its zones ] of width
+    2 L, L = w + 2 W, closed by a tripole fold -- with equal slab widths my local column c and the mirror rank's w - c are
+    images of each other under the fold of that composite (positions c + W and 2 L - c - W), exactly as band_pair pairs
+    them.  Zones are W = 2 m + 1 columns; after m launches of two subcycles the E-W zones of my strip come from the neighbour
+    and the TOP nylM + 2 = 2 m + 3 rows of the mirror strip (the mirror slab M) from the mirror rank; the rows of the mirror
+    strip below them are never refreshed -- they go stale from the bottom exactly as the rows below M would if M had them."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          OMP_NUM_THREADS="2")
+        import torch
+        import torch.distributed as dist
+        from cice5_amd import blocks, constants as C, synth
+        from oracle import orc
+        from tests import util
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        nx, ny, ndte = 48, 40, 24
+        W = 2 * m + 1
+        nylM = max(4, 2 * m + 1)
+        w = nx // world
+        other = 1 - rank                             # two ranks: the mirror rank P-1-r is also both E-W neighbours
+        L = w + 2 * W
+        case = synth.SynthCase(nx=nx, ny=ny, land="continents", ns_boundary=C.BND_TRIPOLE)
+        dx = blocks.create_distrb_cart(2 * L, ny, 2 * L, ny, ew_boundary_type="open", ns_boundary_type="tripole")
+        Iw, Jw = blocks.block_index_windows(dx)
+        # global column of every composite column (the block's own ghost columns 0 and 2L+1 continue the strips)
+        col = Iw[0].astype(np.int64)                 # 0 .. 2L+1
+        gcolumn = np.where(col <= L, rank * w + 1 - W - 1 + col, other * w + 1 - W - 1 + (col - L))
+        I, J = np.broadcast_arrays(gcolumn[None, :], Jw[0][:, None])
+        f = synth.make_block_fields(synth.SynthCase(nx=2 * L, ny=ny, ns_boundary=C.BND_TRIPOLE), dx)
+        cache = {}
+        for name in synth.GRID_FIELDS + synth.INPUT_FIELDS + synth.MASK_FIELDS:
+            f[name][0] = case.field(name, I, J, cache)
+        xmin = synth.global_min_dx(case)
+        p = orc.make_params(3600.0, ndte, xmin)
+        state = ["uvel", "vvel"] + util.SIGMA
+        # The columns on the fold's axes (global nx/2 and nx) are their own images: the fold leaves sgn * (their own top-row
+        # value) there (serial/ice_boundary.F90:818-824 skips them in the symmetrisation, the copy :3752-3776 then negates a
+        # vector).  In the composite each of them sits twice -- as an own column of one strip and as the ghost column 0 of the
+        # other -- and the composite's fold would average the two copies instead; band_pair knows the GLOBAL column of every
+        # lane (gcol) and applies the axis rule, so does this model, through the oracle's halo callback.
+        gw = (gcolumn - 1) % nx + 1
+        axis = [int(k) for k in np.nonzero((gw == nx // 2) | (gw == nx))[0] if 1 <= k <= 2 * L]
+        shape = (1, ny + 2, 2 * L + 2)
+        pre = {}
+
+        def patch(ptr, loc, kind, fill, phase):
+            if loc != C.LOC_NECORNER or kind != C.KIND_VECTOR:
+                return
+            a = np.ctypeslib.as_array(ptr, shape=shape)
+            if phase == 0:
+                pre["top"] = a[0, ny, axis].copy()
+            else:
+                a[0, ny, axis] = -pre["top"]
+
+        keep = orc.set_halo_callback(patch)
+        nex = 0
+        for launch in range(ndte // 2):
+            orc.evp(dx, p, f, nsub=2)
+            if (launch + 1) % m:
+                continue
+            # 1. ghost zones of my strip: the neighbour's own edge columns, all rows (two ranks: one partner for both sides)
+            sendW = torch.from_numpy(np.stack([f[n][0][:, W + 1:2 * W + 1] for n in state]).copy())          # my first W own columns
+            sendE = torch.from_numpy(np.stack([f[n][0][:, w + 1:w + W + 1] for n in state]).copy())          # my last W own columns
+            recvE, recvW = torch.zeros_like(sendW), torch.zeros_like(sendE)
+            if rank == 0:
+                dist.send(sendW, other); dist.send(sendE, other); dist.recv(recvE, other); dist.recv(recvW, other)
+            else:
+                dist.recv(recvE, other); dist.recv(recvW, other); dist.send(sendW, other); dist.send(sendE, other)
+            for k, n in enumerate(state):
+                f[n][0][:, w + W + 1:L + 1] = recvE[k].numpy()
+                f[n][0][:, 1:W + 1] = recvW[k].numpy()
+            # 2. the mirror slab: the top rows of the mirror rank's strip, its (fresh) zones included
+            rows = slice(ny - nylM, ny + 2)
+            sendM = torch.from_numpy(np.stack([f[n][0][rows, 1:L + 1] for n in state]).copy())
+            recvM = torch.zeros_like(sendM)
+            if rank == 0:
+                dist.send(sendM, other); dist.recv(recvM, other)
+            else:
+                dist.recv(recvM, other); dist.send(sendM, other)
+            for k, n in enumerate(state):
+                f[n][0][rows, L + 1:2 * L + 1] = recvM[k].numpy()
+            nex += 1
+        assert nex == ndte // (2 * m)
+        orc.set_halo_callback(None)
+        del keep
+        # reference: the whole domain in this process, another block size, the SAME sequence of calls (the oracle's evp runs
+        # its preparation -- with a velocity halo update, whose fold negates the axis columns once more -- at every call)
+        d1 = blocks.create_distrb_cart(nx, ny, 12, 10, ns_boundary_type="tripole")
+        f1 = synth.make_block_fields(case, d1)
+        for launch in range(ndte // 2):
+            orc.evp(d1, p, f1, nsub=2)
+        bad = []
+        for name in state:
+            G = blocks.gather_global(d1, f1[name])[:, rank * w:rank * w + w]
+            Lc = f[name][0][1:ny + 1, W + 1:W + w + 1]
+            if not np.array_equal(G, Lc):
+                jj, ii = np.nonzero(G != Lc)
+                bad.append((name, int((G != Lc).sum()), int(jj.min()) + 1, int(ii.min()) + 1, int(ii.max()) + 1))
+        assert np.abs(f["uvel"]).max() > 1e-3
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bad))
+    except Exception:
+        q.put((rank, ["EXC " + traceback.format_exc()]))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_two_rank_tripole_mirror_slab_gloo(m):
+    """world size 2 over gloo: zones of 2m+1 columns, a mirror slab of 2m+1 rows, both refreshed once per m launches -- bit for
+    bit the single-domain evp on every rank's own columns"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xband_worker, args=(r, 2, port, m, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in procs:
+        res.append(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()
+    for rank, bad in res:
+        assert not bad, f"rank {rank}: {bad}"
