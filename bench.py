@@ -391,9 +391,9 @@ def next_rows(a, case, d, f, xmin, device, ncat=5, trcr_depend=(0, 1, 1, 1, 1, 2
     res["eap"] = {"what": "eap(dt), kdyn = 2 (ice_dyn_eap.F90:66), same grid / state / ndte as the headline", "ms_per_eap": 1e3 * min(t[1:]),
                   "value": 0.5 * (st.icellt + st.icellu) * a.ndte / min(t[1:]), "unit": "cell-updates/s", "loop_ms": float(st.loop_ms)}
     # whole-loop HBM roofline of eap: what one subcycle (k_eap_sub: stress_eap + stepu) must move -- per T cell 8 metrics 64 B,
-    # tinyarea / strength 16, tarear 8, (u, v) 16, the cached angles 128, sigma 96 in + 96 out, mask 1; per U cell 8 inputs 64,
-    # (u, v) out 16 -- over the loop time per subcycle (launch gaps, halo and the stepa launches included)
-    eap_bytes = 425.0 * st.icellt + 80.0 * st.icellu
+    # tinyarea / strength 16, tarear 8, (u, v) 16, the cached angles (gamma, a' per corner) 64, sigma 96 in + 96 out, mask 1; per U
+    # cell 8 inputs 64, (u, v) out 16 -- over the loop time per subcycle (launch gaps, halo and the stepa launches included)
+    eap_bytes = 361.0 * st.icellt + 80.0 * st.icellu
     res["eap"]["roofline"] = {"bound": "hbm", "alg_bytes_per_subcycle": eap_bytes, "unit": "GB/s", "peak": 8000.0,
                               "achieved": eap_bytes * a.ndte / (float(st.loop_ms) * 1e-3) / 1e9,
                               "frac": eap_bytes * a.ndte / (float(st.loop_ms) * 1e-3) / 1e9 / 8000.0}

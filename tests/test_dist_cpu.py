@@ -366,7 +366,11 @@ def _xband_worker(rank, world, port, m, q):
     images of each other under the fold of that composite (positions c + W and 2 L - c - W), exactly as band_pair pairs
     them.  Zones are W = 2 m + 1 columns; after m launches of two subcycles the E-W zones of my strip come from the neighbour
     and the TOP nylM + 2 = 2 m + 3 rows of the mirror strip (the mirror slab M) from the mirror rank; the rows of the mirror
-    strip below them are never refreshed -- they go stale from the bottom exactly as the rows below M would if M had them."""
+    strip below them are never refreshed -- they go stale from the bottom exactly as the rows below M would if M had them.
+    (What this case can and cannot see: a bit difference that enters at a zone's edge fades below one ulp within about five
+    columns or rows here -- the EVP update is strongly damped -- so too narrow a zone shows (2m columns: late and in a few
+    cells), too shallow a mirror slab does not; the depth rules are the dependency models below, the protocol -- who sends
+    what when, the fold's pairing c <-> w - c, its axis columns -- is what this test holds.)"""
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
