@@ -5,8 +5,13 @@
   * "shm": the host-staged shared-memory relay (unique id "EVPKSHM:<name>") with the semantics of the RCCL
     point-to-point calls, which refuse several ranks on one device.
 Everything else is the production multi-rank path: slabs with i0 > 1, edge-column / ghost-zone exchange, the edge-first
-overlap on two streams, the tripole fold as a packed exchange with the mirror ranks.  Each rank compares its slab with
-the single-process oracle."""
+overlap on two streams, the tripole fold (mirror slab, or the packed exchange with the mirror ranks).  Each rank compares its
+slab with the single-process oracle.
+
+On a node with SEVERAL GPUs (none was available to the builder: the cross-device visibility of the peer-mapped buffers, the
+flags and RCCL itself are unverified) the same cases run one rank per device and also over RCCL:
+    EVPK_TEST_DEVICES=per_rank EVPK_TEST_XPS=ipc,rccl python -m pytest tests/test_multirank_gpu.py -q -m gpu
+("rccl": rank 0 makes the ncclUniqueId, the harness hands it to the other ranks; refused by RCCL when two ranks share a device)."""
 import os
 import sys
 import traceback
@@ -43,7 +48,7 @@ def _wander(d, base, ff, call, ns):
         ff["strairyT"][n] = base["strairyT"][n] * np.cos(0.5 * call) + base["strairxT"][n] * np.sin(0.5 * call)
 
 
-def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
+def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q, uidq=None):
     try:
         import time
         t0 = time.time()
@@ -59,13 +64,20 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
         f = synth.make_block_fields(case, d)
         xmin = synth.global_min_dx(case)
         xp = env.get("TEST_XP", "shm")
-        uid = ({"shm": b"EVPKSHM:", "ipc": b"EVPKIPC:"}[xp] + tag.encode()).ljust(128, b"\0")
+        dev = 0
+        if os.environ.get("EVPK_TEST_DEVICES") == "per_rank":
+            import torch
+            dev = rank % max(1, torch.cuda.device_count())
+        if xp == "rccl":                          # rank 0 made the id (see _run); every rank takes one copy from the queue
+            uid = uidq.get(timeout=120)
+        else:
+            uid = ({"shm": b"EVPKSHM:", "ipc": b"EVPKIPC:"}[xp] + tag.encode()).ljust(128, b"\0")
         eap = bool(env.get("TEST_EAP"))
         if eap:                                   # kdyn = 2: the same slabs, exchange and fold around stress_eap / stepa
             from cice5_amd.eap_tables import eap_tables
             T = eap_tables()
             synth.add_eap_state(f)
-        s = dyn.EvpDynamics(d, f, ndte=ndte, xmin=xmin, device=0, unique_id=uid)
+        s = dyn.EvpDynamics(d, f, ndte=ndte, xmin=xmin, device=dev, unique_id=uid)
         if eap:
             s.init_eap(3600.0, T)
         else:
@@ -198,7 +210,7 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q):
                     bad.append(("transport_remap_state " + name, int((a[m] != r[loc][m]).sum())))
         st = s.ctx.stats()
         s.close()
-        if int(st.transport) != {"shm": 2, "ipc": 3}[xp]:
+        if int(st.transport) != {"shm": 2, "ipc": 3, "rccl": 1}[xp]:
             bad.append(("transport", int(st.transport)))
         q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()), time.time() - t0,
                int(st.zone_cols), int(st.zone_exchanges)))
@@ -212,7 +224,14 @@ def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None, xp="shm"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     tag = "evpk_t_" + uuid.uuid4().hex[:12]
-    procs = [ctx.Process(target=_worker, args=(r, world, tag, ns, nx, ny, bsx, bsy, ndte, env or {}, q)) for r in range(world)]
+    uidq = None
+    if xp == "rccl":
+        from cice5_amd import evpk
+        uidq = ctx.Queue()
+        uid = evpk.get_unique_id()                # (ncclGetUniqueId: no device is touched by this process)
+        for _ in range(world):
+            uidq.put(uid)
+    procs = [ctx.Process(target=_worker, args=(r, world, tag, ns, nx, ny, bsx, bsy, ndte, env or {}, q, uidq)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -236,7 +255,7 @@ def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None, xp="shm"):
     return res
 
 
-XPS = ["ipc", "shm"]
+XPS = [x for x in os.environ.get("EVPK_TEST_XPS", "ipc,shm").split(",") if x]
 
 
 @pytest.mark.parametrize("xp", XPS)
