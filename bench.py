@@ -64,27 +64,58 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def fused_bytes(icellt, icellu, st, revp, two_subcycles):
+def fused_bytes(icellt, icellu, st, revp, fused):
     """Bytes one launch of the fused kernel MUST move (fp64, each distinct array element once, perfect stencil reuse):
     per active T cell: 12 sigma read + 12 written, the (tinyarea, strength) pair, the metrics the variant reads -- the
     (HTN, HTE) pair with compact metrics, else the four pairs cxp/cyp, cxm/cym, dxt/dyt, dxhy/dyhx -- the (u, v) pair and
     the mask byte; per active U cell: the four stepu input pairs (vrelc/uarear, uocn/vocn, forcex/forcey, umassdti/fm),
-    (u, v) written, + the uvel_init pair under revised EVP.  The two-subcycle kernel moves this ONCE per two subcycles."""
-    metrics = 16 if (st.compact_metrics and two_subcycles) else 64
+    (u, v) written, + the uvel_init pair under revised EVP.  The two-subcycle kernel moves this ONCE per two subcycles, the
+    three-subcycle pipeline kernel ONCE per three."""
+    metrics = 16 if (st.compact_metrics and fused) else 64
     per_t = 12 * 8 * 2 + 16 + metrics + 16 + 1
     per_u = 4 * 16 + 16 + (16 if revp else 0)
     return per_t * icellt + per_u * icellu
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` from a bare command line: start the N ranks as CHILD processes through torch.distributed.run
+    before this process has made any GPU call (it never makes one), relay rank 0's JSON line and exit with the children's status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:                      # everything the ranks print is passed on; the JSON line is repeated last
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stdout.write(ln)
+    rc = p.wait()
+    sys.stdout.flush()
+    if line is None:
+        line = json.dumps({"metric": "EVP subcycle cell-updates/sec", "value": None, "unit": "cell-updates/s", "n_gpus": a.gpus,
+                           "failed": "launch", "error": f"torch.distributed.run exited with {rc} and no rank printed a result"})
+    print(line, flush=True)
+    sys.exit(rc if rc else (0 if '"value": null' not in line else 3))
+
+
 def main():
     t_start = time.perf_counter()
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL / IPC handles across processes need dmabuf IPC on this pool
@@ -96,7 +127,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the EVP path has no CPU fallback)")
     if os.environ.get("EVPK_FORCE_DEVICE") is not None:      # debugging only: several ranks on one GPU
         local_rank = int(os.environ["EVPK_FORCE_DEVICE"])
-    torch.cuda.set_device(local_rank)
+    if local_rank < torch.cuda.device_count():
+        torch.cuda.set_device(local_rank)      # (else: evpk.device_check below reports the missing device on every rank's behalf)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # torch.distributed is only the control plane here (rendezvous, barrier, scalar reductions, the 128-byte
@@ -176,16 +208,22 @@ def main():
     r = timed_steps(ctx, a.ndte, a.steps, a.warmup, fence)
     st = r["stats"]
 
-    vals = torch.tensor([r["wall_s"], r["loop_ms"], r["k1_ms"], r["k2_ms"], float(st.icellt), float(st.icellu)], dtype=torch.float64)
+    vals = torch.tensor([r["wall_s"], r["loop_ms"], float(st.icellt), float(st.icellu)], dtype=torch.float64)
+    devs = [(int(st.device), int(st.device_pci))]
+    rccl_ranks = int(st.rccl_ranks)
     if world > 1:
-        tmax = vals[:4].clone()
+        tmax = vals[:2].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = vals[4:].clone()
+        tsum = vals[2:].clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_wall, loop_ms, k1_ms, k2_ms = (float(v) for v in tmax)
+        dt_wall, loop_ms = (float(v) for v in tmax)
         icellt, icellu = float(tsum[0]), float(tsum[1])
+        got = [None] * world
+        dist.all_gather_object(got, (devs[0], rccl_ranks))
+        devs = [g[0] for g in got]
+        rccl_ranks = min(g[1] for g in got)
     else:
-        dt_wall, loop_ms, k1_ms, k2_ms = r["wall_s"], r["loop_ms"], r["k1_ms"], r["k2_ms"]
+        dt_wall, loop_ms = r["wall_s"], r["loop_ms"]
         icellt, icellu = float(st.icellt), float(st.icellu)
 
     n_active = 0.5 * (icellt + icellu)                  # one cell-update = one T stress + one U stepu update
@@ -195,16 +233,18 @@ def main():
     roof = roofline(r, icellt / world, icellu / world, revp=False)
     sha = source_sha()
     traffic, tnote = a.traffic_bytes, "given on the command line" if a.traffic_bytes else None
+    rocprof_ms = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if traffic is None and os.path.exists(tfile):       # measured in separate rocprofv3 --pmc passes of this same command
         ent = [e for e in json.load(open(tfile)).get("entries", []) if e.get("workload") == workload]
         cur = [e for e in ent if e.get("source_sha") == sha]
         if cur:
             traffic, tnote = cur[-1]["hbm_bytes_per_launch"], cur[-1].get("profile")
+            rocprof_ms = cur[-1].get("kernel_avg_ms")      # rocprofv3 --kernel-trace --stats average of the same kernel, same build
         elif ent:
             tnote = f"profiles/traffic.json holds this workload for another kernel build ({ent[-1].get('source_sha')}): not reported"
     kern_s = roof["avg_launch_ms"] * 1e-3
-    roof.update({"traffic": traffic, "traffic_source": tnote, "source_sha": sha,
+    roof.update({"traffic": traffic, "traffic_source": tnote, "source_sha": sha, "rocprof_avg_launch_ms": rocprof_ms,
                  "traffic_GBps": (traffic / kern_s / 1e9) if (traffic and kern_s > 0) else None,
                  "traffic_frac_of_peak": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if (traffic and kern_s > 0) else None,
                  "traffic_over_alg": (traffic / roof["alg_bytes_per_launch"]) if traffic else None,
@@ -219,6 +259,9 @@ def main():
                    "strips_per_launch_rank0": int(st.nstrips2 or st.nstrips),
                    "strip_rows_rank0": int(st.strip_rows2 or st.strip_rows),
                    "transport": evpk.XP_NAMES.get(int(st.transport), "?") if world > 1 else "none",
+                   # what carried the exchanges, as the library itself sees it: ncclCommCount of every rank's communicator (0 = no
+                   # RCCL communicator: one rank, or the ipc / shm transports) and the distinct physical GPUs under the ranks
+                   "rccl_ranks": rccl_ranks, "devices": len(set(p for _, p in devs)), "device_ordinals": [o for o, _ in devs],
                    "ghost_zone_cols": int(st.zone_cols), "zone_exchanges_per_evp": int(st.zone_exchanges), "band_row_exchanges_per_evp": int(st.band_row_exchanges),
                    "zone_bytes_sent_rank0": int(st.zone_bytes), "overlap_split_rank0": int(st.overlap_split),
                    "step": "prep + ndte x (stress+stepu, halo / fold) + stress folds + finish"},
@@ -227,8 +270,24 @@ def main():
 
     t_cpu = time.perf_counter()
     if rank == 0 and world == 1 and a.cpu_subcycles > 0:
+        # verify: the benched context itself against the oracle on the box the number comes from -- state back at rest, the same
+        # `cpu_subcycles` subcycles (default: all ndte) + stress folds + evp_finish on the device (untimed) and, as the cpu_baseline
+        # leg below, in the oracle, over the same blocks; the prognostic state compared bit for bit on every cell the reference
+        # leaves defined.  The oracle is the checker here, never the thing measured.
+        nv = min(a.cpu_subcycles, a.ndte)
+        names = ["uvel", "vvel"] + list(synth.STRESS_FIELDS)
         solver.init_evp(a.dt)          # the host arrays are still the uploaded inputs; state back at rest
-        out["cpu_baseline"] = cpu_baseline(d, f, a, xmin)
+        ctx.upload(f)
+        ctx.prep(); ctx.subcycle(nv); ctx.finish()
+        got = {n: np.empty_like(f[n]) for n in names}
+        ctx.download(got)
+        vst = ctx.stats()
+        out["cpu_baseline"] = cpu_baseline(d, f, a, xmin)       # (runs the oracle in place on f: nv subcycles from the same state)
+        out["verify"] = verify(d, got, f, names, nv, vst, out["cpu_baseline"])
+        del got
+    elif rank == 0:
+        out["verify"] = {"bit_identical": None, "note": "N = 1 only (the oracle is a one-process checker); the multi-rank path is "
+                                                        "covered by tests/test_multirank_gpu.py against the same oracle"}
     t_cpu = time.perf_counter() - t_cpu
     t_extra = time.perf_counter()
     # (profiling runs pass --cpu-subcycles 0 and skip the extras, so that their traces hold the timed workload only)
@@ -271,6 +330,30 @@ def main():
         dist.destroy_process_group()
 
 
+def verify(d, got, ref, names, nsub, st, cpu):
+    """bit comparison of the device result with the oracle's: (u, v) on all cells of every block (ghost cells halo-updated),
+    the stresses on physical + N/E ghost T cells (ice_dyn_shared.F90:528-537), as tests/util.compare does"""
+    allc = np.zeros((d.nblocks, d.ny_block, d.nx_block), dtype=bool)
+    ne = np.zeros_like(allc)
+    for n, b in enumerate(d.local_blocks):
+        allc[n, :b.jhi + 1, :b.ihi + 1] = True
+        ne[n, b.jlo - 1:b.jhi + 1, b.ilo - 1:b.ihi + 1] = True
+    bad, cells = {}, 0
+    for n in names:
+        m = allc if n in ("uvel", "vvel") else ne
+        a, b_ = got[n][m], ref[n][m]
+        neq = ~((a == b_) | (np.isnan(a) & np.isnan(b_)))
+        cells += int(m.sum())
+        if neq.any():
+            bad[n] = {"cells": int(neq.sum()), "max_abs_diff": float(np.nanmax(np.abs(a[neq] - b_[neq])))}
+    return {"bit_identical": not bad, "mismatch": bad, "fields": names, "values_compared": cells, "subcycles": int(nsub),
+            "max_abs_u": float(np.abs(ref["uvel"]).max()),
+            "what": f"state at rest -> {nsub} subcycles + stress folds + evp_finish on the benched context ({d.nblocks} blocks, the "
+                    f"benched decomposition, {int(st.kernel3_launches)} three-subcycle + {int(st.kernel2_launches)} two-subcycle + "
+                    f"{int(st.kernel_launches)} one-subcycle launches) vs the oracle (the cpu_baseline run) on the same inputs",
+            "counts_match": [int(st.icellt), int(st.icellu)] == [int(cpu["icellt"]), int(cpu["icellu"])]}
+
+
 def timed_steps(ctx, ndte, steps, warmup, fence):
     """`warmup` untimed and `steps` timed device-resident evp(dt).  Wall clock around the timed steps (fence = sync +
     barrier on both sides); per step the library's own HIP events on ITS streams: the whole ndte loop and the sampled
@@ -283,18 +366,19 @@ def timed_steps(ctx, ndte, steps, warmup, fence):
     for _ in range(warmup):
         step()
     fence()
-    loop_ms, k1_ms, k1_n, k1_t, k2_ms, k2_n, k2_t = 0.0, 0.0, 0, 0, 0.0, 0, 0
+    loop_ms = 0.0
+    k = {q: [0.0, 0, 0] for q in (1, 2, 3)}      # subcycles per launch -> [ms, launches, launches inside timed spans]
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
         st = ctx.stats()
         loop_ms += st.loop_ms
-        k1_ms += st.kernel_ms; k1_n += st.kernel_launches; k1_t += st.kernel_timed
-        k2_ms += st.kernel2_ms; k2_n += st.kernel2_launches; k2_t += st.kernel2_timed
+        for q, (ms, n, t) in ((1, (st.kernel_ms, st.kernel_launches, st.kernel_timed)), (2, (st.kernel2_ms, st.kernel2_launches, st.kernel2_timed)),
+                              (3, (st.kernel3_ms, st.kernel3_launches, st.kernel3_timed))):
+            k[q][0] += ms; k[q][1] += n; k[q][2] += t
     fence()
     wall = time.perf_counter() - t0
-    return {"wall_s": wall, "loop_ms": loop_ms, "k1_ms": k1_ms, "k1_n": k1_n, "k1_timed": k1_t, "k2_ms": k2_ms, "k2_n": k2_n,
-            "k2_timed": k2_t, "stats": ctx.stats(), "steps": steps}
+    return {"wall_s": wall, "loop_ms": loop_ms, "k": k, "stats": ctx.stats(), "steps": steps}
 
 
 def roofline(r, icellt, icellu, revp):
@@ -303,23 +387,33 @@ def roofline(r, icellt, icellu, revp):
     SURVEY S8d figure (592 B per cell-update: the reference's unfused traffic, which this kernel never moves) is kept
     as `effective_vs_reference_accounting`."""
     st = r["stats"]
-    if r["k2_n"] > 0:
+    k = r["k"]
+    nsub = max((q for q in (1, 2, 3) if k[q][1] > 0), key=lambda q: k[q][0], default=1)     # the kind the loop spends most time in
+    kms, launches, timed = k[nsub]
+    kern_ms = kms / max(launches, 1)
+    if nsub == 3:
+        kname = "evpk::k_subcycle3w (stress+stepu fused, three subcycles per launch, one wave per subcycle stage)"
+    elif nsub == 2:
         base = "evpk::k_subcycle2t" if st.tile_kernel else ("evpk::k_subcycle2" if os.environ.get("EVPK_PREFETCH") == "0" else "evpk::k_subcycle2p")
-        kname, nsub, kern_ms, launches, timed = base + " (stress+stepu fused, two subcycles per launch)", 2, r["k2_ms"] / r["k2_n"], r["k2_n"], r["k2_timed"]
+        kname = base + " (stress+stepu fused, two subcycles per launch)"
     else:
-        kname, nsub, kern_ms, launches, timed = "evpk::k_subcycle (stress+stepu fused)", 1, r["k1_ms"] / max(r["k1_n"], 1), r["k1_n"], r["k1_timed"]
-    alg = fused_bytes(icellt, icellu, st, revp, nsub == 2)
+        kname = "evpk::k_subcycle (stress+stepu fused)"
+    alg = fused_bytes(icellt, icellu, st, revp, nsub >= 2)
     ref = nsub * (ALG_BYTES_STRESS * icellt + ALG_BYTES_STEPU * icellu)
     ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    others = [{"subcycles_per_launch": q, "launches": int(k[q][1]), "launches_timed": int(k[q][2]), "avg_launch_ms": k[q][0] / max(k[q][1], 1)}
+              for q in (1, 2, 3) if q != nsub and k[q][1] > 0]
     return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "alg_bytes_per_launch": alg, "alg_bytes_per_cell_update": alg / max(0.5 * (icellt + icellu) * nsub, 1.0),
             "avg_launch_ms": kern_ms, "launches": int(launches), "launches_timed": int(timed), "subcycles_per_launch": nsub,
+            "timing": "HIP events on the library's stream around runs of six consecutive launches (launches 1..6 of every 8): span "
+                      "time / launches in the span, so launches x avg_launch_ms <= the loop time by construction",
+            "kernel_ms_per_step_all_kinds": sum(k[q][0] for q in (1, 2, 3)) / max(r["steps"], 1),
             "compact_metrics": int(st.compact_metrics),
             "effective_vs_reference_accounting": {"bytes_per_cell_update": ALG_BYTES_STRESS + ALG_BYTES_STEPU,
                                                   "GBps": ref / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,
                                                   "frac_of_peak": ref / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0},
-            "other_kernel": {"name": "k_subcycle on the main stream (odd remainder; one rank: the tripole top band of a pair runs as workgroups of the pair's own launch, band_pair -- x-slab ranks: band launches on the second stream, not in this count)", "launches": int(r["k1_n"]),
-                             "launches_timed": int(r["k1_timed"]), "avg_launch_ms": r["k1_ms"] / max(r["k1_n"], 1)}}
+            "other_kernels": others}
 
 
 def evp_incl_pcie(d, f, a, xmin, device):
@@ -484,7 +578,7 @@ def cpu_baseline(d, f, a, xmin):
     halo = orc.last_halo_seconds
     cores = min(threads, d.nblocks)
     n = 0.5 * (nt + nu) * a.cpu_subcycles
-    return {"value": n / secs, "unit": "cell-updates/s", "cores": cores, "kind": "port", "per_core": n / secs / cores,
+    return {"value": n / secs, "unit": "cell-updates/s", "cores": cores, "kind": "port", "per_core": n / secs / cores, "icellt": nt, "icellu": nu,
             "loop_only": n / max(secs - halo, 1e-9), "with_halo": n / secs, "halo_share": halo / secs,
             "reference_per_core_survey": 1.1e7,
             "sample": f"first {a.cpu_subcycles} of {a.ndte} subcycles of the same {d.nx_global}x{d.ny_global} state "

@@ -276,6 +276,7 @@ struct evpk_ctx {
     // evpk_prep then never waits for the GPU -- the kernels read the list's length from d_ns2, the host reads it (and the cell
     // counts) from page-locked memory once the loop's final event has completed
     bool dev_strips_env = true, dev_strips = false;
+    bool counts_pending = false;      // dev_strips: icellt / icellu / nstrips2 of this evp are still on their way into h_counts
     int *d_ns2 = nullptr;
     unsigned long long *h_counts = nullptr;      // page-locked: [0] icellt, [1] icellu, [2] number of strips (as written by the copies)
     int ns_tot2_cur = 0;
@@ -337,6 +338,14 @@ struct evpk_ctx {
     unsigned char *d_flags2 = nullptr;
     int *d_strips2 = nullptr;
     int double_launches = 0;
+    // three subcycles per launch: k_subcycle3w, the stage-per-wave pipeline (EVPK_TRIPLE; one rank, see subcycle_impl)
+    bool use_triple = false;
+    int triple_env = -1;             // EVPK_TRIPLE=0 / 1 fixes the choice, -1: by the rule in evpk_prep
+    int ncx3 = 0, nry3 = 0, R3 = 24, nstrips3 = 0, ns_tot3_cur = 0;
+    unsigned char *d_flags3 = nullptr;
+    int *d_strips3 = nullptr, *d_ns3 = nullptr;
+    int triple_launches = 0, kernel3_timed = 0;
+    float kernel3_ms = 0.f;
     unsigned char *d_flags = nullptr;
     int *d_strips = nullptr;
     unsigned long long *d_counts = nullptr;
@@ -359,9 +368,8 @@ struct evpk_ctx {
     std::vector<hipEvent_t> bev;   // event pairs around sampled halo / fold / ghost-zone updates of the subcycle loop (timer_bound)
     int bound_updates = 0, bound_timed = 0;
     float bound_ms = 0.f;
-    std::vector<char> kev_is_double;
-    int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around every 7th subcycle kernel launch (default), 2 all
-    std::vector<int> kev_slot;     // launch index -> event pair index, -1 not timed
+    std::vector<int> kev_kind, kev_count;   // per timed span: subcycles per launch of its kernels (1, 2, 3), launches inside it
+    int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around launches 1..6 of every 8 (default), 2 every launch
     int nkev = 0;
     bool force_exchange = false;   // EVPK_FORCE_EXCHANGE=1: single rank takes the multi-rank pack/exchange/unpack path (tests)
     std::string err;
@@ -898,9 +906,9 @@ static PairList state_pairs(int SB) {
 }
 
 static void destroy_impl(evpk_ctx *c) {
-    if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }      // (after the async copies into it have drained)
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
@@ -1685,6 +1693,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
         HIPCHK(c, hipMemcpyAsync(c->h_counts + 2, c->d_ns2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         c->ns_tot2_cur = ns_tot2;
         c->nstrips2 = ns_tot2;            // the launches cover the upper bound; the true number replaces it after the loop
+        c->counts_pending = true;         // (evpk_get_stats before the loop synchronises and reads them)
         c->nstrips2e = c->nstrips2i = 0;
         c->ksub = 0;
         c->prepped = true;
@@ -1839,8 +1848,8 @@ static int eap_subcycle(evpk_ctx *c, int32_t nsub) {
     const dim3 gT((s.nxl + 1 + 63) / 64, (s.nyl + 1 + 3) / 4), gU((s.nxl + 63) / 64, (s.nyl + 3) / 4);
     const double dte = c->p.dt / (double)c->p.ndte, dtei = 1.0 / dte;        // ice_dyn_shared.F90:209-210
     c->kernel_ms = c->kernel2_ms = 0.f;
-    c->kernel_launches = c->double_launches = 0;
-    c->kernel_timed = c->kernel2_timed = 0;
+    c->kernel_launches = c->double_launches = c->triple_launches = 0;
+    c->kernel_timed = c->kernel2_timed = c->kernel3_timed = 0;
     c->bound_updates = 0; c->bound_timed = 0; c->bound_ms = 0.f;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (c->ksub == 0) hipLaunchKernelGGL(k_eap_reset, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);
@@ -1864,6 +1873,16 @@ static int eap_subcycle(evpk_ctx *c, int32_t nsub) {
     return xp_check(c);
 }
 
+// dev_strips: the counts k_strip_flags2 / k_compact_strips left in the page-locked h_counts (valid once the stream has passed the
+// copies evpk_prep queued)
+static void take_counts(evpk_ctx *c) {
+    c->icellt = (long long)c->h_counts[0];
+    c->icellu = (long long)c->h_counts[1];
+    c->nstrips2 = (int)(c->h_counts[2] & 0xffffffffull);
+    if (c->tuned_icellt == -2) c->tuned_icellt = c->icellt;
+    c->counts_pending = false;
+}
+
 static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     if (!c->prepped) FAIL(c, "evpk_prep has not been called");
     if (nsub < 0) FAIL(c, "nsub < 0");
@@ -1877,33 +1896,50 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     const bool need_halo = (c->nranks > 1) || (c->ns == EVPK_BND_TRIPOLE) || c->force_exchange;
     c->kernel_ms = 0.f;
     c->kernel2_ms = 0.f;
+    c->kernel3_ms = 0.f;
     c->kernel_launches = 0;
-    c->kernel_timed = c->kernel2_timed = 0;
-    c->kev_is_double.assign((size_t)nsub + 1, 0);
+    c->kernel_timed = c->kernel2_timed = c->kernel3_timed = 0;
     if (c->time_kernels) {
         while ((int)c->kev.size() < 2 * nsub + 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
     }
-    c->kev_slot.assign((size_t)nsub + 1, -1);
+    c->kev_kind.clear(); c->kev_count.clear();
     c->nkev = 0;
-    // event pairs cost ~8 us per launch: by default only every 7th launch is timed (the launches are alike; 7 is coprime
-    // to the ghost-zone period, so split and whole launches are both sampled on x-slabs)
-    auto timed = [&](int launch) { return c->time_kernels == 2 || (c->time_kernels == 1 && launch % 7 == 3); };
-    auto ev_begin = [&](hipStream_t st) -> int {
-        if (!timed(c->kernel_launches)) return 0;
-        c->kev_slot[c->kernel_launches] = c->nkev;
-        return hipEventRecord(c->kev[2 * c->nkev], st) != hipSuccess;
-    };
-    auto ev_end = [&](hipStream_t st) -> int {
-        if (c->kev_slot[c->kernel_launches] < 0) return 0;
-        const int rc = hipEventRecord(c->kev[2 * c->nkev + 1], st) != hipSuccess;
+    // Kernel timing by HIP events on the stream the launches go to, in SPANS: one event in front of a run of consecutive
+    // launches of one kind (1, 2 or 3 subcycles per launch) and one behind it, launches 1..6 of every 8 by default
+    // (EVPK_TIME_KERNELS=2: every launch a span of its own, 0: none).  A span's time / its launches is the per-launch time as the
+    // stream's timeline has it (launch gaps included, the ~4-8 us an event pair costs spread over six launches), so that
+    // launches x average never exceeds the loop time.  A span ends early when the kind or the stream changes and in front of any
+    // halo / fold / exchange work.
+    bool span_open = false;
+    int span_kind = 0, span_n = 0;
+    hipStream_t span_stream = nullptr;
+    const int span_len = c->time_kernels == 2 ? 1 : 6;
+    auto span_close = [&]() -> int {
+        if (!span_open) return 0;
+        span_open = false;
+        const int rc = hipEventRecord(c->kev[2 * c->nkev + 1], span_stream) != hipSuccess;
+        c->kev_kind.push_back(span_kind); c->kev_count.push_back(span_n);
         c->nkev++;
         return rc;
+    };
+    auto ev_begin = [&](hipStream_t st, int kind) -> int {
+        if (span_open && (kind != span_kind || st != span_stream) && span_close()) return 1;
+        if (span_open || !c->time_kernels) return 0;
+        if (c->time_kernels == 1 && c->kernel_launches % 8 != 1) return 0;
+        if (2 * c->nkev + 2 > (int)c->kev.size()) return 0;
+        span_open = true; span_kind = kind; span_n = 0; span_stream = st;
+        return hipEventRecord(c->kev[2 * c->nkev], st) != hipSuccess;
+    };
+    auto ev_end = [&](hipStream_t) -> int {
+        if (!span_open) return 0;
+        return (++span_n >= span_len) ? span_close() : 0;
     };
     // the same sampling for the halo / fold / ghost-zone updates (what the reference books under timer_bound): an event pair
     // on the stream the update runs on, every 5th update by default
     c->bound_updates = 0; c->bound_timed = 0; c->bound_ms = 0.f;
     bool bound_open = false;
     auto bound_begin = [&](hipStream_t st) {
+        (void)span_close();
         bound_open = c->time_kernels == 2 || (c->time_kernels == 1 && c->bound_updates % 5 == 2);
         c->bound_updates++;
         if (!bound_open) return;
@@ -1921,6 +1957,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (c->eap && c->ksub == 0) hipLaunchKernelGGL(k_eap_reset, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);   // ice_dyn_eap.F90:171-180, :284-298
     c->double_launches = 0;
+    c->triple_launches = 0;
     c->xb_swaps = 0;
     c->zone_exchanges = 0;
     c->zone_bytes = 0;
@@ -2060,10 +2097,9 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
             if (!split) {
                 if (join()) FAIL(c, "hipStreamWaitEvent failed");
                 if (c->nstrips2 > 0) {
-                    if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
+                    if (ev_begin(c->stream, 2)) FAIL(c, "hipEventRecord failed");
                     launch_sub2(c, a, c->stream, revp, pair_ends_evp);
                     if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
-                    c->kev_is_double[c->kernel_launches] = 1;
                     c->kernel_launches++;
                     c->double_launches++;
                 }
@@ -2077,10 +2113,10 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 // interior(k) needs round k-1's kernels, not its exchange: it reads no ghost zone
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evE, 0));
                 a.strips = c->d_strips2i; a.nstrips = c->nstrips2i;
-                if (ev_begin(c->stream2)) FAIL(c, "hipEventRecord failed");
+                if (ev_begin(c->stream2, 2)) FAIL(c, "hipEventRecord failed");
                 launch_sub2(c, a, c->stream2, revp, false);
                 if (ev_end(c->stream2)) FAIL(c, "hipEventRecord failed");
-                c->kev_is_double[c->kernel_launches] = 1;
+                if (span_close()) FAIL(c, "hipEventRecord failed");      // (the other stream's work follows)
                 c->kernel_launches++;
                 c->double_launches++;
                 HIPCHK(c, hipEventRecord(c->evI, c->stream2));
@@ -2119,7 +2155,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
             const bool t1 = c->R <= 7 && (long long)c->nstrips * (c->R + 1) <= 8LL * c->nsimd && c->tile_force != 0;
             const dim3 gt(c->nstrips), bt((c->R + 1) * 64);
             const size_t lds = (size_t)(c->R + 1) * 2048;
-            if (ev_begin(c->stream)) FAIL(c, "hipEventRecord failed");
+            if (ev_begin(c->stream, 1)) FAIL(c, "hipEventRecord failed");
             if (c->eap) {       // eap(dt): stress_eap + stepu in one launch (k_eap_sub), stepa every tenth subcycle (ice_dyn_eap.F90:345-447)
                 EapSubArgs x{c->E, (last || n == nsub) ? 1 : 0};
                 if (last) hipLaunchKernelGGL(k_eap_sub<true>, g, b, 0, c->stream, a, x);
@@ -2152,6 +2188,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         if (c->zone_mode) { c->zone_left = 0; c->inner_ok = true; }     // one ghost column is current, the deeper zone is not
         c->m_need = 1;
     }
+    if (span_close()) FAIL(c, "hipEventRecord failed");
     if (join()) FAIL(c, "hipStreamWaitEvent failed");
     // leave the ghost columns 0 / nxl+1 of the state current (download, finish, a later one-subcycle launch)
     if (c->zone_mode && !c->inner_ok && zone_exchange(c->cur ? F_STATE1 : F_STATE0)) return 1;
@@ -2159,12 +2196,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
-    if (c->dev_strips) {          // what evpk_prep left in flight has arrived with the loop's last event
-        c->icellt = (long long)c->h_counts[0];
-        c->icellu = (long long)c->h_counts[1];
-        c->nstrips2 = (int)(c->h_counts[2] & 0xffffffffull);
-        if (c->tuned_icellt == -2) c->tuned_icellt = c->icellt;
-    }
+    if (c->dev_strips) take_counts(c);   // what evpk_prep left in flight has arrived with the loop's last event
     if (xp_check(c)) return 1;
     if (ov_trying) {
         if (c->ov_trial >= 1) c->ov_ms[c->ov_trial - 1] = c->loop_ms;
@@ -2180,19 +2212,19 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         c->bound_ms = (float)(sum / c->bound_timed * c->bound_updates);
     }
     if (c->time_kernels) {
-        // mean of the timed launches of each kind, scaled to all launches of that kind
-        double sum1 = 0.0, sum2 = 0.0;
-        int n1 = 0, n2 = 0;
-        for (int n = 0; n < c->kernel_launches; n++) {
-            const int k = c->kev_slot[n];
-            if (k < 0) continue;
+        // per kind: time of its spans / launches inside them, scaled to all launches of that kind
+        double sum[4] = {0, 0, 0, 0};
+        int cnt[4] = {0, 0, 0, 0};
+        for (int k = 0; k < c->nkev; k++) {
             float ms = 0.f;
             HIPCHK(c, hipEventElapsedTime(&ms, c->kev[2 * k], c->kev[2 * k + 1]));
-            if (c->kev_is_double[n]) { sum2 += ms; n2++; } else { sum1 += ms; n1++; }
+            sum[c->kev_kind[k]] += ms; cnt[c->kev_kind[k]] += c->kev_count[k];
         }
-        if (n2) c->kernel2_ms = (float)(sum2 / n2 * c->double_launches);
-        if (n1) c->kernel_ms = (float)(sum1 / n1 * (c->kernel_launches - c->double_launches));
-        c->kernel_timed = n1; c->kernel2_timed = n2;
+        const int n1 = c->kernel_launches - c->double_launches - c->triple_launches;
+        if (cnt[1]) c->kernel_ms = (float)(sum[1] / cnt[1] * n1);
+        if (cnt[2]) c->kernel2_ms = (float)(sum[2] / cnt[2] * c->double_launches);
+        if (cnt[3]) c->kernel3_ms = (float)(sum[3] / cnt[3] * c->triple_launches);
+        c->kernel_timed = cnt[1]; c->kernel2_timed = cnt[2]; c->kernel3_timed = cnt[3];
     }
     return 0;
 }
@@ -2625,6 +2657,16 @@ extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat,
     if (halo(c, F_SIG2, 1, false, true, 0.0, -1, nullptr, false, -1, 0, 3)) return 1;
     const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks), gu((s.nxl + 63) / 64, (s.nyl + 3) / 4);
     double *pin = c->uw_pool;
+    // ghost cells that border an eliminated land block: bound_state's halo update writes its fill (0) into the STATE arrays
+    // there (mpi/ice_boundary.F90 srcBlock == 0), not compute_tracers of an empty cell -- the coverage of the slab, halo-updated
+    // like any centre scalar (1 beyond an open / closed boundary: no neighbour at all), tells k_upw_scatter which they are
+    int fcov = -1;
+    if (!c->full_cover || c->nranks > 1) {     // (collective: another rank may have an eliminated block where this one has none)
+        hipLaunchKernelGGL(k_fill_plane, g2, B2D, 0, c->stream, s, (int)F_WORK1, 0.0);
+        hipLaunchKernelGGL(k_cover_f, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (int)F_WORK1);
+        if (halo(c, F_WORK1, 1, false, false, 1.0)) return 1;
+        fcov = F_WORK1;
+    }
     // aice0: physical cells only (no halo update in the reference)
     hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dev5[0], nblk, pin);
     hipLaunchKernelGGL(k_upwind, gu, B2D, 0, c->stream, s, dt, (int)F_SIG1, (int)F_SIG2, (const double *)pin, tab[0]);
@@ -2636,7 +2678,7 @@ extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat,
         }
         if (planes_halo(c, c->uw_tab, c->uw_sgn, nq, false)) return 1;             // bound_state
         hipLaunchKernelGGL(k_upw_scatter, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, (double *const *)c->uw_tab,
-                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0);
+                           c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0, fcov);
     }
     HIPCHK(c, hipGetLastError());
     for (int q = 0; q < 5; q++)
@@ -2979,6 +3021,11 @@ extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
 
 extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     if (!c || !o) return 1;
+    if (c->counts_pending) {      // between evpk_prep and the first evpk_subcycle on the device-compacted path: wait for the counts
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) FAIL(c, "evpk_get_stats: hipStreamSynchronize failed");
+        take_counts(c);
+        if (xp_check(c)) return 1;    // (evpk_prep's own exchanges on this path are only checked here or after the loop)
+    }
     o->icellt = c->icellt; o->icellu = c->icellu;
     o->ncell_slab = (int64_t)c->s.nxl * c->s.nyl;
     o->nstrips = c->nstrips; o->nstrips_total = c->ncx * c->nry;
@@ -2995,5 +3042,16 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->compact_metrics = c->compact ? 1 : 0;
     o->transport = c->ipc ? EVPK_XP_IPC : c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
     o->band_row_exchanges = c->xb_swaps;
+    o->kernel3_ms = c->kernel3_ms; o->kernel3_launches = c->triple_launches; o->kernel3_timed = c->kernel3_timed;
+    o->strip_rows3 = c->use_triple ? c->R3 : 0; o->nstrips3 = c->use_triple ? c->nstrips3 : 0;
+    int nr = 0;
+    if (c->comm && ncclCommCount(c->comm, &nr) != ncclSuccess) nr = -1;
+    o->rccl_ranks = nr;
+    o->device = c->device;
+    int dom = 0, bus = 0, dev = 0;
+    (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, c->device);
+    (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, c->device);
+    (void)hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, c->device);
+    o->device_pci = (dom << 16) | (bus << 8) | dev;
     return 0;
 }

@@ -2506,7 +2506,10 @@ __global__ void k_upw_gather(Slab s, const BlockDesc *bd, int nxb, int nyb, UpwS
 // Every cell of every block with a source is written (physical cells: work_to_state; ghost cells: bound_state, whose values are
 // the neighbour's -- the same arithmetic on the same numbers); a ghost cell without one gets bound_state's fill (0) on the
 // outermost row / column of the array and keeps the caller's value elsewhere (as k_scatter_halo).
-__global__ void k_upw_scatter(Slab s, const BlockDesc *bd, int nxb, int nyb, UpwState u, int n, double *const *planes, int cyclic, int tripole) {
+// fcov >= 0: the halo-updated coverage plane -- a ghost cell whose source lies in an eliminated land block gets the halo fill 0 in
+// every state array (bound_state's ice_HaloUpdate, srcBlock == 0), not compute_tracers of an empty cell.
+__global__ void k_upw_scatter(Slab s, const BlockDesc *bd, int nxb, int nyb, UpwState u, int n, double *const *planes, int cyclic, int tripole,
+                              int fcov) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y + 1;
     const int b = blockIdx.z;
@@ -2520,7 +2523,8 @@ __global__ void k_upw_scatter(Slab s, const BlockDesc *bd, int nxb, int nyb, Upw
     const int gi = s.i0 + si - 1, gj = s.j0 + sj - 1;
     const bool padding = (i > d.ihi + 1 || j > d.jhi + 1);
     const bool has_src = phys || (!padding && ((gi >= 1 && gi <= s.nxg) || cyclic) && ((gj >= 1 && gj <= s.nyg) || (tripole && gj == s.nyg + 1)));
-    if (!has_src && edge) {                             // bound_state's fill on the outermost row / column
+    const bool landsrc = has_src && !phys && fcov >= 0 && FD(s, fcov, cell(s, si, sj)) == 0.0;
+    if ((!has_src && edge) || landsrc) {                // bound_state's fill on the outermost row / column, or next to a land block
         u.aicen[bc] = 0.0; u.vicen[bc] = 0.0; u.vsnon[bc] = 0.0;
         for (int it = 0; it < u.ntrcr; it++) t[(size_t)it * nn] = 0.0;
         return;

@@ -80,7 +80,10 @@ class Stats(ct.Structure):
                 ("zone_cols", ct.c_int32), ("zone_exchanges", ct.c_int32), ("zone_bytes", ct.c_int64),
                 ("overlap_split", ct.c_int32), ("tile_kernel", ct.c_int32), ("kernel_timed", ct.c_int32),
                 ("kernel2_timed", ct.c_int32), ("bound_ms", ct.c_float), ("bound_updates", ct.c_int32),
-                ("compact_metrics", ct.c_int32), ("transport", ct.c_int32), ("band_row_exchanges", ct.c_int32)]
+                ("compact_metrics", ct.c_int32), ("transport", ct.c_int32), ("band_row_exchanges", ct.c_int32),
+                ("kernel3_ms", ct.c_float), ("kernel3_launches", ct.c_int32), ("kernel3_timed", ct.c_int32),
+                ("strip_rows3", ct.c_int32), ("nstrips3", ct.c_int32),
+                ("rccl_ranks", ct.c_int32), ("device", ct.c_int32), ("device_pci", ct.c_int32)]
 
 XP_NAMES = {0: "none", 1: "rccl", 2: "shm relay", 3: "ipc peer-mapped", 4: "self (forced exchange)"}
 

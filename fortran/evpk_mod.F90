@@ -83,6 +83,9 @@
          integer (c_int32_t) :: overlap_split, tile_kernel, kernel_timed, kernel2_timed
          real (c_float) :: bound_ms
          integer (c_int32_t) :: bound_updates, compact_metrics, transport, band_row_exchanges
+         real (c_float) :: kernel3_ms
+         integer (c_int32_t) :: kernel3_launches, kernel3_timed, strip_rows3, nstrips3
+         integer (c_int32_t) :: rccl_ranks, device, device_pci
       end type evpk_stats
 
       ! evpk_eap_state (include/evpk.h): the structure tensor at the four corners, its cell means, the EAP history fields

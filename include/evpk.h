@@ -161,6 +161,12 @@ typedef struct {
     int32_t transport;                 /* EVPK_XP_*: what carries the exchanges between ranks */
     int32_t band_row_exchanges;        /* x-slab ranks on a tripole grid: row messages with the mirror rank in the last evpk_subcycle call
                                           (the fold itself runs inside the pair launches, band_pair) */
+    float kernel3_ms;                  /* the same as kernel2_ms for the three-subcycle pipeline kernel (k_subcycle3w) */
+    int32_t kernel3_launches, kernel3_timed;
+    int32_t strip_rows3, nstrips3;     /* its strip height and active strips */
+    int32_t rccl_ranks;                /* ncclCommCount of the context's communicator (0: no RCCL communicator) */
+    int32_t device;                    /* hipGetDevice ordinal the context runs on */
+    int32_t device_pci;                /* (PCI domain << 16) | (bus << 8) | device of that GPU: distinct per physical device */
 } evpk_stats;
 
 enum { EVPK_XP_NONE = 0, EVPK_XP_RCCL = 1, EVPK_XP_SHM_RELAY = 2, EVPK_XP_IPC = 3, EVPK_XP_SELF = 4 };
@@ -193,6 +199,10 @@ int evpk_finish(evpk_ctx *c);
 int evpk_download(evpk_ctx *c, evpk_state *st);
 int evpk_sync(evpk_ctx *c);
 
+/* On one rank (and on x-slab ranks of a tripole grid) evpk_prep compacts the strip list on the device and returns without
+ * waiting for icellt / icellu / nstrips2; evpk_subcycle fills them in when its loop has run.  evpk_get_stats called in between
+ * synchronises the compute stream once and returns this evp's counts (never stale ones); it also reports a transport error that
+ * an exchange of evpk_prep raised on that path (otherwise reported by evpk_subcycle). */
 int evpk_get_stats(evpk_ctx *c, evpk_stats *s);
 
 /* principal_stress (ice_dyn_shared.F90:853-893; called by ice_history for sig1/sig2): normalised principal
@@ -214,6 +224,9 @@ int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2);
  * (mpi/ice_boundary.F90; ice_dyn_evp.F90:416-481): the tripole north ghost row of a1 from the top row of a2; a ghost cell
  * next to an eliminated land block gets 0; nothing else is touched.
  * Pinned by tests/golden/ref_*.npz (outputs of the reference's own routines). */
+/* Both stage through the scratch state planes that evpk_prep primes for the subcycle loop on some paths: call them before
+ * evpk_prep or after evpk_finish / evpk_run, never between evpk_prep and the end of the subcycle loop (the reference has no halo
+ * update of a foreign field inside evp's loop either, ice_dyn_evp.F90:345-409). */
 int evpk_halo_update(evpk_ctx *c, double *a, int32_t nz, int32_t field_loc, int32_t field_type, double fill);
 int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2);
 

@@ -184,6 +184,8 @@ def test_hot_kernels_keep_their_register_budget():
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box: the resource remarks come from the compiler")
     src = os.path.join(ROOT, "cice5_amd", "csrc", "evpk_api.hip")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                         "-Wno-unused-function", "--cuda-device-only", "-c", "-o", os.devnull, src, "-Rpass-analysis=kernel-resource-usage"],

@@ -9,9 +9,10 @@ overlap on two streams, the tripole fold (mirror slab, or the packed exchange wi
 slab with the single-process oracle.
 
 On a node with SEVERAL GPUs (none was available to the builder: the cross-device visibility of the peer-mapped buffers, the
-flags and RCCL itself are unverified) the same cases run one rank per device and also over RCCL:
-    EVPK_TEST_DEVICES=per_rank EVPK_TEST_XPS=ipc,rccl python -m pytest tests/test_multirank_gpu.py -q -m gpu
-("rccl": rank 0 makes the ncclUniqueId, the harness hands it to the other ranks; refused by RCCL when two ranks share a device)."""
+flags and RCCL itself are unverified) the same cases run one rank per device BY THEMSELVES -- a case whose world size fits
+torch.cuda.device_count() puts rank r on device r -- and the parametrised cases also run over RCCL ("rccl": rank 0 makes the
+ncclUniqueId, the harness hands it to the other ranks; refused by RCCL when two ranks share a device, so those cases are skipped
+where the devices do not suffice).  EVPK_TEST_DEVICES=shared|per_rank and EVPK_TEST_XPS=ipc,shm,rccl override both choices."""
 import os
 import sys
 import traceback
@@ -65,9 +66,8 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q, uidq=None):
         xmin = synth.global_min_dx(case)
         xp = env.get("TEST_XP", "shm")
         dev = 0
-        if os.environ.get("EVPK_TEST_DEVICES") == "per_rank":
-            import torch
-            dev = rank % max(1, torch.cuda.device_count())
+        if env.get("TEST_PER_RANK"):
+            dev = rank % max(1, _device_count())
         if xp == "rccl":                          # rank 0 made the id (see _run); every rank takes one copy from the queue
             uid = uidq.get(timeout=120)
         else:
@@ -218,9 +218,27 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q, uidq=None):
         q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0, 0, 0))
 
 
+def _device_count():
+    """GPUs of the box (torch.cuda.device_count() does not initialise the GPU in the calling process on this image)"""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 1
+
+
+def _per_rank(world):
+    mode = os.environ.get("EVPK_TEST_DEVICES", "auto")
+    return mode == "per_rank" or (mode == "auto" and _device_count() >= world)
+
+
 def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None, xp="shm"):
     import multiprocessing as mp
     env = dict(env or {}, TEST_XP=xp)
+    if _per_rank(world):
+        env["TEST_PER_RANK"] = "1"
+    elif xp == "rccl":
+        pytest.skip(f"RCCL refuses {world} ranks on {_device_count()} device(s)")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     tag = "evpk_t_" + uuid.uuid4().hex[:12]
@@ -255,7 +273,8 @@ def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None, xp="shm"):
     return res
 
 
-XPS = [x for x in os.environ.get("EVPK_TEST_XPS", "ipc,shm").split(",") if x]
+# transports of the parametrised cases: RCCL joins by itself on a box with at least two GPUs
+XPS = [x for x in os.environ.get("EVPK_TEST_XPS", "ipc,shm,rccl" if _device_count() >= 2 else "ipc,shm").split(",") if x]
 
 
 @pytest.mark.parametrize("xp", XPS)

@@ -887,6 +887,43 @@ def test_transport_upwind_with_the_state_transforms(ns, bs, tag):
     assert np.array_equal(sg[4][:, :, kw["ntrcr"]:], state[4][:, :, kw["ntrcr"]:])
 
 
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_transport_upwind_state_next_to_eliminated_land_blocks(ns):
+    """bound_state next to an eliminated land block (ice_domain.F90:387-441): the halo update writes its fill 0 into the ghost
+    cells of aicen / vicen / vsnon / trcrn there (mpi/ice_boundary.F90, srcBlock == 0) -- not compute_tracers of an empty cell,
+    which would leave Tsfc = Tocnfrz and fbri = 1 (round 3's advisor finding)."""
+    nx, ny, bsx, bsy = 120, 96, 6, 4
+    case = synth.SynthCase(nx=nx, ny=ny, land="continents", ns_boundary=C.BND_NAMES[ns])
+    full = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns)
+    ff = synth.make_block_fields(case, full)
+    work = [int(ff["tmask"][n, b.jlo - 1:b.jhi, b.ilo - 1:b.ihi].any()) for n, b in enumerate(full.local_blocks)]
+    assert sum(work) < len(work)
+    for k in (0, len(work) - 1):
+        work[k] = 1
+    d = blocks.create_distrb_cart(nx, ny, bsx, bsy, work_per_block=work, ns_boundary_type=ns)
+    assert d.nblocks < full.nblocks
+    f = synth.make_block_fields(case, d)
+    xmin = synth.global_min_dx(case)
+    state, kw = _upwind_state(d, f, 11, "lvl_ponds")
+    fo, fg = util.clone(f), util.clone(f)
+    orc.evp(d, orc.make_params(3600.0, 12, xmin), fo)
+    s = dyn.EvpDynamics(d, fg, ndte=12, xmin=xmin)
+    s.init_evp(3600.0)
+    s.evp(3600.0)
+    so, sg = [a.copy() for a in state], [a.copy() for a in state]
+    orc.transport_upwind_state(d, 3600.0, fo, *so, **kw)
+    s.ctx.transport_upwind_state(3600.0, *sg, **kw)
+    s.close()
+    every = util.cell_mask(d, "all")
+    for name, a, b_ in zip(("aice0", "aicen", "vicen", "vsnon", "trcrn"), sg, so):
+        m = every if a.ndim == 3 else (every[:, None] if a.ndim == 4 else every[:, None, None])
+        m = np.broadcast_to(m, a.shape)
+        assert np.array_equal(a[m], b_[m]), (name, int((a[m] != b_[m]).sum()), np.argwhere((a != b_) & m)[:4])
+    # the case bites: some ghost cell next to a land block holds the fill where compute_tracers would have left Tocnfrz
+    ghost = ~util.cell_mask(d, "phys")
+    assert (so[4][:, :, kw["nt_Tsfc"] - 1][np.broadcast_to(ghost[:, None], so[1].shape)] == 0.0).any()
+
+
 def _remap_on_device(d, f, mm, tm, tables, dt, order, midpt, env=None, monkeypatch=None):
     """horizontal_remap through the C ABI on synthetic velocities uploaded as the resident state"""
     ttype, depend, has = tables
