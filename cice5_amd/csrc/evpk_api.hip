@@ -862,6 +862,13 @@ static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp
     }
 }
 
+// three subcycles in one launch: one workgroup of three waves per strip (k_subcycle3w)
+static void launch_sub3(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp) {
+    const dim3 g(((a.nstrips + 7) / 8) * 8), b(192);            // multiple of 8: XCD remap in the kernel
+    if (c->compact) { if (revp) hipLaunchKernelGGL((k_subcycle3w<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle3w<false, true>), g, b, 0, st, a); }
+    else            { if (revp) hipLaunchKernelGGL((k_subcycle3w<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle3w<false, false>), g, b, 0, st, a); }
+}
+
 // ---- ghost zones (zW columns per side) of a list of pair planes: x-slab neighbours ------------------------
 // compact: only the rows of the four zone windows that hold an active cell (lists made at prep), else all rows
 static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact) {
@@ -913,7 +920,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->d_mstrips, c->eap_pool, c->eap_tab, c->sigB, c->sigB1};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->d_mstrips, c->eap_pool, c->eap_tab, c->sigB, c->sigB1, c->d_flags3, c->d_strips3, c->d_ns3};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1379,6 +1386,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (const char *bf = getenv("EVPK_BAND_FUSED")) c->band_fused = atoi(bf) != 0;
     if (const char *ds = getenv("EVPK_DEVICE_STRIPS")) c->dev_strips_env = atoi(ds) != 0;
+    if (const char *tr = getenv("EVPK_TRIPLE")) c->triple_env = atoi(tr) != 0 ? 1 : 0;
     HIPCHK(c, hipMalloc(&c->d_ns2, sizeof(int) * 2));
     HIPCHK(c, hipMemset(c->d_ns2, 0, sizeof(int) * 2));
     HIPCHK(c, hipHostMalloc((void **)&c->h_counts, sizeof(unsigned long long) * 4, hipHostMallocDefault));
@@ -1573,6 +1581,38 @@ static int tune_R2(evpk_ctx *c) {
     return 0;
 }
 
+// Strip list of the three-subcycle pipeline kernel (k_subcycle3w): flags and ordered compaction on the device, the kernel reads the
+// list's length from d_ns3; the host never waits for it.  One rank without ghost zones, marching (not tile) pairs, no tripole band
+// (round 4, stage a); EVPK_TRIPLE=0 / 1 overrides.
+static int prep_triple(evpk_ctx *c, int G) {
+    Slab &s = c->s;
+    const bool can = c->use_double && !c->eap && c->nranks == 1 && !c->zone_mode && !c->force_exchange && !c->band_mode &&
+                     !c->tile_mode && c->prefetch && c->p.ndte >= 5 && s.nyl >= 8;
+    c->use_triple = can && c->triple_env == 1;
+    if (!c->use_triple) return 0;
+    if (!c->d_flags3) {
+        const size_t n3 = (size_t)((s.nxl + 2 * (ZW_MAX - 2) + STRIP3_W - 1) / STRIP3_W) * (s.nyl + 2);
+        HIPCHK(c, hipMalloc(&c->d_flags3, n3));
+        HIPCHK(c, hipMalloc(&c->d_strips3, sizeof(int) * n3));
+        HIPCHK(c, hipMalloc(&c->d_ns3, sizeof(int) * 2));
+        HIPCHK(c, hipMemset(c->d_ns3, 0, sizeof(int) * 2));
+    }
+    const char *e = getenv("EVPK_STRIP_ROWS3");
+    c->R3 = (e && atoi(e) > 0) ? std::max(2, std::min(atoi(e), 128)) : 24;
+    c->ncx3 = (s.nxl + 2 * G + STRIP3_W - 1) / STRIP3_W;
+    c->nry3 = (s.nyl + 1 + c->R3 - 1) / c->R3;
+    const int tot = c->ncx3 * c->nry3;
+    hipLaunchKernelGGL(k_strip_flags2, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx3, c->nry3, c->R3,
+                       (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, G, c->d_flags3, (unsigned int *)nullptr,
+                       (unsigned long long *)nullptr, (int)STRIP3_W, (int)STRIP3_OWN0, 2);
+    hipLaunchKernelGGL(k_compact_strips, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)c->d_flags3, tot, c->d_strips3, c->d_ns3);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_counts + 3, c->d_ns3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->ns_tot3_cur = tot;
+    c->nstrips3 = tot;                // (the true number arrives with the loop's last event, as nstrips2 does)
+    return 0;
+}
+
 // Strip list of the one-subcycle kernel (and, when the two-subcycle kernel is off, the active-cell counts): flags on the
 // device, compaction on the host.  Called by evpk_prep when only that kernel exists, else on first use after a prep.
 static int strips1(evpk_ctx *c) {
@@ -1680,6 +1720,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     if (!c->use_double && strips1(c)) return 1;
     if (c->use_double && tune_R2(c)) return 1;
     const int ns_tot2 = c->ncx2 * c->nry2;
+    if (prep_triple(c, G)) return 1;
     // one rank, or x-slab ranks on a tripole grid (no edge / interior lists, no row lists of the zone windows to make on the host)
     c->dev_strips = c->dev_strips_env && c->use_double &&
                     ((!c->zone_mode && c->nranks == 1 && !c->force_exchange) || (c->zone_mode && c->band_mode));
@@ -2003,6 +2044,23 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
         // the LAST variant of k_subcycle)
         const bool pair_ends_evp = pairs && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte);
+        // three subcycles in one launch (k_subcycle3w) while at least one more follows in this evp: the evp then ends with the pair /
+        // single launches below, which write the diagnostics of the last subcycle
+        if (c->use_triple && nsub - n >= 3 && c->ksub + 3 < c->p.ndte) {
+            a.strips = c->d_strips3; a.nstrips = c->ns_tot3_cur; a.nsdev = c->d_ns3; a.ncx = c->ncx3; a.R = c->R3; a.G = 0;
+            a.wrap = (c->ew == EVPK_BND_CYCLIC) ? 1 : 0;
+            if (join()) FAIL(c, "hipStreamWaitEvent failed");
+            if (ev_begin(c->stream, 3)) FAIL(c, "hipEventRecord failed");
+            launch_sub3(c, a, c->stream, revp);
+            if (ev_end(c->stream)) FAIL(c, "hipEventRecord failed");
+            c->kernel_launches++;
+            c->triple_launches++;
+            evE_valid = false;
+            c->ksub += 3;
+            n += 3;
+            c->cur ^= 1;
+            continue;
+        }
         if (pair_inside || pair_ends_evp) {
             a.strips = c->d_strips2; a.nstrips = c->dev_strips ? c->ns_tot2_cur : c->nstrips2; a.ncx = c->ncx2; a.R = c->R2; a.G = G;
             a.nsdev = c->dev_strips ? c->d_ns2 : nullptr;
@@ -2197,6 +2255,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
     if (c->dev_strips) take_counts(c);   // what evpk_prep left in flight has arrived with the loop's last event
+    if (c->use_triple) c->nstrips3 = (int)(c->h_counts[3] & 0xffffffffull);
     if (xp_check(c)) return 1;
     if (ov_trying) {
         if (c->ov_trial >= 1) c->ov_ms[c->ov_trial - 1] = c->loop_ms;
@@ -3031,7 +3090,7 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->nstrips = c->nstrips; o->nstrips_total = c->ncx * c->nry;
     o->subcycles_done = c->ksub;
     o->loop_ms = c->loop_ms;
-    o->kernel_ms = c->kernel_ms; o->kernel_launches = c->kernel_launches - c->double_launches;
+    o->kernel_ms = c->kernel_ms; o->kernel_launches = c->kernel_launches - c->double_launches - c->triple_launches;
     o->kernel2_ms = c->kernel2_ms; o->kernel2_launches = c->double_launches;
     o->strip_rows = c->R; o->strip_rows2 = c->use_double ? c->R2 : 0; o->nstrips2 = c->use_double ? c->nstrips2 : 0;
     o->zone_cols = c->zone_mode ? c->zW : 0; o->zone_exchanges = c->zone_exchanges; o->zone_bytes = c->zone_bytes;

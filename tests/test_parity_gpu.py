@@ -251,6 +251,59 @@ def test_two_subcycle_kernel_equals_single(monkeypatch):
         assert not util.compare(d, outs[1], outs[0])
 
 
+@pytest.mark.parametrize("R3", ["", "3", "7", "40"])
+def test_three_subcycle_kernel_equals_single(R3, monkeypatch):
+    """k_subcycle3w (three subcycles per launch, one wave per subcycle stage, sigma and (u, v) handed from stage to stage through
+    the LDS) vs k_subcycle only: bit-identical -- ndte with every remainder mod 3, subcycles issued in odd pieces, revised EVP, a
+    non-cyclic E-W boundary, grids narrower / wider than one 58-column strip, strip heights 3, 7, 24 (default) and 40."""
+    monkeypatch.setenv("EVPK_TILE", "0")
+    if R3:
+        monkeypatch.setenv("EVPK_STRIP_ROWS3", R3)
+    for (nx, ny), kw, ndte, pieces in [((130, 96), dict(land="continents"), 31, [31]), ((130, 96), dict(land="continents"), 41, [7, 12, 22]),
+                                       ((130, 96), dict(ice="full"), 24, [24]), ((200, 75), dict(land="continents"), 36, [36]),
+                                       ((57, 40), dict(ice="full"), 17, [4, 13]), ((117, 64), dict(land="continents", ew="open"), 30, [30])]:
+        ew = kw.pop("ew", "cyclic")
+        case = synth.SynthCase(nx=nx, ny=ny, ew_boundary=C.BND_NAMES[ew], **kw)
+        d = blocks.create_distrb_cart(nx, ny, nx, ny, ew_boundary_type=ew)
+        f = synth.make_block_fields(case, d)
+        xmin = synth.global_min_dx(case)
+        outs = []
+        for mode in ("single", "triple"):
+            monkeypatch.setenv("EVPK_DOUBLE", "0" if mode == "single" else "1")
+            monkeypatch.setenv("EVPK_TRIPLE", "0" if mode == "single" else "1")
+            g = util.clone(f)
+            s = dyn.EvpDynamics(d, g, ndte=ndte, xmin=xmin, revised_evp=(ndte == 24))
+            s.init_evp(3600.0)
+            s.ctx.upload(g); s.ctx.prep()
+            for n in pieces:
+                s.ctx.subcycle(n)
+            st = s.ctx.stats()
+            assert (st.kernel3_launches > 0) == (mode == "triple"), (mode, st.kernel3_launches)
+            s.ctx.finish(); s.ctx.download(g)
+            s.close()
+            outs.append(g)
+        bad = util.compare(d, outs[1], outs[0])
+        assert not bad, ((nx, ny), kw, ndte, bad[:4])
+        assert np.abs(outs[0]["uvel"]).max() > 1e-4
+
+
+def test_three_subcycle_kernel_equals_oracle(monkeypatch):
+    """the same kernel against the oracle: BASELINE config 3's grid in 24 blocks and a 3-call warm start (new / lost ice)"""
+    monkeypatch.setenv("EVPK_TILE", "0")
+    monkeypatch.setenv("EVPK_TRIPLE", "1")
+    seen = []
+    real = dyn.EvpDynamics.close
+
+    def close(self):
+        seen.append(int(self.ctx.stats().kernel3_launches))
+        real(self)
+
+    monkeypatch.setattr(dyn.EvpDynamics, "close", close)
+    _both(360, 300, 15, 300, land="continents", ndte=24, ncalls=2)
+    _both(320, 384, 80, 96, ndte=31, ncalls=3)
+    assert all(n > 0 for n in seen), seen
+
+
 @pytest.mark.parametrize("H", ["", "2", "5", "13"])
 def test_tile_kernel_equals_oracle(H, monkeypatch):
     """k_subcycle2t (EVPK_TILE=1: one row per wave, three workgroup barriers instead of the north march -- the small-slab
