@@ -345,6 +345,11 @@ struct evpk_ctx {
     unsigned char *d_flags3 = nullptr;
     int *d_strips3 = nullptr, *d_ns3 = nullptr;
     int triple_launches = 0, kernel3_timed = 0;
+    int prio = 0;                        // EVPK_PRIO: SubArgs.prio
+    size_t flags3_n = 0;
+    bool lpt = true;                     // EVPK_LPT=0: the strips of k_subcycle3w in position order instead of longest first
+    const char *dbg_file = nullptr;      // EVPK_DEBUG_CLOCKS
+    unsigned long long *d_dbg = nullptr;
     float kernel3_ms = 0.f;
     unsigned char *d_flags = nullptr;
     int *d_strips = nullptr;
@@ -920,7 +925,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->d_mstrips, c->eap_pool, c->eap_tab, c->sigB, c->sigB1, c->d_flags3, c->d_strips3, c->d_ns3};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->d_mstrips, c->eap_pool, c->eap_tab, c->sigB, c->sigB1, c->d_flags3, c->d_strips3, c->d_ns3, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1387,6 +1392,8 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     if (const char *bf = getenv("EVPK_BAND_FUSED")) c->band_fused = atoi(bf) != 0;
     if (const char *ds = getenv("EVPK_DEVICE_STRIPS")) c->dev_strips_env = atoi(ds) != 0;
     if (const char *tr = getenv("EVPK_TRIPLE")) c->triple_env = atoi(tr) != 0 ? 1 : 0;
+    c->dbg_file = getenv("EVPK_DEBUG_CLOCKS");
+    if (const char *pr = getenv("EVPK_PRIO")) c->prio = atoi(pr);
     HIPCHK(c, hipMalloc(&c->d_ns2, sizeof(int) * 2));
     HIPCHK(c, hipMemset(c->d_ns2, 0, sizeof(int) * 2));
     HIPCHK(c, hipHostMalloc((void **)&c->h_counts, sizeof(unsigned long long) * 4, hipHostMallocDefault));
@@ -1592,7 +1599,9 @@ static int prep_triple(evpk_ctx *c, int G) {
     if (!c->use_triple) return 0;
     if (!c->d_flags3) {
         const size_t n3 = (size_t)((s.nxl + 2 * (ZW_MAX - 2) + STRIP3_W - 1) / STRIP3_W) * (s.nyl + 2);
-        HIPCHK(c, hipMalloc(&c->d_flags3, n3));
+        HIPCHK(c, hipMalloc(&c->d_flags3, 2 * n3));      // flags, then the work (active rows) of every strip
+        c->flags3_n = n3;
+        if (const char *e = getenv("EVPK_LPT")) c->lpt = atoi(e) != 0;
         HIPCHK(c, hipMalloc(&c->d_strips3, sizeof(int) * n3));
         HIPCHK(c, hipMalloc(&c->d_ns3, sizeof(int) * 2));
         HIPCHK(c, hipMemset(c->d_ns3, 0, sizeof(int) * 2));
@@ -1604,8 +1613,9 @@ static int prep_triple(evpk_ctx *c, int G) {
     const int tot = c->ncx3 * c->nry3;
     hipLaunchKernelGGL(k_strip_flags2, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx3, c->nry3, c->R3,
                        (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0, G, c->d_flags3, (unsigned int *)nullptr,
-                       (unsigned long long *)nullptr, (int)STRIP3_W, (int)STRIP3_OWN0, 2);
-    hipLaunchKernelGGL(k_compact_strips, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)c->d_flags3, tot, c->d_strips3, c->d_ns3);
+                       (unsigned long long *)nullptr, (int)STRIP3_W, (int)STRIP3_OWN0, 2, c->d_flags3 + c->flags3_n);
+    if (c->lpt) hipLaunchKernelGGL(k_sort_strips, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)(c->d_flags3 + c->flags3_n), tot, c->d_strips3, c->d_ns3);
+    else hipLaunchKernelGGL(k_compact_strips, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)c->d_flags3, tot, c->d_strips3, c->d_ns3);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_counts + 3, c->d_ns3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->ns_tot3_cur = tot;
@@ -2027,7 +2037,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nsdev = nullptr; a.xm = nullptr;
+        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nsdev = nullptr; a.xm = nullptr; a.dbg = nullptr; a.prio = c->prio;
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
@@ -2044,6 +2054,14 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         // ... or when the second of them is the last one (k_subcycle2<.., LAST2>; tripole: the second band launch is then
         // the LAST variant of k_subcycle)
         const bool pair_ends_evp = pairs && nsub - n >= 2 && (c->ksub + 2 == c->p.ndte);
+        // EVPK_DEBUG_CLOCKS=<file>: the timeline of the loop's sixth launch (per strip: start / end clock of its wave, where it ran)
+        const bool dbg_now = c->dbg_file && c->kernel_launches == 5 && c->evp_count == 3;
+        if (dbg_now) {
+            if (!c->d_dbg) { HIPCHK(c, hipMalloc(&c->d_dbg, sizeof(unsigned long long) * 4 * 65536)); }
+            HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, sizeof(unsigned long long) * 4 * 65536, c->stream));
+            hipLaunchKernelGGL(k_dbg_clock, dim3(1), dim3(64), 0, c->stream, c->d_dbg + 4 * 65535);      // the stream's clock just before the launch
+            a.dbg = c->d_dbg;
+        }
         // three subcycles in one launch (k_subcycle3w) while at least one more follows in this evp: the evp then ends with the pair /
         // single launches below, which write the diagnostics of the last subcycle
         if (c->use_triple && nsub - n >= 3 && c->ksub + 3 < c->p.ndte) {
@@ -2254,6 +2272,16 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(&c->loop_ms, c->ev0, c->ev1));
+    if (c->dbg_file && c->d_dbg && c->evp_count == 3) {
+        std::vector<unsigned long long> h((size_t)4 * 65536);
+        hipLaunchKernelGGL(k_dbg_clock, dim3(1), dim3(64), 0, c->stream, c->d_dbg + 4 * 65535 + 1);
+        HIPCHK(c, hipMemcpy(h.data(), c->d_dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+        if (FILE *fp = fopen(c->dbg_file, "w")) {
+            fprintf(fp, "# t0 %llu\n", h[(size_t)4 * 65535]);
+            for (int k = 0; k < 65535; k++) if (h[(size_t)4 * k]) fprintf(fp, "%d %llu %llu %llx\n", k, h[(size_t)4 * k], h[(size_t)4 * k + 1], h[(size_t)4 * k + 2]);
+            fclose(fp);
+        }
+    }
     if (c->dev_strips) take_counts(c);   // what evpk_prep left in flight has arrived with the loop's last event
     if (c->use_triple) c->nstrips3 = (int)(c->h_counts[3] & 0xffffffffull);
     if (xp_check(c)) return 1;

@@ -979,7 +979,25 @@ struct SubArgs {
                        // host launches for the upper bound nstrips and never waits for the count): one rank, the pair kernels
     int nband;         // > 0 (tripole, one rank, cyclic E-W): the first nband8 = 8*ceil(nband/8) workgroups of the launch are the
                        // tripole top band (band_pair); the strips follow
+    int prio;          // k_subcycle2p: != 0 -- a wave lowers its issue priority as it advances (3, 2, 1, 0 over the quarters of its march), so
+                       // that of the two waves of a SIMD the one that is BEHIND wins the VALU arbitration (by default the older wave wins
+                       // every time, finishes a third earlier and leaves the younger one alone on the SIMD, where a single dependent
+                       // fp64 stream issues at 5.3 us per step instead of 3.4 for two)
+    unsigned long long *dbg;   // != nullptr (EVPK_DEBUG_CLOCKS, one launch per evp): per strip of the list {start, end} of its wave in
+                               // s_memrealtime ticks (100 MHz) and the XCC / CU it ran on -- the launch's timeline (scripts/k_timeline.py)
 };
+__global__ void k_dbg_clock(unsigned long long *out) { if (threadIdx.x == 0) *out = wall_clock64(); }
+__device__ __forceinline__ void dbg_stamp(const SubArgs &a, int sid, int which) {
+    if (a.dbg && (threadIdx.x & 63) == 0) {
+        a.dbg[(size_t)sid * 4 + which] = wall_clock64();
+        if (which == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            a.dbg[(size_t)sid * 4 + 2] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+}
 
 // Neighbour-lane exchange as DPP whole-wave shifts (v_mov_b32_dpp wave_shl:1 / wave_shr:1, VALU only) instead of
 // ds_bpermute through the LDS crossbar: no lgkmcnt wait in the dependent stress -> stepu -> stress chain.  The lane
@@ -2009,6 +2027,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (sid >= ns) return;
     const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
+    dbg_stamp(a, sid, 0);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
     const int G = a.G;
@@ -2110,10 +2129,17 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     unsigned char m = mask_of(jb - 1), m_n1 = mask_of(jb), m_n2 = mask_of(jb + 1);
     issue(jb - 1, m, 0, m_n1);
 
+    const int pq = a.prio ? max(1, (R + 3) / 4) : 0;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t <= R + 2; t++) {
         const int r = jb - 1 + t;
         if (r > nyl + 2) break;
         const bool rok = rowok(r);
+        if (a.prio) {
+            if (t == pq) __builtin_amdgcn_s_setprio(2);
+            else if (t == 2 * pq) __builtin_amdgcn_s_setprio(1);
+            else if (t == 3 * pq) __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---------------- operands of this step: LDS -> registers ----------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2239,6 +2265,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         mpp = mp; mp = m; m = m_n1; m_n1 = m_n2; m_n2 = m_n3;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may be in flight when the wave ends
+    dbg_stamp(a, sid, 1);
 }
 
 template __global__ void k_subcycle2p<false, false, false>(SubArgs);
@@ -2284,14 +2311,14 @@ __global__ __launch_bounds__(192, 3) void k_subcycle3w(SubArgs a) {
     const Slab &s = a.s;
     const int lane = threadIdx.x & 63;
     const int S = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // this wave's subcycle stage: 0, 1, 2
-    // one strip per workgroup; blockIdx -> strip keeps consecutive strips of the list on one XCD (as k_subcycle2).  Every exit below
-    // is taken by the whole workgroup: all three waves pass the same number of barriers.
+    // one strip per workgroup.  Every exit below is taken by the whole workgroup: all three waves pass the same number of barriers.
+    // The list is sorted by work, longest strips first (k_sort_strips), and the dispatcher hands out workgroups in blockIdx order:
+    // block b takes entry b (the XCDs, b mod 8, then get equal shares of every length class).
     const int ns = a.nsdev ? __builtin_amdgcn_readfirstlane(*a.nsdev) : a.nstrips;
-    const int chunk = a.nsdev ? ((ns + 7) >> 3) : (int)(gridDim.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk) return;
-    const int sid = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    const int sid = (int)blockIdx.x;
     if (sid >= ns) return;
     const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
+    if (S == 0) dbg_stamp(a, sid, 0);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
     const int G = a.G;
@@ -2514,6 +2541,7 @@ __global__ __launch_bounds__(192, 3) void k_subcycle3w(SubArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // this step's LDS writes are in place; loads stay in flight
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may be in flight when the wave ends
+    if (S == 2) dbg_stamp(a, sid, 1);
 }
 
 template __global__ void k_subcycle3w<false, false>(SubArgs);
@@ -2698,7 +2726,8 @@ template __global__ void k_subcycle2t<true, true>(SubArgs);
 // W, own0, rmar: strip width, first owned lane and the rows read beyond the owned ones -- 61, 1, 1 for the pair kernels, 59, 2, 2
 // for k_subcycle3w
 __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, unsigned char *flags, unsigned int *count,
-                               unsigned long long *cells = nullptr, int W = STRIP2_W, int own0 = 1, int rmar = 1) {
+                               unsigned long long *cells = nullptr, int W = STRIP2_W, int own0 = 1, int rmar = 1,
+                               unsigned char *work = nullptr /* rows of the window with an active cell (<= 255): the strip's run time */) {
     const int sid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (sid >= ncx * nry) return;
@@ -2709,15 +2738,16 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
     if (cyc) { ci = (c - 1) % s.nxl; if (ci < 0) ci += s.nxl; ci += 1; ok = true; }
     else ok = (c >= -G && c <= s.nxl + 2 + G);
     const int jb = ry * R + 1;
-    int any = 0, nt = 0, nu = 0;
+    int any = 0, nt = 0, nu = 0, nrows = 0;
     const bool owned = (lane >= own0 && lane <= own0 + W - 1 && c >= 1 && c <= s.nxl);
-    if (ok)
-        for (int r = jb - rmar; r <= jb + R + rmar; r++) {
-            if (r < 1 || r > s.nyl + 1) continue;
-            const unsigned char m = s.cmask[mcell(s, ci, r)];
-            if (m) any = 1;
-            if (owned && r >= jb && r < jb + R && r <= s.nyl) { nt += (m & CM_T) ? 1 : 0; nu += (m & CM_U) ? 1 : 0; }
-        }
+    for (int r = jb - rmar; r <= jb + R + rmar; r++) {
+        if (r < 1 || r > s.nyl + 1) continue;
+        const unsigned char m = ok ? s.cmask[mcell(s, ci, r)] : (unsigned char)0;
+        if (m) any = 1;
+        if (work && __ballot(m != 0)) nrows++;
+        if (owned && r >= jb && r < jb + R && r <= s.nyl) { nt += (m & CM_T) ? 1 : 0; nu += (m & CM_U) ? 1 : 0; }
+    }
+    if (work && lane == 0) work[sid] = (unsigned char)min(nrows, 255);
     const unsigned long long b = __ballot(any);
     if (cells) {
         for (int o = 32; o > 0; o >>= 1) { nt += __shfl_down(nt, o); nu += __shfl_down(nu, o); }
@@ -2792,6 +2822,24 @@ __global__ __launch_bounds__(1024) void k_compact_strips(const unsigned char *fl
         __syncthreads();
     }
     if (threadIdx.x == 0) *count = base;
+}
+
+// the active strips (work > 0) in order of DESCENDING work -- longest first, so that the workgroups the dispatcher hands out last
+// are the short ones and the launch's tail is short (k_subcycle3w runs its strips in two or three rounds of resident workgroups).
+// One workgroup: histogram, offsets, scatter (the order inside a class of equal work is arbitrary: it changes no result).
+__global__ __launch_bounds__(1024) void k_sort_strips(const unsigned char *work, int n, int *list, int *count) {
+    __shared__ int hist[256], cur[256];
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) if (work[k]) atomicAdd(&hist[work[k]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int w = 255; w >= 1; w--) { cur[w] = off; off += hist[w]; }
+        *count = off;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) if (work[k]) list[atomicAdd(&cur[work[k]], 1)] = k;
 }
 
 // ------------------------------------------------------------------------------------
