@@ -345,7 +345,7 @@ struct evpk_ctx {
     unsigned char *d_flags3 = nullptr;
     int *d_strips3 = nullptr, *d_ns3 = nullptr;
     int triple_launches = 0, kernel3_timed = 0;
-    int prio = 0;                        // EVPK_PRIO: SubArgs.prio
+    int prio = 1;                        // EVPK_PRIO (default 1): SubArgs.prio
     size_t flags3_n = 0;
     bool lpt = true;                     // EVPK_LPT=0: the strips of k_subcycle3w in position order instead of longest first
     const char *dbg_file = nullptr;      // EVPK_DEBUG_CLOCKS

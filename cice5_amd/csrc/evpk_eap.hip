@@ -387,9 +387,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     double s1c = 0.0, s5c = 0.0, s2r = 0.0, s7r = 0.0;
     unsigned char mprev = 0;
+    const int pq = a.prio ? max(1, (R + 1 + 3) / 4) : 0;      // progress-based issue priority: SubArgs.prio
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     for (int jj = 0; jj <= R; jj++) {
         const int j = jb + jj;
         if (j > s.nyl + 1) break;
+        if (a.prio) {
+            if (jj == pq) __builtin_amdgcn_s_setprio(2);
+            else if (jj == 2 * pq) __builtin_amdgcn_s_setprio(1);
+            else if (jj == 3 * pq) __builtin_amdgcn_s_setprio(0);
+        }
         char *const rb = base + (size_t)j * rowb;
         const size_t km = (size_t)j * s.pitch + C0 + i;
         unsigned char m = 0;

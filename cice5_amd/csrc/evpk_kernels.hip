@@ -1050,9 +1050,74 @@ __device__ __forceinline__ void store_sig(char *rb, size_t pp, int SB, unsigned 
     stp(rb, pp, SB + S_S12, lo, g.s121, g.s122);  stp(rb, pp, SB + S_S12 + 2, lo, g.s123, g.s124);
 }
 
+// ---- fp64 sqrt and divide, FOUR AT A TIME (round 4) ----
+// hipcc expands sqrt() and `/` of doubles into dependent chains of 17 and 11 instructions (v_rsq_f64 / v_rcp_f64, Newton steps as
+// fma, v_div_scale / v_div_fmas / v_div_fixup) and emits the four Deltas and the four divisions of a T cell ONE AFTER THE OTHER: 112
+// instructions in which every one waits for the one before it (the profile of k_subcycle2p: one wave alone on its SIMD issues one
+// VALU instruction per 8.4 cycles, a pair per 5.5, where the pipe takes one per 4).  Here the same sequences -- instruction for
+// instruction what the compiler emits (AMDGPU lowering of fsqrt.f64 / fdiv.f64), hence the same correctly rounded results -- are
+// written out for four operands side by side, so that each instruction has three independent neighbours between itself and its
+// consumer.  tests: every parity test runs through them (bit-identical with the oracle's sqrt() and `/`).
+__device__ __forceinline__ void sqrt4_f64(double &x0, double &x1, double &x2, double &x3) {
+    const double tiny = 0x1.0p-767;
+    const bool s0 = x0 < tiny, s1 = x1 < tiny, s2 = x2 < tiny, s3 = x3 < tiny;
+    const double a0 = __builtin_amdgcn_ldexp(x0, s0 ? 256 : 0), a1 = __builtin_amdgcn_ldexp(x1, s1 ? 256 : 0);
+    const double a2 = __builtin_amdgcn_ldexp(x2, s2 ? 256 : 0), a3 = __builtin_amdgcn_ldexp(x3, s3 ? 256 : 0);
+    const double y0 = __builtin_amdgcn_rsq(a0), y1 = __builtin_amdgcn_rsq(a1), y2 = __builtin_amdgcn_rsq(a2), y3 = __builtin_amdgcn_rsq(a3);
+    double g0 = a0 * y0, g1 = a1 * y1, g2 = a2 * y2, g3 = a3 * y3;
+    double h0 = y0 * 0.5, h1 = y1 * 0.5, h2 = y2 * 0.5, h3 = y3 * 0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5), r1 = __builtin_fma(-h1, g1, 0.5), r2 = __builtin_fma(-h2, g2, 0.5), r3 = __builtin_fma(-h3, g3, 0.5);
+    g0 = __builtin_fma(g0, r0, g0); g1 = __builtin_fma(g1, r1, g1); g2 = __builtin_fma(g2, r2, g2); g3 = __builtin_fma(g3, r3, g3);
+    double d0 = __builtin_fma(-g0, g0, a0), d1 = __builtin_fma(-g1, g1, a1), d2 = __builtin_fma(-g2, g2, a2), d3 = __builtin_fma(-g3, g3, a3);
+    h0 = __builtin_fma(h0, r0, h0); h1 = __builtin_fma(h1, r1, h1); h2 = __builtin_fma(h2, r2, h2); h3 = __builtin_fma(h3, r3, h3);
+    g0 = __builtin_fma(d0, h0, g0); g1 = __builtin_fma(d1, h1, g1); g2 = __builtin_fma(d2, h2, g2); g3 = __builtin_fma(d3, h3, g3);
+    d0 = __builtin_fma(-g0, g0, a0); d1 = __builtin_fma(-g1, g1, a1); d2 = __builtin_fma(-g2, g2, a2); d3 = __builtin_fma(-g3, g3, a3);
+    g0 = __builtin_fma(d0, h0, g0); g1 = __builtin_fma(d1, h1, g1); g2 = __builtin_fma(d2, h2, g2); g3 = __builtin_fma(d3, h3, g3);
+    g0 = __builtin_amdgcn_ldexp(g0, s0 ? -128 : 0); g1 = __builtin_amdgcn_ldexp(g1, s1 ? -128 : 0);
+    g2 = __builtin_amdgcn_ldexp(g2, s2 ? -128 : 0); g3 = __builtin_amdgcn_ldexp(g3, s3 ? -128 : 0);
+    const int zi = 0x260;       // +inf | +0 | -0: sqrt(x) = x
+    x0 = __builtin_amdgcn_class(a0, zi) ? a0 : g0; x1 = __builtin_amdgcn_class(a1, zi) ? a1 : g1;
+    x2 = __builtin_amdgcn_class(a2, zi) ? a2 : g2; x3 = __builtin_amdgcn_class(a3, zi) ? a3 : g3;
+}
+// q_k = n / d_k
+__device__ __forceinline__ void div4_f64(double n, double d0, double d1, double d2, double d3, double &q0, double &q1, double &q2, double &q3) {
+    bool f0, f1, f2, f3, u0, u1, u2, u3;
+    const double e0 = __builtin_amdgcn_div_scale(n, d0, false, &u0), e1 = __builtin_amdgcn_div_scale(n, d1, false, &u1);
+    const double e2 = __builtin_amdgcn_div_scale(n, d2, false, &u2), e3 = __builtin_amdgcn_div_scale(n, d3, false, &u3);
+    double r0 = __builtin_amdgcn_rcp(e0), r1 = __builtin_amdgcn_rcp(e1), r2 = __builtin_amdgcn_rcp(e2), r3 = __builtin_amdgcn_rcp(e3);
+    double t0 = __builtin_fma(-e0, r0, 1.0), t1 = __builtin_fma(-e1, r1, 1.0), t2 = __builtin_fma(-e2, r2, 1.0), t3 = __builtin_fma(-e3, r3, 1.0);
+    r0 = __builtin_fma(r0, t0, r0); r1 = __builtin_fma(r1, t1, r1); r2 = __builtin_fma(r2, t2, r2); r3 = __builtin_fma(r3, t3, r3);
+    t0 = __builtin_fma(-e0, r0, 1.0); t1 = __builtin_fma(-e1, r1, 1.0); t2 = __builtin_fma(-e2, r2, 1.0); t3 = __builtin_fma(-e3, r3, 1.0);
+    r0 = __builtin_fma(r0, t0, r0); r1 = __builtin_fma(r1, t1, r1); r2 = __builtin_fma(r2, t2, r2); r3 = __builtin_fma(r3, t3, r3);
+    const double m0 = __builtin_amdgcn_div_scale(n, d0, true, &f0), m1 = __builtin_amdgcn_div_scale(n, d1, true, &f1);
+    const double m2 = __builtin_amdgcn_div_scale(n, d2, true, &f2), m3 = __builtin_amdgcn_div_scale(n, d3, true, &f3);
+    const double p0 = m0 * r0, p1 = m1 * r1, p2 = m2 * r2, p3 = m3 * r3;
+    t0 = __builtin_fma(-e0, p0, m0); t1 = __builtin_fma(-e1, p1, m1); t2 = __builtin_fma(-e2, p2, m2); t3 = __builtin_fma(-e3, p3, m3);
+    q0 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(t0, r0, p0, f0), d0, n);
+    q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(t1, r1, p1, f1), d1, n);
+    q2 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(t2, r2, p2, f2), d2, n);
+    q3 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(t3, r3, p3, f3), d3, n);
+}
+// (q0, q1) = (n0, n1) / d: two quotients by one denominator, side by side (stepu)
+__device__ __forceinline__ void div2_f64(double n0, double n1, double d, double &q0, double &q1) {
+    bool f0, f1, u0, u1;
+    const double e0 = __builtin_amdgcn_div_scale(n0, d, false, &u0), e1 = __builtin_amdgcn_div_scale(n1, d, false, &u1);
+    double r0 = __builtin_amdgcn_rcp(e0), r1 = __builtin_amdgcn_rcp(e1);
+    double t0 = __builtin_fma(-e0, r0, 1.0), t1 = __builtin_fma(-e1, r1, 1.0);
+    r0 = __builtin_fma(r0, t0, r0); r1 = __builtin_fma(r1, t1, r1);
+    t0 = __builtin_fma(-e0, r0, 1.0); t1 = __builtin_fma(-e1, r1, 1.0);
+    r0 = __builtin_fma(r0, t0, r0); r1 = __builtin_fma(r1, t1, r1);
+    const double m0 = __builtin_amdgcn_div_scale(n0, d, true, &f0), m1 = __builtin_amdgcn_div_scale(n1, d, true, &f1);
+    const double p0 = m0 * r0, p1 = m1 * r1;
+    t0 = __builtin_fma(-e0, p0, m0); t1 = __builtin_fma(-e1, p1, m1);
+    q0 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(t0, r0, p0, f0), d, n0);
+    q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(t1, r1, p1, f1), d, n1);
+}
+
 // ---- stress of one T cell (ice_dyn_evp.F90:618-847), the reference's operation order ----
 // u/v naming: _ij = (i,j), _mj = (i-1,j), _im = (i,j-1), _mm = (i-1,j-1).  g: sigma in -> sigma out.
-template <bool DIAG>
+// ILP: the four Deltas and the four divisions through sqrt4_f64 / div4_f64 (the kernels with registers to spare for it)
+template <bool DIAG, bool ILP = false>
 __device__ __forceinline__ void stress_cell(const TMet &m, double u_ij, double u_mj, double u_im, double u_mm,
                                             double v_ij, double v_mj, double v_im, double v_mm,
                                             double ecci, double arlx1i, double denom1, double tarear,
@@ -1078,10 +1143,12 @@ __device__ __forceinline__ void stress_cell(const TMet &m, double u_ij, double u
     const double shearse = -cym * v_im - dyt * v_mm - cxp * u_im + dxt * u_ij;
 
     // Delta (:657-660)
-    const double Deltane = sqrt(divune * divune + ecci * (tensionne * tensionne + shearne * shearne));
-    const double Deltanw = sqrt(divunw * divunw + ecci * (tensionnw * tensionnw + shearnw * shearnw));
-    const double Deltase = sqrt(divuse * divuse + ecci * (tensionse * tensionse + shearse * shearse));
-    const double Deltasw = sqrt(divusw * divusw + ecci * (tensionsw * tensionsw + shearsw * shearsw));
+    double Deltane = divune * divune + ecci * (tensionne * tensionne + shearne * shearne);
+    double Deltanw = divunw * divunw + ecci * (tensionnw * tensionnw + shearnw * shearnw);
+    double Deltase = divuse * divuse + ecci * (tensionse * tensionse + shearse * shearse);
+    double Deltasw = divusw * divusw + ecci * (tensionsw * tensionsw + shearsw * shearsw);
+    if (ILP) sqrt4_f64(Deltane, Deltanw, Deltase, Deltasw);
+    else { Deltane = sqrt(Deltane); Deltanw = sqrt(Deltanw); Deltase = sqrt(Deltase); Deltasw = sqrt(Deltasw); }
 
     if (DIAG) {                                                                     // :665-677
         dg.divu = 0.25 * (divune + divunw + divuse + divusw) * tarear;
@@ -1094,10 +1161,14 @@ __device__ __forceinline__ void stress_cell(const TMet &m, double u_ij, double u
     }
 
     // replacement pressure / Delta (:683-697)
-    double c0ne = m.strength / fmax(Deltane, m.tiny);
-    double c0nw = m.strength / fmax(Deltanw, m.tiny);
-    double c0sw = m.strength / fmax(Deltasw, m.tiny);
-    double c0se = m.strength / fmax(Deltase, m.tiny);
+    double c0ne, c0nw, c0sw, c0se;
+    if (ILP) div4_f64(m.strength, fmax(Deltane, m.tiny), fmax(Deltanw, m.tiny), fmax(Deltasw, m.tiny), fmax(Deltase, m.tiny), c0ne, c0nw, c0sw, c0se);
+    else {
+        c0ne = m.strength / fmax(Deltane, m.tiny);
+        c0nw = m.strength / fmax(Deltanw, m.tiny);
+        c0sw = m.strength / fmax(Deltasw, m.tiny);
+        c0se = m.strength / fmax(Deltase, m.tiny);
+    }
     if (DIAG) dg.prs = c0ne * Deltane;
     const double c1ne = c0ne * arlx1i, c1nw = c0nw * arlx1i, c1sw = c0sw * arlx1i, c1se = c0se * arlx1i;
     c0ne = c1ne * ecci; c0nw = c1nw * ecci; c0sw = c1sw * ecci; c0se = c1se * ecci;
@@ -1272,6 +1343,7 @@ __device__ __forceinline__ UStat load_ustat(const char *ru, size_t pp, unsigned 
     const double2 fo = ldp(ru, pp, F_FORCEX, lo), mf = ldp(ru, pp, F_UMASSDTI, lo);
     return UStat{va.x, va.y, oc.x, oc.y, fo.x, fo.y, mf.x, mf.y};
 }
+template <bool ILP = false>
 __device__ __forceinline__ void stepu_cell(const UStat &q, double uold, double vold, double ui, double vi,
                                            double sx, double sy, double brlx, double revp, double cosw, double sinw,
                                            double &un, double &vn, double &strintx, double &strinty) {
@@ -1289,8 +1361,11 @@ __device__ __forceinline__ void stepu_cell(const UStat &q, double uold, double v
     strinty = q.uarear * sy;
     const double cc1 = strintx + q.forcex + taux + q.umassdti * (brlx * uold + revp * ui);   // :731-734
     const double cc2 = strinty + q.forcey + tauy + q.umassdti * (brlx * vold + revp * vi);
-    un = (cca * cc1 + ccb * cc2) / ab2;                                             // :736-737
-    vn = (cca * cc2 - ccb * cc1) / ab2;
+    if (ILP) div2_f64(cca * cc1 + ccb * cc2, cca * cc2 - ccb * cc1, ab2, un, vn);
+    else {
+        un = (cca * cc1 + ccb * cc2) / ab2;                                         // :736-737
+        vn = (cca * cc2 - ccb * cc1) / ab2;
+    }
 }
 
 template <bool LAST, bool REVP>
@@ -1329,10 +1404,17 @@ __global__ __launch_bounds__(256) void k_subcycle(SubArgs a) {
     }
     double s1c = 0.0, s5c = 0.0, s2r = 0.0, s7r = 0.0;
     unsigned char mprev = 0;
+    const int pq = a.prio ? max(1, (R + 1 + 3) / 4) : 0;      // progress-based issue priority: SubArgs.prio
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
 
     for (int jj = 0; jj <= R; jj++) {
         const int j = jb + jj;
         if (j > s.nyl + 1) break;
+        if (a.prio) {
+            if (jj == pq) __builtin_amdgcn_s_setprio(2);
+            else if (jj == 2 * pq) __builtin_amdgcn_s_setprio(1);
+            else if (jj == 3 * pq) __builtin_amdgcn_s_setprio(0);
+        }
         char *const rb = base + (size_t)j * rowb;     // wave-uniform
         unsigned char m = 0;
         double u_ij = 0.0, u_mj = 0.0, v_ij = 0.0, v_mj = 0.0;
@@ -2007,6 +2089,10 @@ __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
 }
 
 // CM (compact metrics): slots 2,3 hold (HTN,HTE) at columns c and c-1 instead of the four metric pairs in slots 2..5
+#ifndef EVPK_K2P_ILP
+#define EVPK_K2P_ILP 0      // measured (round 4, scripts/lib_ab.sh): 255 VGPRs + 2 spilled, 0 ... -1.5 % -- the partner wave already fills the bubbles
+#endif
+constexpr bool K2P_ILP = EVPK_K2P_ILP != 0;
 template <bool REVP, bool LAST2, bool CM>
 __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two workgroups per CU: at most 256 VGPRs
     __shared__ double2 smem[4 * PF_SLOTS * 64];
@@ -2129,16 +2215,24 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     unsigned char m = mask_of(jb - 1), m_n1 = mask_of(jb), m_n2 = mask_of(jb + 1);
     issue(jb - 1, m, 0, m_n1);
 
+    // (prio 2: the wave in the odd hardware slot -- with two waves per SIMD the YOUNGER one, which loses every tie -- steps down
+    // half a quarter later than its partner: at equal progress it wins half of the time instead of never)
     const int pq = a.prio ? max(1, (R + 3) / 4) : 0;
+    int psh = 0;
+    if (a.prio >= 2) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        psh = (hwid & 1u) ? (pq + 1) / 2 : 0;
+    }
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t <= R + 2; t++) {
         const int r = jb - 1 + t;
         if (r > nyl + 2) break;
         const bool rok = rowok(r);
         if (a.prio) {
-            if (t == pq) __builtin_amdgcn_s_setprio(2);
-            else if (t == 2 * pq) __builtin_amdgcn_s_setprio(1);
-            else if (t == 3 * pq) __builtin_amdgcn_s_setprio(0);
+            if (t == pq + psh) __builtin_amdgcn_s_setprio(2);
+            else if (t == 2 * pq + psh) __builtin_amdgcn_s_setprio(1);
+            else if (t == 3 * pq + psh) __builtin_amdgcn_s_setprio(0);
         }
 
         // ---------------- operands of this step: LDS -> registers ----------------
@@ -2194,7 +2288,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         if (__any(t1act)) {
             if (t1act) {
                 Diag dg;
-                stress_cell<false>(mt, un_c, un_m, uo_c, uo_m, vn_c, vn_m, vo_c, vo_m, a.ecci, a.arlx1i, a.denom1, 0.0, g1, o1, dg);
+                stress_cell<false, K2P_ILP>(mt, un_c, un_m, uo_c, uo_m, vn_c, vn_m, vo_c, vo_m, a.ecci, a.arlx1i, a.denom1, 0.0, g1, o1, dg);
             }
         }
         const double a2n = shfl_dn1(o1.s2), a4n = shfl_dn1(o1.s4), a7n = shfl_dn1(o1.s7), a8n = shfl_dn1(o1.s8);
@@ -2204,7 +2298,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         if (__any(u1act)) {
             if (u1act) {
                 double sxi, syi;
-                stepu_cell(q1, uo_c, vo_c, ui1, vi1, ((a1c + a2r) + o1.s3) + a4n, ((a5c + o1.s6) + a7r) + a8n,
+                stepu_cell<K2P_ILP>(q1, uo_c, vo_c, ui1, vi1, ((a1c + a2r) + o1.s3) + a4n, ((a5c + o1.s6) + a7r) + a8n,
                            a.brlx, a.revp, a.cosw, a.sinw, u1_c, v1_c, sxi, syi);
             }
         }
@@ -2222,7 +2316,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
                 double tarear = 0.0;
                 if (LAST2) tarear = *reinterpret_cast<const double *>(rq + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
                 const TMet mt2 = CM ? tmet_from_lengths(hn_p, hn_pp, he_p, hw_p, tiny_p, str_p) : mtp;
-                stress_cell<LAST2>(mt2, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
+                stress_cell<LAST2, K2P_ILP>(mt2, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
                 if (own && q2 >= jb && q2 < jb + R && q2 <= a.jmax) {
                     store_sig(rq, pp, SW, lo, g2);
                     if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);
@@ -2242,7 +2336,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         if (__any(u2act)) {
             if (u2act) {
                 double un, vn, sxi, syi;
-                stepu_cell(qp, u1p_c, v1p_c, uip, vip, ((b1c + b2r) + o2.s3) + b4n, ((b5c + o2.s6) + b7r) + b8n,
+                stepu_cell<K2P_ILP>(qp, u1p_c, v1p_c, uip, vip, ((b1c + b2r) + o2.s3) + b4n, ((b5c + o2.s6) + b7r) + b8n,
                            a.brlx, a.revp, a.cosw, a.sinw, un, vn, sxi, syi);
                 char *const ru = base + (size_t)q3 * rowb;
                 stp(ru, pp, SW + S_U, lo, un, vn);
@@ -2740,6 +2834,18 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
     const int jb = ry * R + 1;
     int any = 0, nt = 0, nu = 0, nrows = 0;
     const bool owned = (lane >= own0 && lane <= own0 + W - 1 && c >= 1 && c <= s.nxl);
+    {   // quick reject: cmask is non-zero only where k_prep2 ran, i.e. in tiles of act_any -- 74 % of the bench grid has none
+        // (tiles: TILE_X x TILE_Y cells, the thread blocks of the per-evp kernels; columns beyond the ring count as the edge tile)
+        const int jlo = max(jb - rmar, 1), jhi = min(jb + R + rmar, s.nyl + 1);
+        const int tx = min(max(ci, 0), s.nxl + 1) / TILE_X;
+        bool hit = false;
+        if (ok)
+            for (int ty = jlo / TILE_Y; ty <= jhi / TILE_Y; ty++) hit = hit || s.act_any[ty * s.ntx + tx] != 0;
+        if (!__any(hit)) {
+            if (lane == 0) { if (flags) flags[sid] = 0; if (work) work[sid] = 0; }
+            return;
+        }
+    }
     for (int r = jb - rmar; r <= jb + R + rmar; r++) {
         if (r < 1 || r > s.nyl + 1) continue;
         const unsigned char m = ok ? s.cmask[mcell(s, ci, r)] : (unsigned char)0;

@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevpk.so")
+LIB_PATH = os.environ.get("EVPK_LIB") or os.path.join(_HERE, "libevpk.so")      # (EVPK_LIB: A/B builds of the kernels, scripts/)
 
 c_i32p = ct.POINTER(ct.c_int32)
 c_f64p = ct.POINTER(ct.c_double)

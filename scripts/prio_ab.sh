@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the pair kernel with and without progress-based wave priority (EVPK_PRIO), same box, alternating
+# A/B of the pair kernel without / with progress-based wave priority (EVPK_PRIO = 0, 1, 2), same box, alternating
 out=gpurun_out/${1:-prio}
 mkdir -p $out
 run() {
@@ -15,12 +15,12 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
 }
-for rep in 1 2; do
-  run base_$rep EVPK_PRIO=0
-  run prio_$rep EVPK_PRIO=1
+for rep in 1 2 3; do
+  for p in ${PRIOS:-0 1 2}; do run prio${p}_$rep EVPK_PRIO=$p; done
 done
 EXTRA="--ns open"
-run open_base EVPK_PRIO=0
-run open_prio EVPK_PRIO=1
-EVPK_PRIO=1 EVPK_DEBUG_CLOCKS=$out/tl_prio.txt python3 bench.py --ns open --steps 2 --warmup 2 --cpu-subcycles 0 --no-variants > /dev/null 2>&1
-python3 scripts/k_timeline.py $out/tl_prio.txt | head -5
+for p in ${PRIOS:-0 1 2}; do run open_prio$p EVPK_PRIO=$p; done
+for p in ${PRIOS:-0 1 2}; do
+EVPK_PRIO=$p EVPK_DEBUG_CLOCKS=$out/tl_prio$p.txt python3 bench.py --ns open --steps 2 --warmup 2 --cpu-subcycles 0 --no-variants > /dev/null 2>&1
+python3 scripts/k_timeline.py $out/tl_prio$p.txt | head -5
+done
