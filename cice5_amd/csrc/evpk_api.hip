@@ -346,6 +346,8 @@ struct evpk_ctx {
     int *d_strips3 = nullptr, *d_ns3 = nullptr;
     int triple_launches = 0, kernel3_timed = 0;
     int prio = 1;                        // EVPK_PRIO (default 1): SubArgs.prio
+    unsigned char *up_dat = nullptr;     // per tile: the uploaded inputs hold something (k_up_tiles)
+    bool up_dirty = true;                // ... and an upload has happened since it was computed
     size_t flags3_n = 0;
     bool lpt = true;                     // EVPK_LPT=0: the strips of k_subcycle3w in position order instead of longest first
     const char *dbg_file = nullptr;      // EVPK_DEBUG_CLOCKS
@@ -925,7 +927,7 @@ static void destroy_impl(evpk_ctx *c) {
     if (c->relay) { c->relay->close_(); delete c->relay; }
     if (c->ipc) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); c->ipc->close_(); delete c->ipc; }
     void *ptrs[] = {c->itd, c->stage_itd, c->d_zflags, c->d_zrows, c->s.F, c->s.tmask, c->s.umask, c->s.iceumask, c->s.cmask, c->s.tmphm, c->d_bd, c->stage, c->d_flags,
-                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->d_mstrips, c->eap_pool, c->eap_tab, c->sigB, c->sigB1, c->d_flags3, c->d_strips3, c->d_ns3, c->d_dbg};
+                    c->d_strips, c->d_counts, c->tile_buf, c->d_tune, c->d_flags2, c->d_strips2, c->d_strips2e, c->d_strips2i, c->d_band, c->cbuf, c->sendbuf, c->recvbuf, c->foldbuf, c->foldloc, c->foldall, c->d_slab_i0, c->foldseg, c->foldrcv, c->io_raw, c->io_act, c->tp_a, c->tp_b, c->tp_stage, c->rm_grid, c->rm_pool, c->rm_stage, c->rm_tab, c->rm_sgn, c->rm_bad, c->uw_pool, c->uw_tab, c->uw_sgn, c->d_ns2, c->d_bmap, c->m.F, c->m.cmask, c->d_mslab, c->xb_send, c->xb_recv, c->d_mstrips, c->eap_pool, c->eap_tab, c->sigB, c->sigB1, c->d_flags3, c->d_strips3, c->d_ns3, c->d_dbg, c->up_dat};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1432,6 +1434,7 @@ extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
     d.sparse_io = p->sparse_io;
     if ((p->revised_evp != 0) != (p->revp == 1.0)) FAIL(c, "revised_evp and revp disagree");
     c->have_params = true;
+    c->up_dirty = true;            // (rhoi / rhos enter the tile scan of the inputs)
     return 0;
 }
 
@@ -1459,6 +1462,7 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
         act = c->io_act;
     }
     c->io_sparse_now = sparse;
+    c->up_dirty = true;
     struct { const double *h; int f; bool need; } ip[] = {
         {in->aice, F_AICE, true}, {in->vice, F_VICE, true}, {in->vsno, F_VSNO, true}, {in->aice_init, F_AICE_INIT, true},
         {in->uocn, F_UOCN, true}, {in->vocn, F_VOCN, true}, {in->Cdn_ocn, F_CW, true}, {in->strength, F_STRENGTH, false},
@@ -1659,7 +1663,12 @@ extern "C" int evpk_prep(evpk_ctx *c) {
     s.tile_ice = c->tile_buf + (size_t)(c->tile_cur ? 2 : 0) * ntile;
     s.tile_dat = s.tile_ice + ntile;
     c->tile_cur ^= 1;
-    hipLaunchKernelGGL(k_prep1a, g2, B2D, 0, c->stream, s, c->p, fresh);
+    if (c->up_dirty) {      // the host's inputs changed since the last scan: which tiles hold anything at all
+        if (!c->up_dat) HIPCHK(c, hipMalloc(&c->up_dat, ntile));
+        hipLaunchKernelGGL(k_up_tiles, g2, B2D, 0, c->stream, s, c->p, c->up_dat);
+        c->up_dirty = false;
+    }
+    hipLaunchKernelGGL(k_prep1a, g2, B2D, 0, c->stream, s, c->p, fresh, (const unsigned char *)c->up_dat);
     hipLaunchKernelGGL(k_tile_dilate, dim3((s.ntx + 63) / 64, s.nty), dim3(64), 0, c->stream, s, (const unsigned char *)prev_ice,
                        (const unsigned char *)prev_dat, fresh);
     hipLaunchKernelGGL(k_prep1b, g2, B2D, 0, c->stream, s);

@@ -221,9 +221,33 @@ __global__ void k_fill_plane(Slab s, int f, double v) {
 // ------------------------------------------------------------------------------------
 // `fresh` = the state planes were just uploaded from the host (anything may be non-zero anywhere).
 // Otherwise cells that were inactive at the previous prep still hold their zeros and are skipped.
-__global__ void k_prep1a(Slab s, DevParams p, int fresh) {
+// up_dat (k_up_tiles, after every upload): tiles in which the host's inputs hold anything at all.  A tile without, that was not active
+// at the previous evp either, is left alone WITHOUT reading its cells (74 % of the bench grid; the inputs only change by uploads).
+__global__ void k_up_tiles(Slab s, DevParams p, unsigned char *up_dat) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    bool dat = false;
+    if (i <= s.nxl + 1 && j <= s.nyl + 1) {
+        const size_t k = cell(s, i, j);
+        const double vice = FD(s, F_VICE, k), vsno = FD(s, F_VSNO, k), aice = FD(s, F_AICE, k);
+        const double tmass = s.tmask[mcell(s, i, j)] != 0 ? (p.rhoi * vice + p.rhos * vsno) : 0.0;
+        dat = (tmass != 0.0) || (aice != 0.0) || (FD(s, F_AICE_INIT, k) != 0.0) || (FD(s, F_STRAIRXT, k) != 0.0) || (FD(s, F_STRAIRYT, k) != 0.0);
+    }
+    const int any = __syncthreads_or(dat ? 1 : 0);
+    if (threadIdx.x == 0 && threadIdx.y == 0) up_dat[blockIdx.y * s.ntx + blockIdx.x] = any ? 1 : 0;
+}
+
+__global__ void k_prep1a(Slab s, DevParams p, int fresh, const unsigned char *up_dat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    {   // (block-uniform: every thread of the tile leaves before the block-wide votes below)
+        const int t0 = blockIdx.y * s.ntx + blockIdx.x;
+        const bool edge0 = (blockIdx.x == 0 || blockIdx.x == (unsigned)s.ntx - 1 || blockIdx.y == 0 || blockIdx.y == (unsigned)s.nty - 1);
+        if (up_dat && !up_dat[t0] && !edge0 && !fresh && !s.act_any[t0]) {
+            if (threadIdx.x == 0 && threadIdx.y == 0) { s.tile_ice[t0] = 0; s.tile_dat[t0] = 0; }
+            return;
+        }
+    }
     const bool in = (i <= s.nxl + 1 && j <= s.nyl + 1);
     const size_t k = in ? cell(s, i, j) : 0, km = in ? mcell(s, i, j) : 0;
     double tmass = 0.0, wx = 0.0, wy = 0.0;
@@ -2846,12 +2870,22 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
             return;
         }
     }
-    for (int r = jb - rmar; r <= jb + R + rmar; r++) {
-        if (r < 1 || r > s.nyl + 1) continue;
-        const unsigned char m = ok ? s.cmask[mcell(s, ci, r)] : (unsigned char)0;
-        if (m) any = 1;
-        if (work && __ballot(m != 0)) nrows++;
-        if (owned && r >= jb && r < jb + R && r <= s.nyl) { nt += (m & CM_T) ? 1 : 0; nu += (m & CM_U) ? 1 : 0; }
+    const int rend = jb + R + rmar;
+    for (int r0 = jb - rmar; r0 <= rend; r0 += 8) {           // eight rows' mask bytes in flight at a time
+        unsigned char mm[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int r = r0 + q;
+            mm[q] = (ok && r >= 1 && r <= s.nyl + 1 && r <= rend) ? s.cmask[mcell(s, ci, r)] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int r = r0 + q;
+            const unsigned char m = mm[q];
+            if (m) any = 1;
+            if (work && __ballot(m != 0)) nrows++;
+            if (owned && r >= jb && r < jb + R && r <= s.nyl) { nt += (m & CM_T) ? 1 : 0; nu += (m & CM_U) ? 1 : 0; }
+        }
     }
     if (work && lane == 0) work[sid] = (unsigned char)min(nrows, 255);
     const unsigned long long b = __ballot(any);
