@@ -406,7 +406,7 @@ def roofline(r, icellt, icellu, revp):
     return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "alg_bytes_per_launch": alg, "alg_bytes_per_cell_update": alg / max(0.5 * (icellt + icellu) * nsub, 1.0),
             "avg_launch_ms": kern_ms, "launches": int(launches), "launches_timed": int(timed), "subcycles_per_launch": nsub,
-            "timing": "HIP events on the library's stream around runs of six consecutive launches (launches 1..6 of every 8): span "
+            "timing": "HIP events on the library's stream around runs of six consecutive launches (launches 3..8 of every 20): span "
                       "time / launches in the span, so launches x avg_launch_ms <= the loop time by construction",
             "kernel_ms_per_step_all_kinds": sum(k[q][0] for q in (1, 2, 3)) / max(r["steps"], 1),
             "compact_metrics": int(st.compact_metrics),

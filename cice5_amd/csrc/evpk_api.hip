@@ -376,7 +376,7 @@ struct evpk_ctx {
     int bound_updates = 0, bound_timed = 0;
     float bound_ms = 0.f;
     std::vector<int> kev_kind, kev_count;   // per timed span: subcycles per launch of its kernels (1, 2, 3), launches inside it
-    int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around launches 1..6 of every 8 (default), 2 every launch
+    int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around launches 3..8 of every 20 (default), 2 every launch
     int nkev = 0;
     bool force_exchange = false;   // EVPK_FORCE_EXCHANGE=1: single rank takes the multi-rank pack/exchange/unpack path (tests)
     std::string err;
@@ -1965,7 +1965,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     c->kev_kind.clear(); c->kev_count.clear();
     c->nkev = 0;
     // Kernel timing by HIP events on the stream the launches go to, in SPANS: one event in front of a run of consecutive
-    // launches of one kind (1, 2 or 3 subcycles per launch) and one behind it, launches 1..6 of every 8 by default
+    // launches of one kind (1, 2 or 3 subcycles per launch) and one behind it, launches 3..8 of every 20 by default
     // (EVPK_TIME_KERNELS=2: every launch a span of its own, 0: none).  A span's time / its launches is the per-launch time as the
     // stream's timeline has it (launch gaps included, the ~4-8 us an event pair costs spread over six launches), so that
     // launches x average never exceeds the loop time.  A span ends early when the kind or the stream changes and in front of any
@@ -1985,7 +1985,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
     auto ev_begin = [&](hipStream_t st, int kind) -> int {
         if (span_open && (kind != span_kind || st != span_stream) && span_close()) return 1;
         if (span_open || !c->time_kernels) return 0;
-        if (c->time_kernels == 1 && c->kernel_launches % 8 != 1) return 0;
+        if (c->time_kernels == 1 && c->kernel_launches % 20 != 3) return 0;      // (an event pair stalls the queue for a few microseconds)
         if (2 * c->nkev + 2 > (int)c->kev.size()) return 0;
         span_open = true; span_kind = kind; span_n = 0; span_stream = st;
         return hipEventRecord(c->kev[2 * c->nkev], st) != hipSuccess;

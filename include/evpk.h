@@ -138,8 +138,9 @@ typedef struct {
     int32_t nstrips_total;
     int32_t subcycles_done;  /* since the last evpk_prep */
     float loop_ms;           /* HIP-event time of the last evpk_subcycle call on the compute stream */
-    float kernel_ms;         /* time of the one-subcycle kernel launches (k_subcycle) of that call: mean of the HIP-event-timed
-                                launches (every 7th by default, EVPK_TIME_KERNELS=2: all, 0: none) x number of launches */
+    float kernel_ms;         /* time of the one-subcycle kernel launches (k_subcycle) of that call: HIP events around runs of six
+                                consecutive launches (launches 3..8 of every 20 by default; EVPK_TIME_KERNELS=2: every launch, 0: none),
+                                span time / launches in the spans x number of launches -- never more than loop_ms */
     int32_t kernel_launches; /* ... and their number */
     float kernel2_ms;        /* the same for the two-subcycle kernel (k_subcycle2) */
     int32_t kernel2_launches;
