@@ -1,0 +1,50 @@
+"""The C oracle against a second, independently written restatement of evp(dt) (tests/npref.py: whole-array numpy, another
+reading of the Fortran) -- bit for bit, on one-block domains.  CPU only.  What it buys: oracle/evp_oracle.c is no longer the
+only reading of ice_dyn_evp.F90 / ice_dyn_shared.F90 / ice_grid.F90 the HIP kernels are compared with."""
+import numpy as np
+import pytest
+
+from cice5_amd import synth
+from oracle import orc
+from tests import npref, util
+
+
+def _run_both(nx, ny, ndte, revised=False, cosw=1.0, sinw=0.0, ncalls=1, nsub=None, **kw):
+    case, d, f = util.make_case(nx, ny, nx, ny, **kw)
+    xmin = synth.global_min_dx(case)
+    fo, fn = util.clone(f), util.clone(f)
+    p = orc.make_params(3600.0, ndte, xmin, revised_evp=revised, cosw=cosw, sinw=sinw)
+    for call in range(ncalls):
+        if call:
+            for ff in (fo, fn):
+                ff["aice"] *= 0.9
+                ff["vice"] *= 0.97
+                ff["strairxT"], ff["strairyT"] = ff["strairyT"].copy(), -ff["strairxT"]
+        nt, nu, _ = orc.evp(d, p, fo, nsub=nsub or 0)
+        g = {k: v[0] for k, v in fn.items() if isinstance(v, np.ndarray) and v.ndim == 3}      # the one block, views into fn
+        mt, mu = npref.evp(g, 3600.0, ndte, xmin, revised_evp=revised, cosw=cosw, sinw=sinw, nsub=nsub)
+        assert (nt, nu) == (mt, mu)
+        bad = util.compare(d, fn, fo)
+        assert not bad, (call, bad[:6])
+    assert nu > 0 and np.abs(fo["uvel"]).max() > 1e-3
+    # the parameters of set_evp_parameters too (ice_dyn_shared.F90:185-259)
+    P = npref.set_evp_parameters(3600.0, ndte, revised, xmin)
+    for n in ("ecci", "revp", "arlx1i", "brlx", "denom1"):
+        assert P[n] == getattr(p, n), n
+
+
+def test_numpy_restatement_equals_c_oracle_classic():
+    _run_both(48, 40, 30, land="continents", ncalls=3)
+
+
+def test_numpy_restatement_equals_c_oracle_gx3_shape():
+    _run_both(100, 116, 120, land="continents")
+
+
+def test_numpy_restatement_equals_c_oracle_revised_evp_and_turning_angle():
+    _run_both(40, 36, 24, revised=True, land="continents", ncalls=2)
+    _run_both(37, 29, 17, cosw=np.cos(0.4), sinw=np.sin(0.4), ice="full", ncalls=2)
+
+
+def test_numpy_restatement_equals_c_oracle_partial_loop():
+    _run_both(48, 40, 30, nsub=7, land="rows")
