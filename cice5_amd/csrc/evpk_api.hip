@@ -308,7 +308,7 @@ struct evpk_ctx {
     int ncx = 0, nry = 0, R = 8, nstrips = 0;
     int ncx2 = 0, nstrips2 = 0;      // 61-column strips of the two-subcycle kernel
     int R2 = 16, nry2 = 0;           // their height, tuned to the active area (tune_R2)
-    long long tuned_icellt = -1;
+    long long tuned_icellt = -1, tuned1_icellt = -1;
     int slots2 = 512;                // resident 256-thread workgroups of k_subcycle2 on the whole chip
     int nsimd = 1024;                // SIMDs of the chip (4 per CU)
     double *tp_a = nullptr, *tp_b = nullptr, *tp_stage = nullptr;   // transport_upwind: two scratch planes, staging of the work array
@@ -1301,8 +1301,11 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->R = std::max(1, std::min(R, 64));
     }
     c->nry = (s.nyl + 1 + c->R - 1) / c->R;
-    HIPCHK(c, hipMalloc(&c->d_flags, (size_t)c->ncx * c->nry));
-    HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * (size_t)c->ncx * c->nry));
+    {
+        const size_t n1 = (size_t)c->ncx * ((s.nyl + 1 + std::min(c->R, 4) - 1) / std::min(c->R, 4));      // (tune_R1 goes down to R = 4)
+        HIPCHK(c, hipMalloc(&c->d_flags, n1));
+        HIPCHK(c, hipMalloc(&c->d_strips, sizeof(int) * n1));
+    }
     HIPCHK(c, hipMalloc(&c->d_counts, sizeof(unsigned long long) * 4));
     c->ncx2 = (s.nxl + STRIP2_W - 1) / STRIP2_W;
     {
@@ -1629,8 +1632,45 @@ static int prep_triple(evpk_ctx *c, int G) {
 
 // Strip list of the one-subcycle kernel (and, when the two-subcycle kernel is off, the active-cell counts): flags on the
 // device, compaction on the host.  Called by evpk_prep when only that kernel exists, else on first use after a prep.
+// Strip height of the one-subcycle kernels when they ARE the loop (eap, EVPK_DOUBLE=0) on a large slab.  A launch runs its strips in
+// rounds of resident workgroups (four strips each, four workgroups per CU at 128 VGPRs: 4 096 strips); measured for k_eap_sub at
+// 3600x2700 (round 4, EVPK_STRIP_ROWS sweep): R = 16, the fixed default until then, 47.2 ms per eap with 2 816 strips = 2.75 waves per
+// SIMD; R = 11 41.8 ms (3 850 strips, 3.76 waves per SIMD: the latency-bound corner chains want every wave they can get); R = 10
+// 52.9 ms (4 240 strips: a second round).  A march step takes ~(2.2 + waves per SIMD) x 4.9 us, so the cheapest
+// rounds x (R + 1) x (2.2 + 4 x fill) wins.  Re-tuned when the active area changed by more than 5 %.
+static int tune_R1(evpk_ctx *c) {
+    Slab &s = c->s;
+    if (getenv("EVPK_STRIP_ROWS") || (long long)s.nxl * s.nyl < 500000 || !(c->eap || !c->use_double)) return 0;
+    if (c->tuned1_icellt >= 0 && std::llabs(c->icellt - c->tuned1_icellt) * 20 <= c->tuned1_icellt) return 0;
+    static const int cand[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 26, 28, 32, 36, 40, 48};
+    const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
+    HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int) * 32, c->stream));
+    for (int k = 0; k < ncand; k++) {
+        const int R = cand[k], nry = (s.nyl + 1 + R - 1) / R, tot = c->ncx * nry;
+        hipLaunchKernelGGL(k_strip_flags, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx, nry, R, (unsigned char *)nullptr,
+                           (unsigned long long *)nullptr, c->d_tune + k);
+    }
+    unsigned int cnt[32];
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_tune, sizeof(unsigned int) * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double slots = 4.0 * c->nsimd;          // strips resident at four waves per SIMD
+    double best = 1e300;
+    int bestR = c->R;
+    for (int k = 0; k < ncand; k++) {
+        if (cnt[k] == 0) continue;
+        const double rounds = std::ceil(cnt[k] / slots), fill = cnt[k] / (rounds * slots);
+        const double cost = rounds * (cand[k] + 1) * (2.2 + 4.0 * fill);
+        if (cost < best * 0.999) { best = cost; bestR = cand[k]; }
+    }
+    c->R = bestR;
+    c->nry = (s.nyl + 1 + c->R - 1) / c->R;
+    c->tuned1_icellt = c->icellt > 0 ? c->icellt : -1;      // (the first evp tunes before icellt is known: tune once more then)
+    return 0;
+}
+
 static int strips1(evpk_ctx *c) {
     if (c->strips1_valid) return 0;
+    if (tune_R1(c)) return 1;
     Slab &s = c->s;
     const int ns_tot = c->ncx * c->nry;
     unsigned long long *d_cnt = c->use_double ? c->d_counts + 2 : c->d_counts;      // (the counts of prep stay untouched)
@@ -2233,6 +2273,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         c->ksub++;
         n++;
         a.strips = c->d_strips; a.nstrips = c->nstrips; a.ncx = c->ncx; a.wrap = wrap ? 1 : 0;
+        a.R = c->R;                     // (strips1 may have re-tuned it: tune_R1)
         const bool last = (c->ksub == c->p.ndte);
         if (c->nstrips > 0) {
             const dim3 g((((c->nstrips + 3) / 4 + 7) / 8) * 8), b(256);   // multiple of 8: see the XCD remap in k_subcycle

@@ -949,7 +949,8 @@ __global__ void k_zone_copy(Slab s, int W, int fsrc, int fdst, int npairs) {
 
 // one wave per strip: is there any T work (cols cx*63+1..+64, rows jb..jb+R) or U work?
 // Also counts active cells: T on physical cells, U.
-__global__ void k_strip_flags(Slab s, int ncx, int nry, int R, unsigned char *flags, unsigned long long *counts) {
+// flags / counts / nact may be null: nact counts the active strips (the strip-height tuner of the one-subcycle kernels)
+__global__ void k_strip_flags(Slab s, int ncx, int nry, int R, unsigned char *flags, unsigned long long *counts, unsigned int *nact = nullptr) {
     const int sid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (sid >= ncx * nry) return;
@@ -972,9 +973,12 @@ __global__ void k_strip_flags(Slab s, int ncx, int nry, int R, unsigned char *fl
     const unsigned long long b = __ballot(any);
     for (int o = 32; o > 0; o >>= 1) { nt += __shfl_down(nt, o); nu += __shfl_down(nu, o); }
     if (lane == 0) {
-        flags[sid] = b ? 1 : 0;
-        if (nt) atomicAdd(&counts[0], (unsigned long long)nt);
-        if (nu) atomicAdd(&counts[1], (unsigned long long)nu);
+        if (flags) flags[sid] = b ? 1 : 0;
+        if (nact && b) atomicAdd(nact, 1u);
+        if (counts) {
+            if (nt) atomicAdd(&counts[0], (unsigned long long)nt);
+            if (nu) atomicAdd(&counts[1], (unsigned long long)nu);
+        }
     }
 }
 
