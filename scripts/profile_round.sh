@@ -22,7 +22,7 @@ profile() {   # name, bench flags
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$w/pmc_write" -o w -- python3 bench.py $COMMON "$@" --calib 3 > "$w/pmc_write.log" 2>&1
   python3 scripts/pmc_traffic.py "$(ls "$w"/pmc_fetch/*/*counter_collection.csv "$w"/pmc_fetch/*counter_collection.csv 2>/dev/null | head -1)" \
       "$(ls "$w"/pmc_write/*/*counter_collection.csv "$w"/pmc_write/*counter_collection.csv 2>/dev/null | head -1)" "$w/pmc_traffic.json" "$name" > /dev/null \
-    && python3 scripts/update_traffic.py "$w/pmc_traffic.json" "$w/bench.json" "profiles/$tag/$name/pmc_traffic.json" >> "$out/traffic_updates.txt"
+    && python3 scripts/update_traffic.py "$w/pmc_traffic.json" "$w/bench.json" "profiles/$tag/$name/pmc_traffic.json" "$w/kernel_stats.csv" >> "$out/traffic_updates.txt"
   rm -rf "$w"/trace "$w"/pmc_fetch "$w"/pmc_write
 }
 profile cfg5_3600x2700_tripole                                   # the bench default = BASELINE config 5's grid and boundary, ndte = 120
@@ -36,6 +36,10 @@ profile cfg4_1440x1080 --grid 1440x1080 --xblocks 8 --yblocks 4 --dt 1800 --ns o
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d "$out/pmc_sq" -o sq -- python3 bench.py $COMMON > "$out/pmc_sq.log" 2>&1
 python3 scripts/pmc_sq.py "$out/pmc_sq" k_subcycle2p > "$out/sq_counters.txt"
 rm -rf "$out"/pmc_sq
+# 3b. timeline of one launch of the hot kernel (per-strip start / end clocks written by the kernel itself), prep / finish kernels one by one
+EVPK_DEBUG_CLOCKS=$out/tl.txt python3 bench.py --steps 2 --warmup 2 --cpu-subcycles 0 --no-variants > /dev/null 2>&1
+python3 scripts/k_timeline.py "$out/tl.txt" > "$out/timeline_pair.txt" 2>&1; rm -f "$out/tl.txt"
+bash scripts/prep_prof.sh "$tag/prep" > /dev/null 2>&1; rm -f "$out/prep/kernel_trace.csv" "$out/prep/trace.log"
 # 4. other configurations in one table, PCIe-inclusive run, x-slab machinery on one GPU
 bash scripts/configs.sh > "$out/configs.txt" 2>&1
 python3 scripts/pcie_run.py > "$out/pcie.txt" 2>&1
