@@ -211,3 +211,21 @@ def test_hot_kernels_keep_their_register_budget():
             assert v["ScratchSize"] <= 64, (k, v)                            #  the LAST2 variants, once per evp, spill more)
         if "k_eap_sub" in k and "Lb0" in k:
             assert v["VGPRs"] <= 128 and v["ScratchSize"] <= 64, (k, v)
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` from a bare command line (no WORLD_SIZE): the parent starts the ranks as child processes through
+    torch.distributed.run before it touches a GPU, relays the result line and exits with their status.  Here there is no GPU: every
+    rank refuses to run (no CPU fallback), the parent prints ONE JSON line with value null and exits non-zero."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run")
+    assert r.returncode != 0
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["value"] is None and line["failed"] == "launch" and line["n_gpus"] == 2
