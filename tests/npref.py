@@ -301,3 +301,28 @@ def stepu(f, strt, ium, aiu, umassdti, waterx, watery, forcex, forcey, u, v, brl
     v[c] = (cca * cc2 - ccb * cc1) / ab2
     f["strocnx"][c] = taux
     f["strocny"][c] = tauy
+
+
+def transport_upwind(f, works, dt):
+    """transport_upwind without its state transforms (ice_transport_driver.F90:634-772): cell-edge velocities (:688-701), their halo
+    updates (E face / N face vectors: ghost rows 0, ghost columns wrap), upwind_field (:1614-1689) of every plane of
+    works[narr, ny_block, nx_block] in place on the physical cells"""
+    u, v = f["uvel"], f["vvel"]
+    uee, vnn = np.zeros_like(u), np.zeros_like(u)
+    ph = (slice(1, -1), slice(1, -1))
+    uee[ph] = p5 * (u[ph] + u[0:-2, 1:-1])
+    vnn[ph] = p5 * (v[ph] + v[1:-1, 0:-2])
+    halo(uee)
+    halo(vnn)
+    HTE, HTN, tarea = f["HTE"], f["HTN"], f["tarea"]
+
+    def upwind(y1, y2, a, h):
+        return p5 * dt * h * ((a + np.abs(a)) * y1 + (a - np.abs(a)) * y2)
+
+    for n in range(works.shape[0]):
+        phi = works[n]
+        wa, wb = np.zeros_like(phi), np.zeros_like(phi)
+        s_ = (slice(0, -1), slice(0, -1))                      # j = 1..jhi, i = 1..ihi
+        wa[s_] = upwind(phi[0:-1, 0:-1], phi[0:-1, 1:], uee[s_], HTE[s_])
+        wb[s_] = upwind(phi[0:-1, 0:-1], phi[1:, 0:-1], vnn[s_], HTN[s_])
+        phi[ph] = phi[ph] - (wa[ph] - wa[1:-1, 0:-2] + wb[ph] - wb[0:-2, 1:-1]) / tarea[ph]

@@ -48,3 +48,22 @@ def test_numpy_restatement_equals_c_oracle_revised_evp_and_turning_angle():
 
 def test_numpy_restatement_equals_c_oracle_partial_loop():
     _run_both(48, 40, 30, nsub=7, land="rows")
+
+
+def test_numpy_upwind_equals_c_oracle():
+    """row f-3, first step: the edge velocities and upwind_field of transport_upwind, after a real evp"""
+    from cice5_amd import constants as C
+    nx, ny = 48, 40
+    case, d, f = util.make_case(nx, ny, nx, ny, land="continents")
+    xmin = synth.global_min_dx(case)
+    orc.evp(d, orc.make_params(3600.0, 20, xmin), f)
+    synth.add_thickness_distribution(f)
+    planes = [f["aice0"]] + [a for n in range(f["aicen"].shape[1]) for a in (f["aicen"][:, n], f["vicen"][:, n])]
+    works = np.ascontiguousarray(np.stack(planes, axis=1))
+    for k in range(works.shape[1]):
+        w = np.ascontiguousarray(works[:, k]); orc.halo_r8(d, w, C.LOC_CENTER, C.KIND_SCALAR, 0.0); works[:, k] = w
+    wo, wn = works.copy(), works.copy()
+    orc.transport_upwind(d, 3600.0, f, wo)
+    npref.transport_upwind({k: v[0] for k, v in f.items() if isinstance(v, np.ndarray) and v.ndim == 3}, wn[0], 3600.0)
+    assert np.abs(wo - works).max() > 1e-6
+    assert np.array_equal(wn, wo)
