@@ -847,7 +847,7 @@ static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp
     const int nband8 = (a.nband + 7) & ~7;      // the tripole top band as the first workgroups of the launch (band_pair)
     if (c->tile_mode) {      // small-slab variant: one workgroup of R + 3 waves per strip, one row per wave
         const dim3 gt(((a.nstrips + 7) / 8) * 8 + nband8), bt((a.R + 3) * 64);
-        const size_t lds = std::max((size_t)(a.R + 3) * 4096, a.nband ? sizeof(double) * BAND_LDS_DOUBLES : (size_t)0);
+        const size_t lds = std::max((size_t)(a.R + 3) * (4096 + 5 * 1024), a.nband ? sizeof(double) * BAND_LDS_DOUBLES : (size_t)0);
         if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, true>), gt, bt, lds, st, a); }
         else       { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false>), gt, bt, lds, st, a); }
         return;

@@ -2703,6 +2703,7 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     const int wg = (bidx & 7) * chunk + (bidx >> 3);
     if ((bidx >> 3) >= chunk || wg >= ns) return;     // (the whole workgroup leaves: no barrier is left waiting)
     const int st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
+    if (w == 0) dbg_stamp(a, wg, 0);
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
     const int G = a.G;
@@ -2732,6 +2733,9 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     char *const base = reinterpret_cast<char *>(s.F);
     double *const X = tl, *const Y = tl + (size_t)NW * 256;
     double *const Xw = X + (size_t)w * 256 + lane, *const Yw = Y + (size_t)w * 256 + lane;
+    // the stepu inputs of this wave's row (four pairs + uvel_init): global -> LDS directly, no registers while the two stresses
+    // are computed (round 4: the kernel is compiled for 128 VGPRs and spilled 8 with them live from the start)
+    double2 *const Qw = reinterpret_cast<double2 *>(tl + (size_t)NW * 512) + (size_t)w * 5 * 64;
 
     const int r = jb - 1 + w;                         // this wave's row
     const bool rowok = (r >= 0 && r <= nyl + 1);
@@ -2758,17 +2762,24 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     Str8 o1{0, 0, 0, 0, 0, 0, 0, 0};
     Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    UStat q1{0, 0, 0, 0, 0, 0, 0, 0};
-    double ui1 = 0.0, vi1 = 0.0;
     if (__any(t1act)) {
         if (t1act) { mt = load_tmet(rb, pp, lo); g1 = load_sig(rb, pp, SR, lo); }
     }
-    if (__any(u1act)) {      // the stepu inputs of this row serve both subcycles; fetched beside the T planes
+    if (__any(u1act)) {      // the stepu inputs of this row serve both subcycles; fetched beside the T planes, into the LDS
         if (u1act) {
-            q1 = load_ustat(rb, pp, lo);
-            if (REVP) { const double2 iv = ldp(rb, pp, F_UVEL_INIT, lo); ui1 = iv.x; vi1 = iv.y; }
+            lds_dma16(rb + (size_t)(F_VRELC >> 1) * pp + lo, Qw + 0 * 64);
+            lds_dma16(rb + (size_t)(F_UOCN >> 1) * pp + lo, Qw + 1 * 64);
+            lds_dma16(rb + (size_t)(F_FORCEX >> 1) * pp + lo, Qw + 2 * 64);
+            lds_dma16(rb + (size_t)(F_UMASSDTI >> 1) * pp + lo, Qw + 3 * 64);
+            if (REVP) lds_dma16(rb + (size_t)(F_UVEL_INIT >> 1) * pp + lo, Qw + 4 * 64);
         }
     }
+    auto load_q = [&](UStat &q, double &ui, double &vi) {
+        const double2 va = Qw[0 * 64 + lane], oc = Qw[1 * 64 + lane], fo = Qw[2 * 64 + lane], mf = Qw[3 * 64 + lane];
+        q = UStat{va.x, va.y, oc.x, oc.y, fo.x, fo.y, mf.x, mf.y};
+        ui = 0.0; vi = 0.0;
+        if (REVP) { const double2 iv = Qw[4 * 64 + lane]; ui = iv.x; vi = iv.y; }
+    };
     if (__any(t1act)) {
         if (t1act) {
             Diag dg;
@@ -2777,6 +2788,7 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     }
     const double a2n = shfl_dn1(o1.s2), a4n = shfl_dn1(o1.s4), a7n = shfl_dn1(o1.s7), a8n = shfl_dn1(o1.s8);
     Xw[0] = o1.s3; Xw[64] = o1.s6; Xw[128] = a4n; Xw[192] = a8n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (this wave's LDS-DMA has landed)
     __syncthreads();
 
     // ---------------- phase B: U1(r) ----------------
@@ -2785,6 +2797,8 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
         if (u1act) {
             const double *Xn = Xw + 256;              // the row above
             double sxi, syi;
+            UStat q1; double ui1, vi1;
+            load_q(q1, ui1, vi1);
             stepu_cell(q1, un_c, vn_c, ui1, vi1, ((o1.s1 + a2n) + Xn[0]) + Xn[128], ((o1.s5 + Xn[64]) + a7n) + Xn[192],
                        a.brlx, a.revp, a.cosw, a.sinw, u1_c, v1_c, sxi, syi);
         }
@@ -2825,6 +2839,8 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
         if (u2act) {
             const double *Xn = Xw + 256;
             double un, vn, sxi, syi;
+            UStat q1; double ui1, vi1;
+            load_q(q1, ui1, vi1);
             stepu_cell(q1, u1_c, v1_c, ui1, vi1, ((o2.s1 + b2n) + Xn[0]) + Xn[128], ((o2.s5 + Xn[64]) + b7n) + Xn[192],
                        a.brlx, a.revp, a.cosw, a.sinw, un, vn, sxi, syi);
             stp(rb, pp, SW + S_U, lo, un, vn);
@@ -2835,6 +2851,7 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
             if (LAST2) { st1(rb, pp, F_STRINTX, lo, sxi); st1(rb, pp, F_STRINTY, lo, syi); }
         }
     }
+    if (w == 0) dbg_stamp(a, wg, 1);
 }
 
 template __global__ void k_subcycle2t<false, false>(SubArgs);
