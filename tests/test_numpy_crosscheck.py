@@ -67,3 +67,30 @@ def test_numpy_upwind_equals_c_oracle():
     npref.transport_upwind({k: v[0] for k, v in f.items() if isinstance(v, np.ndarray) and v.ndim == 3}, wn[0], 3600.0)
     assert np.abs(wo - works).max() > 1e-6
     assert np.array_equal(wn, wo)
+
+
+def test_numpy_eap_equals_libm_build_of_the_c_oracle():
+    """row f-4: eap(dt) -- stress_eap, update_stress_rdg, stepa, calc_ffrac and the driver around them -- read a second time
+    (tests/npref.py) against the C oracle built on the host's libm (the build whose sin / cos / atan2 numpy's math.* shares)"""
+    from cice5_amd.eap_tables import eap_tables
+    T = eap_tables()
+    for (nx, ny, ndte, ncalls) in ((40, 36, 22, 2), (48, 40, 31, 1)):
+        case, d, f = util.make_case(nx, ny, nx, ny, land="continents")
+        synth.add_eap_state(f)
+        xmin = synth.global_min_dx(case)
+        fo, fn = util.clone(f), util.clone(f)
+        p = orc.make_params(3600.0, ndte, xmin)
+        for call in range(ncalls):
+            if call:
+                for ff in (fo, fn):
+                    ff["aice"] *= 0.9
+                    ff["vice"] *= 0.97
+            orc.eap(d, p, fo, T, libm=True)
+            g = {k: v[0] for k, v in fn.items() if isinstance(v, np.ndarray) and v.ndim == 3}
+            npref.evp(g, 3600.0, ndte, xmin, eap_tables=T)
+            bad = util.compare(d, fn, fo)
+            assert not bad, (call, bad[:6])
+            ne = util.cell_mask(d, "ne")
+            for n in synth.EAP_STATE + synth.EAP_HISTORY:
+                assert np.array_equal(fn[n][ne], fo[n][ne]), (call, n, int((fn[n][ne] != fo[n][ne]).sum()))
+        assert np.abs(fo["uvel"]).max() > 1e-3 and np.abs(fo["a11_1"] - 0.5).max() > 1e-6
