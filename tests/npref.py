@@ -50,7 +50,7 @@ def set_evp_parameters(dt, ndte, revised_evp, xmin):
     return dict(ecci=ecci, revp=revp, arlx1i=arlx1i, brlx=brlx, denom1=denom1)
 
 
-def halo(a):
+def halo_cyclic(a):
     """ice_HaloUpdate of a one-block domain, cyclic E-W, open N-S (centre or NE-corner field alike): the ghost rows get the fill
     value 0, then the ghost columns wrap over all rows (mpi/ice_boundary.F90:1409-1416, :1489-1560)"""
     a[0, :] = 0.0
@@ -75,9 +75,17 @@ def to_tgrid(w1, tarea, uarea):
     return p25 * (w1[c] * uarea[c] + w1[w] * uarea[w] + w1[s_] * uarea[s_] + w1[sw] * uarea[sw]) / tarea[c]
 
 
-def evp(f, dt, ndte, xmin, revised_evp=False, cosw=1.0, sinw=0.0, nsub=None, eap_tables=None):
+LOC_CENTER, LOC_NECORNER = 1, 2                                                    # ice_constants.F90: field_loc_*
+KIND_SCALAR, KIND_VECTOR = 1, 2                                                    #                    field_type_*
+
+
+def evp(f, dt, ndte, xmin, revised_evp=False, cosw=1.0, sinw=0.0, nsub=None, eap_tables=None, halo_update=None, stress_fold=None):
     """one call of evp(dt) in place on the dict of 2-D arrays `f` (names as in ice_state / ice_flux / ice_grid);
-    eap_tables = (s11r, s12r, s22r, s11s, s12s, s22s): eap(dt) instead (ice_dyn_eap.F90:66-486)"""
+    eap_tables = (s11r, s12r, s22r, s11s, s12s, s22s): eap(dt) instead (ice_dyn_eap.F90:66-486).
+    halo_update(a, field_loc, field_type) replaces the cyclic / open update above (a tripole domain: the caller passes the
+    halo routine that IS pinned by reference output); stress_fold(array1, array2) is ice_HaloUpdate_stress
+    (ice_dyn_evp.F90:416-481), called as the reference calls it when given"""
+    halo = halo_update if halo_update is not None else (lambda a, loc, kind: halo_cyclic(a))
     P = set_evp_parameters(dt, ndte, revised_evp, xmin)
     ecci, revp, arlx1i, brlx, denom1 = P["ecci"], P["revp"], P["arlx1i"], P["brlx"], P["denom1"]
     ph = (slice(1, -1), slice(1, -1))
@@ -101,7 +109,7 @@ def evp(f, dt, ndte, xmin, revised_evp=False, cosw=1.0, sinw=0.0, nsub=None, eap
     icetmask[ph] = np.where(near[ph] & tmask[ph], 1, 0)
     f["tmass"][...] = tmass
     tmp = icetmask.astype(np.float64)
-    halo(tmp)                                                                    # :210-211
+    halo(tmp, LOC_CENTER, KIND_SCALAR)                                           # :210-211
     icetmask = tmp.astype(np.int32)
 
     # ---- T -> U (:218-241) ----
@@ -109,7 +117,7 @@ def evp(f, dt, ndte, xmin, revised_evp=False, cosw=1.0, sinw=0.0, nsub=None, eap
     aiu = to_ugrid(f["aice_init"], f["tarea"], f["uarea"])
     for n in ("strairx", "strairy"):                                             # t2ugrid_vector
         w1 = f[n].copy()
-        halo(w1)
+        halo(w1, LOC_CENTER, KIND_VECTOR)
         f[n][...] = to_ugrid(w1, f["tarea"], f["uarea"])
     f["umass"][...] = umass
     f["aiu"][...] = aiu
@@ -154,9 +162,9 @@ def evp(f, dt, ndte, xmin, revised_evp=False, cosw=1.0, sinw=0.0, nsub=None, eap
         for c in (1, 2, 3, 4):
             f[f"a11_{c}"][icetmask == 0] = p5
             f[f"a12_{c}"][icetmask == 0] = 0.0
-    halo(f["strength"])                                                          # :311-315
-    halo(u)
-    halo(v)
+    halo(f["strength"], LOC_CENTER, KIND_SCALAR)                                 # :311-315
+    halo(u, LOC_NECORNER, KIND_VECTOR)
+    halo(v, LOC_NECORNER, KIND_VECTOR)
 
     # ---- the subcycle loop ----
     g = {n: f[n] for n in ("cxp", "cyp", "cxm", "cym", "dxt", "dyt", "dxhy", "dyhx", "tarear", "tinyarea", "strength")}
@@ -169,8 +177,15 @@ def evp(f, dt, ndte, xmin, revised_evp=False, cosw=1.0, sinw=0.0, nsub=None, eap
         stepu(f, strt, ium, aiu, umassdti, waterx, watery, forcex, forcey, u, v, brlx, revp, cosw, sinw)
         if eap_tables is not None and ksub % 10 == 1:                            # ice_dyn_eap.F90:411-426
             stepa(f, tcell, S, dtei)
-        halo(u)
-        halo(v)
+        halo(u, LOC_NECORNER, KIND_VECTOR)
+        halo(v, LOC_NECORNER, KIND_VECTOR)
+
+    if stress_fold is not None and eap_tables is None:                           # ice_dyn_evp.F90:416-481
+        for k in (0, 4, 8):
+            stress_fold(S[k + 0], S[k + 2])
+            stress_fold(S[k + 2], S[k + 0])
+            stress_fold(S[k + 1], S[k + 3])
+            stress_fold(S[k + 3], S[k + 1])
 
     # ---- evp_finish + u2tgrid_vector ----
     f["strocnxT"][...] = 0.0
@@ -187,7 +202,7 @@ def evp(f, dt, ndte, xmin, revised_evp=False, cosw=1.0, sinw=0.0, nsub=None, eap
         f["strocnyT"][ium] = (sy / aiu)[ium]
     for n in ("strocnxT", "strocnyT"):
         w1 = f[n].copy()
-        halo(w1)
+        halo(w1, LOC_NECORNER, KIND_VECTOR)
         f[n][ph] = to_tgrid(w1, f["tarea"], f["uarea"])
     f["icetmask"][...] = icetmask
     return int(tcell[1:-1, 1:-1].sum()), int(ium.sum())
@@ -326,8 +341,8 @@ def transport_upwind(f, works, dt):
     ph = (slice(1, -1), slice(1, -1))
     uee[ph] = p5 * (u[ph] + u[0:-2, 1:-1])
     vnn[ph] = p5 * (v[ph] + v[1:-1, 0:-2])
-    halo(uee)
-    halo(vnn)
+    halo_cyclic(uee)
+    halo_cyclic(vnn)
     HTE, HTN, tarea = f["HTE"], f["HTN"], f["tarea"]
 
     def upwind(y1, y2, a, h):
