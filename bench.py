@@ -156,8 +156,10 @@ def main():
         sys.exit(3)
 
     nx, ny = (int(v) for v in a.grid.split("x"))
-    if nx % a.xblocks or a.xblocks % world or ny % a.yblocks:
-        raise SystemExit("grid / xblocks / yblocks / gpus do not divide")
+    # (block columns need not divide over the ranks: create_distrb_cart gives every rank ceil(xblocks / world) of them and the last
+    #  one the rest, ice_distribution.F90:603-640 -- it must own at least one)
+    if nx % a.xblocks or ny % a.yblocks or (world - 1) * -(-a.xblocks // world) >= a.xblocks:
+        raise SystemExit("grid / xblocks / yblocks do not divide, or a rank would own no block column")
     bsx, bsy = nx // a.xblocks, ny // a.yblocks
     case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[a.ns], land=a.land, ice=a.ice, dt=a.dt, ndte=a.ndte)
     d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=a.ns)
@@ -367,18 +369,20 @@ def timed_steps(ctx, ndte, steps, warmup, fence):
         step()
     fence()
     loop_ms = 0.0
+    bound = [0.0, 0]                              # timer_bound's share of the loops (ice_dyn_evp.F90:392-400): ms, updates
     k = {q: [0.0, 0, 0] for q in (1, 2, 3)}      # subcycles per launch -> [ms, launches, launches inside timed spans]
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
         st = ctx.stats()
         loop_ms += st.loop_ms
+        bound[0] += st.bound_ms; bound[1] += st.bound_updates
         for q, (ms, n, t) in ((1, (st.kernel_ms, st.kernel_launches, st.kernel_timed)), (2, (st.kernel2_ms, st.kernel2_launches, st.kernel2_timed)),
                               (3, (st.kernel3_ms, st.kernel3_launches, st.kernel3_timed))):
             k[q][0] += ms; k[q][1] += n; k[q][2] += t
     fence()
     wall = time.perf_counter() - t0
-    return {"wall_s": wall, "loop_ms": loop_ms, "k": k, "stats": ctx.stats(), "steps": steps}
+    return {"wall_s": wall, "loop_ms": loop_ms, "k": k, "stats": ctx.stats(), "steps": steps, "bound": bound}
 
 
 def roofline(r, icellt, icellu, revp):
@@ -409,6 +413,7 @@ def roofline(r, icellt, icellu, revp):
             "timing": "HIP events on the library's stream around runs of six consecutive launches (launches 3..8 of every 20): span "
                       "time / launches in the span, so launches x avg_launch_ms <= the loop time by construction",
             "kernel_ms_per_step_all_kinds": sum(k[q][0] for q in (1, 2, 3)) / max(r["steps"], 1),
+            "bound_ms_per_step": r["bound"][0] / max(r["steps"], 1), "bound_updates_per_step": r["bound"][1] / max(r["steps"], 1),
             "compact_metrics": int(st.compact_metrics),
             "effective_vs_reference_accounting": {"bytes_per_cell_update": ALG_BYTES_STRESS + ALG_BYTES_STEPU,
                                                   "GBps": ref / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0,

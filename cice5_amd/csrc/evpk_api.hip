@@ -269,7 +269,11 @@ struct evpk_ctx {
     Slab *d_mslab = nullptr;
     double2 *xb_send = nullptr, *xb_recv = nullptr;
     size_t xb_cap = 0;
-    int xb_partner = -1, m_need = 1, xb_swaps = 0;     // m_need: the mirror slab's state must be fetched before the next pair launch
+    int w_bound = 0;
+    bool xb_fuse = true;
+    int m_need = 1, xb_swaps = 0;     // m_need: the mirror slab's state must be fetched before the next pair launch
+    struct XbPeer { int rank; XbSeg seg; };
+    std::vector<XbPeer> xb_to, xb_from;   // whose mirror slabs hold columns of mine (runs of MY columns); who holds columns of my M (runs of M's)
     int *d_mstrips = nullptr;        // every strip of the mirror slab (its own advance between two refreshes), for (ms_R, ms_ncx)
     int ms_R = 0, ms_ncx = 0, ms_n = 0;
     // strip list of the pair kernels compacted on the device (one rank, no ghost zones; EVPK_DEVICE_STRIPS=0: on the host):
@@ -690,39 +694,66 @@ static int xp_check(evpk_ctx *c) {
 constexpr int XB_PLANES = 13;                                       // pair planes of the widest message (static fields of evpk_prep)
 constexpr int XB_ROWS_MAX = 2 * ((ZW_MAX - 1) / 2) + 1 + 2;         // nylM + 2 at the deepest zones
 
-// ---- rows r0 .. r0+nr-1 of the pair planes L (+ the mask bytes) of MY slab to the mirror rank, the mirror rank's into rows
-// m0 .. of the mirror slab M (band_pair): one swap with rank P-1-r over the context's transport ----
+// ---- rows r0 .. r0+nr-1 of the pair planes L (+ the mask bytes) of MY columns to every rank whose mirror slab holds some of
+// them, and from the owners of the columns of MY mirror slab M into its rows m0 .. (band_pair): one message per partner and
+// direction over the context's transport (a rank's own share -- the middle rank of an odd count mirrors onto itself -- stays
+// on the device) ----
+static size_t xb_bytes(const XbList &L, const XbSeg &G, int nr, int mask) {
+    return ((size_t)L.np * nr * G.tot * sizeof(double2) + (mask ? (size_t)nr * G.tot : 0) + 15) & ~(size_t)15;
+}
 static int xband_swap(evpk_ctx *c, const XbList &L, int r0, int m0, int nr, int mask, hipStream_t st) {
     Slab &s = c->s;
-    const int q = c->xb_partner, ch = xp_channel(c, st), tx = 128;
-    const size_t ncol = (size_t)s.nxl + 2 * ZW_MAX;
-    const size_t bytes = ((size_t)L.np * nr * ncol * sizeof(double2) + (mask ? (size_t)nr * ncol : 0) + 15) & ~(size_t)15;
-    if (bytes > c->xb_cap) FAIL(c, "xband_swap: message larger than its buffer");
-    if (c->relay && bytes > c->relay->slot) FAIL(c, "shared-memory relay: band rows message larger than its slot");
-    double2 *snd = c->xb_send, *rcv = c->xb_recv;
-    if (c->ipc) {
-        if (bytes > c->ipc->slot[ch] / 2) FAIL(c, "ipc transport: band rows message larger than its slot");
-        snd = reinterpret_cast<double2 *>(ipc_send_ptr(c, ch, q, 0));
-        rcv = reinterpret_cast<double2 *>(ipc_recv_ptr(c, ch, q, 0));
+    const int ch = xp_channel(c, st), tx = 128;
+    auto sndp = [&](size_t k, int q) { return (c->ipc && q != c->rank) ? reinterpret_cast<double2 *>(ipc_send_ptr(c, ch, q, 0))
+                                                                        : reinterpret_cast<double2 *>((char *)c->xb_send + k * c->xb_cap); };
+    auto rcvp = [&](size_t k, int q) { return q == c->rank ? static_cast<const double2 *>(nullptr)
+                                              : c->ipc ? reinterpret_cast<const double2 *>(ipc_recv_ptr(c, ch, q, 0))
+                                                       : reinterpret_cast<const double2 *>((char *)c->xb_recv + k * c->xb_cap); };
+    const double2 *self = nullptr;
+    for (size_t k = 0; k < c->xb_to.size(); k++) {
+        const auto &P = c->xb_to[k];
+        const size_t bytes = xb_bytes(L, P.seg, nr, mask);
+        if (bytes > c->xb_cap) FAIL(c, "xband_swap: message larger than its buffer");
+        if (c->relay && P.rank != c->rank && bytes > c->relay->slot) FAIL(c, "shared-memory relay: band rows message larger than its slot");
+        if (c->ipc && P.rank != c->rank && bytes > c->ipc->slot[ch] / 2) FAIL(c, "ipc transport: band rows message larger than its slot");
+        double2 *snd = sndp(k, P.rank);
+        if (P.rank == c->rank) self = snd;
+        const dim3 g((unsigned)((P.seg.tot + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
+        hipLaunchKernelGGL(k_xband_pack, g, dim3(tx), 0, st, s, L, P.seg, r0, nr, mask, snd);
     }
-    const dim3 g((unsigned)((ncol + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
-    hipLaunchKernelGGL(k_xband_pack, g, dim3(tx), 0, st, s, L, r0, nr, mask, snd);
     HIPCHK(c, hipGetLastError());
+    std::vector<const double2 *> rcv_of(c->xb_from.size());          // (peer-mapped: the page of the NEXT message, before the wait turns it)
+    for (size_t k = 0; k < c->xb_from.size(); k++) rcv_of[k] = rcvp(k, c->xb_from[k].rank);
     if (c->ipc) {
-        if (ipc_signal(c, ch, q, st)) return 1;
-        if (ipc_wait(c, ch, q, st)) return 1;
+        for (const auto &P : c->xb_to) if (P.rank != c->rank && ipc_signal(c, ch, P.rank, st)) return 1;
+        for (const auto &P : c->xb_from) if (P.rank != c->rank && ipc_wait(c, ch, P.rank, st)) return 1;
     } else if (c->relay) {
-        int rc = c->relay->send(q, snd, bytes, st);
-        rc |= c->relay->recv(q, rcv, bytes, st);
+        int rc = 0;
+        for (size_t k = 0; k < c->xb_to.size(); k++)
+            if (c->xb_to[k].rank != c->rank) rc |= c->relay->send(c->xb_to[k].rank, sndp(k, c->xb_to[k].rank), xb_bytes(L, c->xb_to[k].seg, nr, mask), st);
+        for (size_t k = 0; k < c->xb_from.size(); k++)
+            if (c->xb_from[k].rank != c->rank)
+                rc |= c->relay->recv(c->xb_from[k].rank, (char *)c->xb_recv + k * c->xb_cap, xb_bytes(L, c->xb_from[k].seg, nr, mask), st);
         if (rc) FAIL(c, "shared-memory relay: band rows exchange failed");
     } else {
         NCCLCHK(c, ncclGroupStart());
-        const ncclResult_t r1 = ncclSend(snd, bytes, ncclChar, q, c->comm, st);
-        const ncclResult_t r2 = ncclRecv(rcv, bytes, ncclChar, q, c->comm, st);
-        const ncclResult_t r3 = ncclGroupEnd();
-        if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) FAIL(c, "band rows exchange: ncclSend / ncclRecv failed");
+        ncclResult_t rc = ncclSuccess;
+        auto keep = [&](ncclResult_t e) { if (rc == ncclSuccess) rc = e; };
+        for (size_t k = 0; k < c->xb_to.size(); k++)
+            if (c->xb_to[k].rank != c->rank) keep(ncclSend(sndp(k, c->xb_to[k].rank), xb_bytes(L, c->xb_to[k].seg, nr, mask), ncclChar, c->xb_to[k].rank, c->comm, st));
+        for (size_t k = 0; k < c->xb_from.size(); k++)
+            if (c->xb_from[k].rank != c->rank)
+                keep(ncclRecv((char *)c->xb_recv + k * c->xb_cap, xb_bytes(L, c->xb_from[k].seg, nr, mask), ncclChar, c->xb_from[k].rank, c->comm, st));
+        const ncclResult_t rce = ncclGroupEnd();
+        if (rc != ncclSuccess || rce != ncclSuccess) FAIL(c, "band rows exchange: ncclSend / ncclRecv failed");
     }
-    hipLaunchKernelGGL(k_xband_unpack, g, dim3(tx), 0, st, c->m, L, m0, nr, mask, (const double2 *)rcv);
+    for (size_t k = 0; k < c->xb_from.size(); k++) {
+        const auto &P = c->xb_from[k];
+        const double2 *rcv = P.rank == c->rank ? self : rcv_of[k];
+        if (!rcv) FAIL(c, "xband_swap: no message for the rank's own share of its mirror slab");
+        const dim3 g((unsigned)((P.seg.tot + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
+        hipLaunchKernelGGL(k_xband_unpack, g, dim3(tx), 0, st, c->m, L, P.seg, m0, nr, mask, rcv);
+    }
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -845,17 +876,23 @@ static int halo_stress12(evpk_ctx *c, int f0) {
 // ---- launch of the two-subcycle kernel (plain or LDS-prefetch variant) ------------------------------------
 static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp, bool last2) {
     const int nband8 = (a.nband + 7) & ~7;      // the tripole top band as the first workgroups of the launch (band_pair)
+    const bool xm = a.nmir > 0 && !last2 && a.xm && (c->tile_mode || c->prefetch);      // ... then the strips of the mirror slab (x-slab ranks, XM kernels)
     if (c->tile_mode) {      // small-slab variant: one workgroup of R + 3 waves per strip, one row per wave
-        const dim3 gt(((a.nstrips + 7) / 8) * 8 + nband8), bt((a.R + 3) * 64);
+        const dim3 gt(((a.nstrips + 7) / 8) * 8 + nband8 + (xm ? (a.nmir + 7) & ~7 : 0)), bt((a.R + 3) * 64);
         const size_t lds = std::max((size_t)(a.R + 3) * (4096 + 5 * 1024), a.nband ? sizeof(double) * BAND_LDS_DOUBLES : (size_t)0);
-        if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, true>), gt, bt, lds, st, a); }
-        else       { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false>), gt, bt, lds, st, a); }
+        if (xm)         { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false, true>), gt, bt, lds, st, a); }
+        else if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, true>), gt, bt, lds, st, a); }
+        else            { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false>), gt, bt, lds, st, a); }
         return;
     }
-    const dim3 g((((a.nstrips + 3) / 4 + 7) / 8) * 8 + nband8), b(256);     // multiple of 8: XCD remap in the kernel
+    const dim3 g((((a.nstrips + 3) / 4 + 7) / 8) * 8 + nband8 + (xm ? (((a.nmir + 3) / 4) + 7) & ~7 : 0)), b(256);     // multiples of 8: XCD remap in the kernel
     if (c->prefetch) {
 #define EVPK_L2P(RV, L2, CMX) hipLaunchKernelGGL((k_subcycle2p<RV, L2, CMX>), g, b, 0, st, a)
-        if (c->compact) {
+#define EVPK_L2X(RV, CMX) hipLaunchKernelGGL((k_subcycle2p<RV, false, CMX, true>), g, b, 0, st, a)
+        if (xm) {
+            if (c->compact) { if (revp) EVPK_L2X(true, true); else EVPK_L2X(false, true); }
+            else            { if (revp) EVPK_L2X(true, false); else EVPK_L2X(false, false); }
+        } else if (c->compact) {
             if (last2) { if (revp) EVPK_L2P(true, true, true); else EVPK_L2P(false, true, true); }
             else       { if (revp) EVPK_L2P(true, false, true); else EVPK_L2P(false, false, true); }
         } else {
@@ -863,6 +900,7 @@ static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp
             else       { if (revp) EVPK_L2P(true, false, false); else EVPK_L2P(false, false, false); }
         }
 #undef EVPK_L2P
+#undef EVPK_L2X
     } else {
         if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, true>), g, b, 0, st, a); }
         else       { if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, st, a); }
@@ -962,8 +1000,8 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             // test transport: host-staged relay through POSIX shared memory (several ranks on one GPU)
             const size_t slot = std::max<size_t>((size_t)2 * c->cslot * sizeof(double2),
                                                  (size_t)c->max_nf * 2 * (size_t)s.nxg * sizeof(double)) + 4096 +
-                                (c->ns == EVPK_BND_TRIPOLE      // the band rows of xband_swap (equal slab widths, or no such message)
-                                     ? (size_t)(XB_PLANES * XB_ROWS_MAX * sizeof(double2) + XB_ROWS_MAX) * ((size_t)s.nxg / c->nranks + 1 + 2 * ZW_MAX) : 0);
+                                (c->ns == EVPK_BND_TRIPOLE      // the band rows of xband_swap: at most a mirror slab's columns, zones included
+                                     ? (size_t)(XB_PLANES * XB_ROWS_MAX * sizeof(double2) + XB_ROWS_MAX) * ((size_t)c->w_bound + 2 * ZW_MAX) + 64 : 0);
             c->relay = new ShmRelay();
             std::string err;
             if (c->relay->open(nm, c->rank, c->nranks, slot, err)) FAIL(c, "%s", err.c_str());
@@ -1094,12 +1132,41 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
         const char *zm = getenv("EVPK_ZONE_M");
         int m = zm ? atoi(zm) : ZW_MAX / 2;
         m = std::max(1, std::min(m, std::min(ZW_MAX / 2, minw / 2)));
-        {   // tripole between ranks without a per-subcycle exchange: see band_pair (every rank decides alike)
+        // tripole between ranks without a per-subcycle exchange: see band_pair (every rank decides alike).  The mirror slab M of
+        // rank d is a VIRTUAL slab of d's width that starts at global column nx - i0_d - w_d + 2 (NE-corner image of d's local
+        // column i = M's local column w_d - i); its columns, ghost zones included, come from whichever ranks own them (cyclic):
+        // the mirror rank P-1-d alone when the slabs are equal and P is even, up to three ranks (or d itself) otherwise
+        std::vector<std::vector<XbSeg>> xsrc, xdst;     // [q][d]: runs of q's columns / of M_d's columns, message q -> d
+        {
             const char *xe = getenv("EVPK_XBAND");
-            bool eq = true;
-            for (int r = 0; r < c->nranks; r++) eq = eq && (c->slab_i0[r + 1] - c->slab_i0[r] == s.nxl);
-            c->xband = c->band_mode && c->nranks > 1 && (c->nranks % 2 == 0) && eq && c->prefetch && c->band_fused && !(xe && atoi(xe) == 0) &&
-                       s.nxl >= 2 * ZW_MAX && s.nyl >= XB_ROWS_MAX + 1;
+            if (const char *e = getenv("EVPK_XB_FUSE")) c->xb_fuse = atoi(e) != 0;
+            bool ok = c->band_mode && c->nranks > 1 && c->prefetch && c->band_fused && !(xe && atoi(xe) == 0) &&
+                      minw >= 2 * ZW_MAX && s.nyl >= XB_ROWS_MAX + 1;
+            if (ok) {
+                const int P = c->nranks, nx = s.nxg;
+                xsrc.assign(P, std::vector<XbSeg>(P, XbSeg{}));
+                xdst.assign(P, std::vector<XbSeg>(P, XbSeg{}));
+                auto owner = [&](int g) { int r = 0; while (g >= c->slab_i0[r + 1]) r++; return r; };
+                for (int d = 0; d < P && ok; d++) {
+                    const int wd = c->slab_i0[d + 1] - c->slab_i0[d], m0 = nx - c->slab_i0[d] - wd + 2;
+                    if (wd + 2 * ZW_MAX > nx) { ok = false; break; }      // (a column would appear twice in M)
+                    int lastq = -1, lastc = 0;
+                    for (int cm = 1 - ZW_MAX; cm <= wd + ZW_MAX; cm++) {
+                        int g = (m0 + cm - 2) % nx; if (g < 0) g += nx; g += 1;
+                        const int q = owner(g), cq = g - c->slab_i0[q] + 1;
+                        XbSeg &A = xsrc[q][d], &B = xdst[q][d];
+                        if (q == lastq && cq == lastc + 1) { A.len[A.n - 1]++; B.len[B.n - 1]++; }
+                        else if (A.n == 4) { ok = false; break; }
+                        else { A.c0[A.n] = cq; A.len[A.n++] = 1; B.c0[B.n] = cm; B.len[B.n++] = 1; }
+                        A.tot++; B.tot++;
+                        lastq = q; lastc = cq;
+                    }
+                }
+                // the exchange relation is symmetric (mirror of [i0 - Z, i0 + w - 1 + Z] under g -> nx - g + 1): the peer-mapped
+                // transport's double buffering counts on every pair swapping messages
+                for (int q = 0; q < P && ok; q++) for (int d = 0; d < P; d++) if ((xsrc[q][d].n != 0) != (xsrc[d][q].n != 0)) ok = false;
+            }
+            c->xband = ok;
         }
         if (c->band_mode && !c->xband) m = 1;          // the fold is exchanged after every subcycle anyway
         c->zM = m; c->zW = 2 * m;
@@ -1110,15 +1177,18 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             // w+zW-2k) -- zones of 2m+1 columns pay for it
             m = std::min(m, (ZW_MAX - 1) / 2);
             c->zM = m; c->zW = 2 * m + 1;
-            c->xb_partner = c->nranks - 1 - c->rank;
+            for (int q = 0; q < c->nranks; q++) {
+                if (xsrc[c->rank][q].n) c->xb_to.push_back({q, xsrc[c->rank][q]});
+                if (xdst[q][c->rank].n) c->xb_from.push_back({q, xdst[q][c->rank]});
+            }
             c->m = s;
-            // rows 1 .. nylM <-> the partner's rows N-nylM+1 .. N, rows 0 and nylM+1 the rows below / its north ghost row.  band_pair
-            // needs rows N-3 .. N+1; the rows below them are the ghost zone of the mirror slab IN Y: between two refreshes M is
-            // advanced here like a slab of its own (the pair kernel over its strips), every pair of subcycles costing two rows of
-            // validity from the bottom, so that one message per zM pairs -- sent together with the ghost-zone exchange --
+            // rows 1 .. nylM <-> rows N-nylM+1 .. N of the columns' owners, rows 0 and nylM+1 the row below / the north ghost row.
+            // band_pair needs rows N-3 .. N+1; the rows below them are the ghost zone of the mirror slab IN Y: between two refreshes
+            // M is advanced here like a slab of its own (the pair kernel over its strips), every pair of subcycles costing two rows
+            // of validity from the bottom, so that one message per zM pairs -- sent together with the ghost-zone exchange --
             // replaces the message per pair that the four-row M of the first version needed
             c->m.nyl = std::max(4, 2 * m + 1);
-            c->m.i0 = c->slab_i0[c->xb_partner];
+            c->m.i0 = s.nxg - s.i0 - s.nxl + 2;
             c->m.tmask = c->m.umask = c->m.iceumask = nullptr;
             c->m.tmphm = c->m.tile_ice = c->m.tile_dat = c->m.act_ice = c->m.act_any = nullptr;
             HIPCHK(c, hipMalloc(&c->m.F, sizeof(double) * slab_doubles(c->m)));
@@ -1127,10 +1197,13 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             HIPCHK(c, hipMemset(c->m.cmask, 0, mask_elems(c->m)));
             HIPCHK(c, hipMalloc(&c->d_mslab, sizeof(Slab)));
             HIPCHK(c, hipMemcpy(c->d_mslab, &c->m, sizeof(Slab), hipMemcpyHostToDevice));
-            const size_t ncol = (size_t)s.nxl + 2 * ZW_MAX;
-            c->xb_cap = ((size_t)XB_PLANES * (c->m.nyl + 2) * ncol * sizeof(double2) + (size_t)(c->m.nyl + 2) * ncol + 64) & ~(size_t)15;
-            HIPCHK(c, hipMalloc(&c->xb_send, c->xb_cap));
-            HIPCHK(c, hipMalloc(&c->xb_recv, c->xb_cap));
+            // one buffer per partner and direction, each large enough for the widest message (the static fields of evpk_prep)
+            size_t cols = 0;
+            for (const auto &P : c->xb_to) cols = std::max(cols, (size_t)P.seg.tot);
+            for (const auto &P : c->xb_from) cols = std::max(cols, (size_t)P.seg.tot);
+            c->xb_cap = ((size_t)XB_PLANES * (c->m.nyl + 2) * cols * sizeof(double2) + (size_t)(c->m.nyl + 2) * cols + 64) & ~(size_t)15;
+            HIPCHK(c, hipMalloc(&c->xb_send, c->xb_cap * c->xb_to.size()));
+            HIPCHK(c, hipMalloc(&c->xb_recv, c->xb_cap * c->xb_from.size()));
         }
         std::vector<int> band(c->ncx);
         for (int k = 0; k < c->ncx; k++) band[k] = k;
@@ -1212,6 +1285,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
             FAIL(c, "%s (blocks span i %d..%d, the rank's share is %d..%d)", g->nranks > 1 ? "multi-rank runs need x-slabs of whole columns (processor_shape slenderX1)"
                                                                                         : "single-rank context: blocks outside the grid", i0, i1, r0, r1);
         i0 = r0; i1 = r1; j0 = 1; j1 = g->ny_global;
+        c->w_bound = std::min(nbx_pp * bsx, (int)g->nx_global);          // no rank's slab is wider (every rank computes the same)
     }
     Slab &s = c->s;
     s.nxl = i1 - i0 + 1; s.nyl = j1 - j0 + 1; s.i0 = i0; s.j0 = j0; s.nxg = g->nx_global; s.nyg = g->ny_global;
@@ -2086,7 +2160,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nsdev = nullptr; a.xm = nullptr; a.dbg = nullptr; a.prio = c->prio;
+        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nmir = 0; a.mjmax = 0; a.nsdev = nullptr; a.xm = nullptr; a.dbg = nullptr; a.prio = c->prio;
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
@@ -2184,7 +2258,13 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                     }
                     SubArgs bm = a;
                     bm.s = c->m; bm.strips = c->d_mstrips; bm.nstrips = c->ms_n; bm.nsdev = nullptr; bm.jmax = c->m.nyl - 2;
-                    launch_sub2(c, bm, c->stream, revp, false);
+                    // M's advance writes M's rows below the band, the band workgroups of the main launch the rows above, both read
+                    // the other state buffer: the advance runs as workgroups OF the main launch (SubArgs::nmir) -- a launch of its
+                    // own, seven to nine rows of dependent marching, took as long as the main launch of a narrow slab and sat in
+                    // front of every pair (round 4, xp_compare: 52 us per pair; on stream2 beside the main launch the two event
+                    // hand-overs cost more than that: 29.5 against 24.4 ms per evp, rejected).  EVPK_XB_FUSE=0: the launch of its own
+                    if (c->xb_fuse) { a.nmir = c->ms_n; a.mjmax = c->m.nyl - 2; }
+                    else launch_sub2(c, bm, c->stream, revp, false);
                 }
                 a.xm = c->d_mslab;
                 a.nband = (s.nxl + 2 * G + 60) / 61;

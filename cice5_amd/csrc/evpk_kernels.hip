@@ -1005,6 +1005,9 @@ struct SubArgs {
     __device__ const Slab *xm_slab() const { return xm; }
     const int *nsdev;  // != nullptr: the number of entries of strips[] lives on the device (k_compact_strips wrote list and count; the
                        // host launches for the upper bound nstrips and never waits for the count): one rank, the pair kernels
+    int nmir, mjmax;   // > 0 (x-slab ranks on a tripole grid, XM kernels): the nmir strips of the mirror slab *xm (identity list, the
+                       // same ncx / R / G) are advanced by workgroups of THIS launch, after the band workgroups and before the slab's
+                       // own strips, storing rows <= mjmax -- M's advance between two refreshes costs no launch of its own
     int nband;         // > 0 (tripole, one rank, cyclic E-W): the first nband8 = 8*ceil(nband/8) workgroups of the launch are the
                        // tripole top band (band_pair); the strips follow
     int prio;          // k_subcycle2p: != 0 -- a wave lowers its issue priority as it advances (3, 2, 1, 0 over the quarters of its march), so
@@ -1864,11 +1867,12 @@ constexpr int BAND_LDS_DOUBLES = 2048 + 1024 + 4608 + 512;      // X, U1, S1, V2
 //  * ONE RANK (a.xm == nullptr): strip A and strip B are both strips of the rank's own slab (cyclic wrap), A covering columns
 //    0 .. nx/2 over the band workgroups and B their mirror images -- lane l of A <-> column 61 k - 1 + l, of B <-> nx - 61 k - 61 + l.
 //  * X-SLAB RANKS (a.xm = the mirror slab M, round 3): strip A is a strip of MY slab (ghost-zone mode: columns 1-G .. w+G), strip
-//    B the mirror strip of the MIRROR RANK P-1-r, read from and written to M -- a copy of that rank's rows N-3 .. N+1 (its ghost
-//    zones included) with the same column numbering as its own slab.  With equal slab widths w the image of my local column i
-//    is the partner's local column w - i, whatever the rank: lane l of A <-> column cA + l, of B <-> w - cA - 62 + l.  Both
-//    ranks compute both strips (the same bits); rows N-1 .. N+1 of M are therefore kept current HERE, rows N-3, N-2 come with
-//    one message per pair (xband_swap) -- instead of four exchanges per pair around band launches on a second stream.
+//    B its mirror image, read from and written to M -- rows N-3 .. N+1 of a VIRTUAL slab of my own width w that starts at global
+//    column nx - i0 - w + 2 (with equal slab widths and an even number of ranks: the slab of the mirror rank P-1-r; otherwise
+//    the columns of up to three ranks, round 4), ghost zones included.  The image of my local column i is M's local column
+//    w - i, whatever the rank: lane l of A <-> column cA + l, of B <-> w - cA - 62 + l.  The owners of M's columns compute the
+//    same strips (the same bits); rows N-1 .. N+1 of M are therefore kept current HERE, the rows below come with one message
+//    per zM pairs (xband_swap) -- instead of four exchanges per pair around band launches on a second stream.
 template <bool REVP, bool LAST2>
 __device__ __forceinline__ void band_pair(const SubArgs &a, int k, double *lds) {
     const Slab &sA = a.s;
@@ -2117,15 +2121,32 @@ __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
 }
 
 // CM (compact metrics): slots 2,3 hold (HTN,HTE) at columns c and c-1 instead of the four metric pairs in slots 2..5
+// what the pair kernels use of a slab, in scalar registers: the rank's own (kernel arguments) or, for the workgroups that advance
+// the mirror slab (XM), the struct in device memory -- read lane-uniformly so that it stays in SGPRs
+struct SlabV { double *F; const unsigned char *cmask; int pitch, rstride, nxl, nyl; };
+__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+}
+__device__ __forceinline__ SlabV slab_view(const SubArgs &a, bool mir) {
+    SlabV v{a.s.F, a.s.cmask, a.s.pitch, a.s.rstride, a.s.nxl, a.s.nyl};
+    if (mir) {
+        const Slab *m = a.xm;
+        v.F = reinterpret_cast<double *>(uni64(reinterpret_cast<unsigned long long>(m->F)));
+        v.cmask = reinterpret_cast<const unsigned char *>(uni64(reinterpret_cast<unsigned long long>(m->cmask)));
+        v.pitch = __builtin_amdgcn_readfirstlane(m->pitch); v.rstride = __builtin_amdgcn_readfirstlane(m->rstride);
+        v.nxl = __builtin_amdgcn_readfirstlane(m->nxl); v.nyl = __builtin_amdgcn_readfirstlane(m->nyl);
+    }
+    return v;
+}
+
 #ifndef EVPK_K2P_ILP
 #define EVPK_K2P_ILP 0      // measured (round 4, scripts/lib_ab.sh): 255 VGPRs + 2 spilled, 0 ... -1.5 % -- the partner wave already fills the bubbles
 #endif
 constexpr bool K2P_ILP = EVPK_K2P_ILP != 0;
-template <bool REVP, bool LAST2, bool CM>
+template <bool REVP, bool LAST2, bool CM, bool XM = false>
 __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two workgroups per CU: at most 256 VGPRs
     __shared__ double2 smem[4 * PF_SLOTS * 64];
     static_assert(sizeof(double2) * 4 * PF_SLOTS * 64 >= sizeof(double) * BAND_LDS_DOUBLES, "the band workgroups use the same LDS");
-    const Slab &s = a.s;
     const int lane = threadIdx.x & 63;
     double2 *const L = smem + (size_t)(threadIdx.x >> 6) * PF_SLOTS * 64;     // this wave's slots
     const int nband8 = (a.nband + 7) & ~7;
@@ -2133,15 +2154,27 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, reinterpret_cast<double *>(smem));
         return;
     }
-    const int bidx = (int)blockIdx.x - nband8;
-    const int ns = pair_nstrips(a);
-    const int chunk = a.nsdev ? (((ns + 3) >> 2) + 7) >> 3 : ((int)gridDim.x - nband8) >> 3;
-    if ((bidx >> 3) >= chunk) return;
-    const int wg = (bidx & 7) * chunk + (bidx >> 3);
-    const int sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
-    if (sid >= ns) return;
-    const int st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
-    dbg_stamp(a, sid, 0);
+    // XM (x-slab ranks, tripole): the next workgroups advance the strips of the mirror slab (SubArgs::nmir)
+    const int nmir8 = XM ? ((((a.nmir + 3) >> 2) + 7) & ~7) : 0;
+    const bool mir = XM && (int)blockIdx.x - nband8 < nmir8;
+    const SlabV s = slab_view(a, mir);
+    const int jmax = mir ? a.mjmax : a.jmax;
+    int sid, st;
+    if (mir) {
+        sid = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - nband8) * 4 + (int)(threadIdx.x >> 6));
+        if (sid >= a.nmir) return;
+        st = sid;
+    } else {
+        const int bidx = (int)blockIdx.x - nband8 - nmir8;
+        const int ns = pair_nstrips(a);
+        const int chunk = a.nsdev ? (((ns + 3) >> 2) + 7) >> 3 : ((int)gridDim.x - nband8 - nmir8) >> 3;
+        if ((bidx >> 3) >= chunk) return;
+        const int wg = (bidx & 7) * chunk + (bidx >> 3);
+        sid = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
+        if (sid >= ns) return;
+        st = __builtin_amdgcn_readfirstlane(a.strips[sid]);
+        dbg_stamp(a, sid, 0);
+    }
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
     const int G = a.G;
@@ -2345,7 +2378,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
                 if (LAST2) tarear = *reinterpret_cast<const double *>(rq + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
                 const TMet mt2 = CM ? tmet_from_lengths(hn_p, hn_pp, he_p, hw_p, tiny_p, str_p) : mtp;
                 stress_cell<LAST2, K2P_ILP>(mt2, u1_c, u1_m, u1p_c, u1p_m, v1_c, v1_m, v1p_c, v1p_m, a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
-                if (own && q2 >= jb && q2 < jb + R && q2 <= a.jmax) {
+                if (own && q2 >= jb && q2 < jb + R && q2 <= jmax) {
                     store_sig(rq, pp, SW, lo, g2);
                     if (cyc && c == 1) store_sig(rq, pp, SW, lo + (unsigned)nxl * 16u, g2);
                     if (LAST2) {
@@ -2360,7 +2393,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
 
         // ---------------- stage 2: U2(r-2) ----------------
         const int q3 = r - 2;
-        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl && q3 <= a.jmax;
+        const bool u2act = (t >= 3) && own && (mpp & CM_U) != 0 && q3 >= jb && q3 < jb + R && q3 <= nyl && q3 <= jmax;
         if (__any(u2act)) {
             if (u2act) {
                 double un, vn, sxi, syi;
@@ -2387,7 +2420,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         mpp = mp; mp = m; m = m_n1; m_n1 = m_n2; m_n2 = m_n3;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may be in flight when the wave ends
-    dbg_stamp(a, sid, 1);
+    if (!mir) dbg_stamp(a, sid, 1);
 }
 
 template __global__ void k_subcycle2p<false, false, false>(SubArgs);
@@ -2398,6 +2431,10 @@ template __global__ void k_subcycle2p<false, false, true>(SubArgs);
 template __global__ void k_subcycle2p<true, false, true>(SubArgs);
 template __global__ void k_subcycle2p<false, true, true>(SubArgs);
 template __global__ void k_subcycle2p<true, true, true>(SubArgs);
+template __global__ void k_subcycle2p<false, false, false, true>(SubArgs);      // (the mirror slab is only advanced when another pair follows)
+template __global__ void k_subcycle2p<true, false, false, true>(SubArgs);
+template __global__ void k_subcycle2p<false, false, true, true>(SubArgs);
+template __global__ void k_subcycle2p<true, false, true, true>(SubArgs);
 
 template __global__ void k_subcycle2<false, false>(SubArgs);
 template __global__ void k_subcycle2<true, false>(SubArgs);
@@ -2685,10 +2722,9 @@ template __global__ void k_subcycle3w<true, true>(SubArgs);
 // same column / ghost-zone / tripole-band (jmax) rules, same arithmetic in the same order: bit-identical to k_subcycle2.
 // LDS: two arrays of [waves][4][64] doubles (the first one serves phases A and C).
 // ------------------------------------------------------------------------------------
-template <bool REVP, bool LAST2>
+template <bool REVP, bool LAST2, bool XM = false>
 __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     extern __shared__ double tl[];
-    const Slab &s = a.s;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = blockDim.x >> 6;                   // R + 3
@@ -2697,13 +2733,25 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
         if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, tl);
         return;
     }
-    const int bidx = (int)blockIdx.x - nband8;
-    const int ns = pair_nstrips(a);
-    const int chunk = a.nsdev ? (ns + 7) >> 3 : ((int)gridDim.x - nband8) >> 3;
-    const int wg = (bidx & 7) * chunk + (bidx >> 3);
-    if ((bidx >> 3) >= chunk || wg >= ns) return;     // (the whole workgroup leaves: no barrier is left waiting)
-    const int st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
-    if (w == 0) dbg_stamp(a, wg, 0);
+    // XM (x-slab ranks, tripole): the next workgroups advance the strips of the mirror slab (SubArgs::nmir), one each
+    const int nmir8 = XM ? ((a.nmir + 7) & ~7) : 0;
+    const bool mir = XM && (int)blockIdx.x - nband8 < nmir8;
+    const SlabV s = slab_view(a, mir);
+    const int jmax = mir ? a.mjmax : a.jmax;
+    int wg, st;
+    if (mir) {
+        wg = (int)blockIdx.x - nband8;
+        if (wg >= a.nmir) return;                     // (the whole workgroup leaves: no barrier is left waiting)
+        st = wg;
+    } else {
+        const int bidx = (int)blockIdx.x - nband8 - nmir8;
+        const int ns = pair_nstrips(a);
+        const int chunk = a.nsdev ? (ns + 7) >> 3 : ((int)gridDim.x - nband8 - nmir8) >> 3;
+        wg = (bidx & 7) * chunk + (bidx >> 3);
+        if ((bidx >> 3) >= chunk || wg >= ns) return; // (likewise)
+        st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
+        if (w == 0) dbg_stamp(a, wg, 0);
+    }
     const int cx = st % a.ncx, ry = st / a.ncx;
     const int R = a.R, nxl = s.nxl, nyl = s.nyl;
     const int G = a.G;
@@ -2818,7 +2866,7 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
             double tarear = 0.0;
             if (LAST2) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
             stress_cell<LAST2>(mt, u1_c, u1_m, Ys[0], Ys[128], v1_c, v1_m, Ys[64], Ys[192], a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
-            if (own && w <= R && r <= a.jmax) {
+            if (own && w <= R && r <= jmax) {
                 store_sig(rb, pp, SW, lo, g2);
                 if (cyc && c == 1) store_sig(rb, pp, SW, lo + (unsigned)nxl * 16u, g2);     // east ghost T column = image of column 1
                 if (LAST2) {
@@ -2834,7 +2882,7 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     __syncthreads();
 
     // ---------------- phase D: U2(r) ----------------
-    const bool u2act = (w >= 1) && (w <= R) && own && (m & CM_U) != 0 && r <= nyl && r <= a.jmax;
+    const bool u2act = (w >= 1) && (w <= R) && own && (m & CM_U) != 0 && r <= nyl && r <= jmax;
     if (__any(u2act)) {
         if (u2act) {
             const double *Xn = Xw + 256;
@@ -2851,13 +2899,15 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
             if (LAST2) { st1(rb, pp, F_STRINTX, lo, sxi); st1(rb, pp, F_STRINTY, lo, syi); }
         }
     }
-    if (w == 0) dbg_stamp(a, wg, 1);
+    if (w == 0 && !mir) dbg_stamp(a, wg, 1);
 }
 
 template __global__ void k_subcycle2t<false, false>(SubArgs);
 template __global__ void k_subcycle2t<true, false>(SubArgs);
 template __global__ void k_subcycle2t<false, true>(SubArgs);
 template __global__ void k_subcycle2t<true, true>(SubArgs);
+template __global__ void k_subcycle2t<false, false, true>(SubArgs);
+template __global__ void k_subcycle2t<true, false, true>(SubArgs);
 
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
@@ -2924,13 +2974,22 @@ __global__ void k_strip_flags2(Slab s, int ncx, int nry, int R, int cyc, int G, 
 }
 
 // ---- rows of pair planes <-> a message, for the mirror slab M of band_pair (x-slab ranks, tripole): pair planes L.f[0 .. np)
-// (even field ids), rows r0 .. r0+nr-1, columns 1-ZW_MAX .. nxl+ZW_MAX (ncol of them), then (mask != 0) the cmask bytes of the
-// same rows and columns.  Message layout: double2 [np][nr][ncol], bytes [nr][ncol]. ----
+// (even field ids), rows r0 .. r0+nr-1, the columns of the segment list G (up to four runs of columns: a run of the SENDER's
+// own columns that maps onto a run of the receiver's mirror slab -- M is a virtual slab of the receiver's width that starts at
+// global column nx - i0 - w + 2, so its columns come from the one, two or three ranks whose slabs cover that range, cyclically,
+// the way ice_HaloUpdate's tripole messages come from whichever blocks hold the mirrored columns, mpi/ice_boundary.F90:2737-2913),
+// then (mask != 0) the cmask bytes of the same rows and columns.  Message layout: double2 [np][nr][G.tot], bytes [nr][G.tot]. ----
 struct XbList { int f[16]; int np; };
-__global__ void k_xband_pack(Slab s, XbList L, int r0, int nr, int mask, double2 *msg) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, ncol = s.nxl + 2 * ZW_MAX;
+struct XbSeg { int n, tot; int len[4]; int c0[4]; };          // c0: first local column of the run (pack: in my slab; unpack: in M)
+__device__ __forceinline__ int xb_col(const XbSeg &G, int x) {
+    int c = G.c0[0] + x;
+    for (int k = 1, o = G.len[0]; k < G.n; o += G.len[k], k++) if (x >= o) c = G.c0[k] + (x - o);
+    return c;
+}
+__global__ void k_xband_pack(Slab s, XbList L, XbSeg G, int r0, int nr, int mask, double2 *msg) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ncol = G.tot;
     if (x >= ncol) return;
-    const int y = blockIdx.y, c = 1 - ZW_MAX + x;
+    const int y = blockIdx.y, c = xb_col(G, x);
     if (y < L.np * nr) {
         const int p = y / nr, k = y - p * nr;
         msg[(size_t)y * ncol + x] = *reinterpret_cast<const double2 *>(&FD(s, L.f[p], cell(s, c, r0 + k)));
@@ -2939,10 +2998,10 @@ __global__ void k_xband_pack(Slab s, XbList L, int r0, int nr, int mask, double2
         reinterpret_cast<unsigned char *>(msg + (size_t)L.np * nr * ncol)[(size_t)k * ncol + x] = s.cmask[mcell(s, c, r0 + k)];
     }
 }
-__global__ void k_xband_unpack(Slab m, XbList L, int r0, int nr, int mask, const double2 *msg) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, ncol = m.nxl + 2 * ZW_MAX;
+__global__ void k_xband_unpack(Slab m, XbList L, XbSeg G, int r0, int nr, int mask, const double2 *msg) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ncol = G.tot;
     if (x >= ncol) return;
-    const int y = blockIdx.y, c = 1 - ZW_MAX + x;
+    const int y = blockIdx.y, c = xb_col(G, x);
     if (y < L.np * nr) {
         const int p = y / nr, k = y - p * nr;
         *reinterpret_cast<double2 *>(&FD(m, L.f[p], cell(m, c, r0 + k))) = msg[(size_t)y * ncol + x];

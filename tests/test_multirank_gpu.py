@@ -213,9 +213,9 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q, uidq=None):
         if int(st.transport) != {"shm": 2, "ipc": 3, "rccl": 1}[xp]:
             bad.append(("transport", int(st.transport)))
         q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()), time.time() - t0,
-               int(st.zone_cols), int(st.zone_exchanges)))
+               int(st.zone_cols), int(st.zone_exchanges), int(st.band_row_exchanges)))
     except Exception:
-        q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0, 0, 0))
+        q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0, 0, 0, 0))
 
 
 def _device_count():
@@ -266,7 +266,7 @@ def _run(world, ns, nx, ny, bsx, bsy, ndte, env=None, xp="shm"):
         except OSError:
             pass
     assert len(res) == world
-    for rank, bad, icellu, k2, umax, secs, zc, zx in res:
+    for rank, bad, icellu, k2, umax, secs, zc, zx, bx in res:
         assert not bad, f"rank {rank}: {bad}"
     assert max(r[4] for r in res) > 1e-3
     print(f"[{world} ranks {ns}] worker seconds: {[round(r[5], 1) for r in res]}")
@@ -358,6 +358,18 @@ def test_x_slabs_tripole(xp):
     _run(3, "tripole", 240, 64, 20, 32, ndte=10, xp=xp)          # uneven mirror: 3 slabs
 
 
+@pytest.mark.parametrize("world,nx,bsx", [(3, 240, 20), (2, 240, 48), (5, 240, 48), (3, 240, 48), (4, 400, 40)])
+def test_mirror_slab_for_any_rank_count(world, nx, bsx):
+    """mpi/ice_boundary.F90:2737-2913 folds whatever blocks hold the mirrored columns.  The mirror slab of band_pair does the
+    same since round 4: an odd number of ranks (the middle one mirrors onto itself), slabs of unequal width (5 block columns on
+    2 or 3 ranks: 3 + 2, 2 + 2 + 1; 10 on 4: 3 + 3 + 3 + 1) -- one message per partner and zone refresh instead of an exchange
+    after every subcycle"""
+    res = _run(world, "tripole", nx, 64, bsx, 32, ndte=120, xp="ipc")
+    for r in res:
+        assert r[6] >= 3, r                      # ghost zones deeper than one launch: the mirror-slab path ran
+        assert 0 < r[8] <= 20, r                 # band_row_exchanges per evp(dt) of 120 subcycles (two calls: the last one's count)
+
+
 @pytest.mark.parametrize("ns,world", [("open", 3), ("tripole", 2), ("tripole", 4)])
 def test_transport_upwind_across_slabs(ns, world):
     _run(world, ns, 240, 64, 20, 32, ndte=12, env={"TEST_UPWIND": "1"}, xp="ipc")
@@ -418,3 +430,27 @@ def test_random_multirank_configuration(seed):
     xp = XPS[seed % 2]
     print("config:", world, ns, nx, ny, bsx, bsy, ndte, env, xp)
     _run(world, ns, nx, ny, bsx, bsy, ndte=ndte, env=env, xp=xp)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVPK_FUZZ_MR_N", "8"))))
+def test_random_unequal_slabs_on_a_tripole_grid(seed):
+    """Seeded random tripole runs whose block columns do NOT divide evenly over the ranks (create_distrb_cart then gives the
+    last rank a narrower slab) on 2-5 ranks: the mirror slab's columns come from two or three ranks, or the rank itself."""
+    rng = np.random.default_rng(9100 + seed + int(os.environ.get("EVPK_FUZZ_BASE", "0")))
+    while True:
+        world = int(rng.choice([2, 3, 4, 5]))
+        bsx = int(rng.choice([8, 12, 18, 20, 30]))
+        nbx = int(rng.integers(world, 3 * world + 1))
+        pp = (nbx - 1) // world + 1
+        if (world - 1) * pp < nbx and (nbx % world or world % 2) and nbx * bsx % 2 == 0:
+            break
+    nx = nbx * bsx
+    ny = int(rng.choice([24, 40, 64]))
+    bsy = int(rng.choice([ny, ny // 2]))
+    env = {"EVPK_ZONE_M": str(int(rng.integers(1, 5)))}
+    if rng.random() < 0.5:
+        env["TEST_WANDER_CALLS"] = "3"
+    ndte = int(rng.choice([8, 13, 24]))
+    xp = XPS[seed % 2]
+    print("config:", world, nx, ny, bsx, bsy, ndte, env, xp)
+    _run(world, "tripole", nx, ny, bsx, bsy, ndte=ndte, env=env, xp=xp)
