@@ -270,7 +270,7 @@ struct evpk_ctx {
     double2 *xb_send = nullptr, *xb_recv = nullptr;
     size_t xb_cap = 0;
     int w_bound = 0;
-    bool xb_fuse = true;
+    bool xb_fuse = true, xb_merge = true;
     int m_need = 1, xb_swaps = 0;     // m_need: the mirror slab's state must be fetched before the next pair launch
     struct XbPeer { int rank; XbSeg seg; };
     std::vector<XbPeer> xb_to, xb_from;   // whose mirror slabs hold columns of mine (runs of MY columns); who holds columns of my M (runs of M's)
@@ -571,18 +571,26 @@ static void xp_ring_bufs(evpk_ctx *c, hipStream_t st, double *lsend, size_t nSW,
         if (c->east >= 0) { b->sE = ipc_send_ptr(c, ch, c->east, 1); b->rE = ipc_recv_ptr(c, ch, c->east, 0); }
     }
 }
-static int xp_ring(evpk_ctx *c, const RingBufs &b, size_t nSW, size_t nSE, size_t nRE, size_t nRW, hipStream_t st = nullptr) {
+// phase: XP_ALL, or XP_POST (the peer-mapped transport rings the neighbours; the others do nothing yet) followed later by XP_DONE (it
+// waits for them; RCCL / the relay move the bytes) -- so that another exchange can be posted in between (zone_mirror_exchange)
+enum { XP_ALL = 0, XP_POST = 1, XP_DONE = 2 };
+static int xp_ring(evpk_ctx *c, const RingBufs &b, size_t nSW, size_t nSE, size_t nRE, size_t nRW, hipStream_t st = nullptr, int phase = XP_ALL) {
     if (!st) st = c->stream;
     const bool merged = (c->west == c->east && c->west >= 0);
     if (c->ipc) {
         const int ch = xp_channel(c, st);
-        if ((nSW > c->ipc->slot[ch] / 16) || (nSE > c->ipc->slot[ch] / 16)) FAIL(c, "ipc transport: message larger than its slot");
-        if (c->west >= 0 && ipc_signal(c, ch, c->west, st)) return 1;
-        if (c->east >= 0 && !merged && ipc_signal(c, ch, c->east, st)) return 1;
-        if (c->east >= 0 && ipc_wait(c, ch, c->east, st)) return 1;
-        if (c->west >= 0 && !merged && ipc_wait(c, ch, c->west, st)) return 1;
+        if (phase != XP_DONE) {
+            if ((nSW > c->ipc->slot[ch] / 16) || (nSE > c->ipc->slot[ch] / 16)) FAIL(c, "ipc transport: message larger than its slot");
+            if (c->west >= 0 && ipc_signal(c, ch, c->west, st)) return 1;
+            if (c->east >= 0 && !merged && ipc_signal(c, ch, c->east, st)) return 1;
+        }
+        if (phase != XP_POST) {
+            if (c->east >= 0 && ipc_wait(c, ch, c->east, st)) return 1;
+            if (c->west >= 0 && !merged && ipc_wait(c, ch, c->west, st)) return 1;
+        }
         return 0;
     }
+    if (phase == XP_POST) return 0;
     if (merged && (b.sE != b.sW + nSW || b.rW != b.rE + nRE)) FAIL(c, "xp_ring: merged message needs contiguous buffers");
     if (c->relay) {
         int rc = 0;
@@ -701,67 +709,82 @@ constexpr int XB_ROWS_MAX = 2 * ((ZW_MAX - 1) / 2) + 1 + 2;         // nylM + 2 
 static size_t xb_bytes(const XbList &L, const XbSeg &G, int nr, int mask) {
     return ((size_t)L.np * nr * G.tot * sizeof(double2) + (mask ? (size_t)nr * G.tot : 0) + 15) & ~(size_t)15;
 }
-static int xband_swap(evpk_ctx *c, const XbList &L, int r0, int m0, int nr, int mask, hipStream_t st) {
+struct XbXchg { std::vector<const double2 *> rcv; const double2 *self = nullptr; int ch = 0; };
+// phase XP_ALL, or XP_POST (pack; peer-mapped: ring the partners) / XP_DONE (the bytes arrive) / XP_UNPACK with the same XbXchg;
+// chan >= 0: the peer-mapped channel to use instead of the stream's own
+enum { XP_UNPACK = 3 };
+static int xband_swap(evpk_ctx *c, const XbList &L, int r0, int m0, int nr, int mask, hipStream_t st, int phase = XP_ALL, XbXchg *xx = nullptr,
+                      int chan = -1) {
     Slab &s = c->s;
-    const int ch = xp_channel(c, st), tx = 128;
+    XbXchg loc;
+    XbXchg &X = xx ? *xx : loc;
+    const int tx = 128;
+    if (phase == XP_ALL || phase == XP_POST) X.ch = chan >= 0 ? chan : xp_channel(c, st);
+    const int ch = X.ch;
     auto sndp = [&](size_t k, int q) { return (c->ipc && q != c->rank) ? reinterpret_cast<double2 *>(ipc_send_ptr(c, ch, q, 0))
                                                                         : reinterpret_cast<double2 *>((char *)c->xb_send + k * c->xb_cap); };
     auto rcvp = [&](size_t k, int q) { return q == c->rank ? static_cast<const double2 *>(nullptr)
                                               : c->ipc ? reinterpret_cast<const double2 *>(ipc_recv_ptr(c, ch, q, 0))
                                                        : reinterpret_cast<const double2 *>((char *)c->xb_recv + k * c->xb_cap); };
-    const double2 *self = nullptr;
-    for (size_t k = 0; k < c->xb_to.size(); k++) {
-        const auto &P = c->xb_to[k];
-        const size_t bytes = xb_bytes(L, P.seg, nr, mask);
-        if (bytes > c->xb_cap) FAIL(c, "xband_swap: message larger than its buffer");
-        if (c->relay && P.rank != c->rank && bytes > c->relay->slot) FAIL(c, "shared-memory relay: band rows message larger than its slot");
-        if (c->ipc && P.rank != c->rank && bytes > c->ipc->slot[ch] / 2) FAIL(c, "ipc transport: band rows message larger than its slot");
-        double2 *snd = sndp(k, P.rank);
-        if (P.rank == c->rank) self = snd;
-        const dim3 g((unsigned)((P.seg.tot + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
-        hipLaunchKernelGGL(k_xband_pack, g, dim3(tx), 0, st, s, L, P.seg, r0, nr, mask, snd);
+    if (phase == XP_ALL || phase == XP_POST) {
+        for (size_t k = 0; k < c->xb_to.size(); k++) {
+            const auto &P = c->xb_to[k];
+            const size_t bytes = xb_bytes(L, P.seg, nr, mask);
+            if (bytes > c->xb_cap) FAIL(c, "xband_swap: message larger than its buffer");
+            if (c->relay && P.rank != c->rank && bytes > c->relay->slot) FAIL(c, "shared-memory relay: band rows message larger than its slot");
+            if (c->ipc && P.rank != c->rank && bytes > c->ipc->slot[ch] / 2) FAIL(c, "ipc transport: band rows message larger than its slot");
+            double2 *snd = sndp(k, P.rank);
+            if (P.rank == c->rank) X.self = snd;
+            const dim3 g((unsigned)((P.seg.tot + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
+            hipLaunchKernelGGL(k_xband_pack, g, dim3(tx), 0, st, s, L, P.seg, r0, nr, mask, snd);
+        }
+        HIPCHK(c, hipGetLastError());
+        X.rcv.resize(c->xb_from.size());          // (peer-mapped: the page of the NEXT message, before the wait turns it)
+        for (size_t k = 0; k < c->xb_from.size(); k++) X.rcv[k] = rcvp(k, c->xb_from[k].rank);
+        if (c->ipc)
+            for (const auto &P : c->xb_to) if (P.rank != c->rank && ipc_signal(c, ch, P.rank, st)) return 1;
     }
-    HIPCHK(c, hipGetLastError());
-    std::vector<const double2 *> rcv_of(c->xb_from.size());          // (peer-mapped: the page of the NEXT message, before the wait turns it)
-    for (size_t k = 0; k < c->xb_from.size(); k++) rcv_of[k] = rcvp(k, c->xb_from[k].rank);
-    if (c->ipc) {
-        for (const auto &P : c->xb_to) if (P.rank != c->rank && ipc_signal(c, ch, P.rank, st)) return 1;
-        for (const auto &P : c->xb_from) if (P.rank != c->rank && ipc_wait(c, ch, P.rank, st)) return 1;
-    } else if (c->relay) {
-        int rc = 0;
-        for (size_t k = 0; k < c->xb_to.size(); k++)
-            if (c->xb_to[k].rank != c->rank) rc |= c->relay->send(c->xb_to[k].rank, sndp(k, c->xb_to[k].rank), xb_bytes(L, c->xb_to[k].seg, nr, mask), st);
-        for (size_t k = 0; k < c->xb_from.size(); k++)
-            if (c->xb_from[k].rank != c->rank)
-                rc |= c->relay->recv(c->xb_from[k].rank, (char *)c->xb_recv + k * c->xb_cap, xb_bytes(L, c->xb_from[k].seg, nr, mask), st);
-        if (rc) FAIL(c, "shared-memory relay: band rows exchange failed");
-    } else {
-        NCCLCHK(c, ncclGroupStart());
-        ncclResult_t rc = ncclSuccess;
-        auto keep = [&](ncclResult_t e) { if (rc == ncclSuccess) rc = e; };
-        for (size_t k = 0; k < c->xb_to.size(); k++)
-            if (c->xb_to[k].rank != c->rank) keep(ncclSend(sndp(k, c->xb_to[k].rank), xb_bytes(L, c->xb_to[k].seg, nr, mask), ncclChar, c->xb_to[k].rank, c->comm, st));
-        for (size_t k = 0; k < c->xb_from.size(); k++)
-            if (c->xb_from[k].rank != c->rank)
-                keep(ncclRecv((char *)c->xb_recv + k * c->xb_cap, xb_bytes(L, c->xb_from[k].seg, nr, mask), ncclChar, c->xb_from[k].rank, c->comm, st));
-        const ncclResult_t rce = ncclGroupEnd();
-        if (rc != ncclSuccess || rce != ncclSuccess) FAIL(c, "band rows exchange: ncclSend / ncclRecv failed");
+    if (phase == XP_ALL || phase == XP_DONE) {
+        if (c->ipc) {
+            for (const auto &P : c->xb_from) if (P.rank != c->rank && ipc_wait(c, ch, P.rank, st)) return 1;
+        } else if (c->relay) {
+            int rc = 0;
+            for (size_t k = 0; k < c->xb_to.size(); k++)
+                if (c->xb_to[k].rank != c->rank) rc |= c->relay->send(c->xb_to[k].rank, sndp(k, c->xb_to[k].rank), xb_bytes(L, c->xb_to[k].seg, nr, mask), st);
+            for (size_t k = 0; k < c->xb_from.size(); k++)
+                if (c->xb_from[k].rank != c->rank)
+                    rc |= c->relay->recv(c->xb_from[k].rank, (char *)c->xb_recv + k * c->xb_cap, xb_bytes(L, c->xb_from[k].seg, nr, mask), st);
+            if (rc) FAIL(c, "shared-memory relay: band rows exchange failed");
+        } else {
+            NCCLCHK(c, ncclGroupStart());
+            ncclResult_t rc = ncclSuccess;
+            auto keep = [&](ncclResult_t e) { if (rc == ncclSuccess) rc = e; };
+            for (size_t k = 0; k < c->xb_to.size(); k++)
+                if (c->xb_to[k].rank != c->rank) keep(ncclSend(sndp(k, c->xb_to[k].rank), xb_bytes(L, c->xb_to[k].seg, nr, mask), ncclChar, c->xb_to[k].rank, c->comm, st));
+            for (size_t k = 0; k < c->xb_from.size(); k++)
+                if (c->xb_from[k].rank != c->rank)
+                    keep(ncclRecv((char *)c->xb_recv + k * c->xb_cap, xb_bytes(L, c->xb_from[k].seg, nr, mask), ncclChar, c->xb_from[k].rank, c->comm, st));
+            const ncclResult_t rce = ncclGroupEnd();
+            if (rc != ncclSuccess || rce != ncclSuccess) FAIL(c, "band rows exchange: ncclSend / ncclRecv failed");
+        }
     }
-    for (size_t k = 0; k < c->xb_from.size(); k++) {
-        const auto &P = c->xb_from[k];
-        const double2 *rcv = P.rank == c->rank ? self : rcv_of[k];
-        if (!rcv) FAIL(c, "xband_swap: no message for the rank's own share of its mirror slab");
-        const dim3 g((unsigned)((P.seg.tot + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
-        hipLaunchKernelGGL(k_xband_unpack, g, dim3(tx), 0, st, c->m, L, P.seg, m0, nr, mask, rcv);
+    if (phase == XP_ALL || phase == XP_UNPACK) {
+        for (size_t k = 0; k < c->xb_from.size(); k++) {
+            const auto &P = c->xb_from[k];
+            const double2 *rcv = P.rank == c->rank ? X.self : X.rcv[k];
+            if (!rcv) FAIL(c, "xband_swap: no message for the rank's own share of its mirror slab");
+            const dim3 g((unsigned)((P.seg.tot + tx - 1) / tx), (unsigned)(L.np * nr + (mask ? nr : 0)));
+            hipLaunchKernelGGL(k_xband_unpack, g, dim3(tx), 0, st, c->m, L, P.seg, m0, nr, mask, rcv);
+        }
+        HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipGetLastError());
     return 0;
 }
 // the state (u, v and the twelve stresses) of buffer SB: every row of M, ghost rows included <- the mirror rank's rows N-nylM .. N+1
-static int xband_state(evpk_ctx *c, int SB, hipStream_t st) {
+static int xband_state(evpk_ctx *c, int SB, hipStream_t st, int phase = XP_ALL, XbXchg *xx = nullptr, int chan = -1) {
     XbList L{};
     for (int q = 0; q < NSTATE / 2; q++) L.f[L.np++] = SB + 2 * q;
-    return xband_swap(c, L, c->s.nyl - c->m.nyl, 0, c->m.nyl + 2, 0, st);
+    return xband_swap(c, L, c->s.nyl - c->m.nyl, 0, c->m.nyl + 2, 0, st, phase, xx, chan);
 }
 
 // ---- halo update of nf consecutive planes starting at f ---------------------------------
@@ -916,8 +939,18 @@ static void launch_sub3(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp
 
 // ---- ghost zones (zW columns per side) of a list of pair planes: x-slab neighbours ------------------------
 // compact: only the rows of the four zone windows that hold an active cell (lists made at prep), else all rows
-static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact) {
+struct ColsXchg { RingBufs rb; ZoneRows zr; size_t nSW, nSE, nRE, nRW; int npr; };
+static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact, int phase = XP_ALL, ColsXchg *cx = nullptr) {
     Slab &s = c->s;
+    ColsXchg loc;
+    ColsXchg &Q = cx ? *cx : loc;
+    if (phase == XP_DONE) return xp_ring(c, Q.rb, 2 * Q.nSW, 2 * Q.nSE, 2 * Q.nRE, 2 * Q.nRW, nullptr, XP_DONE);
+    if (phase == XP_UNPACK) {
+        if (Q.npr > 0) hipLaunchKernelGGL(k_cols_unpack, dim3((Q.npr + 255) / 256), dim3(256), 0, c->stream, s, pl, c->zW, Q.zr, (const double2 *)Q.rb.rW,
+                                          (const double2 *)Q.rb.rE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     const int W = c->zW, rows = s.nyl + 2;
     const int npl = pl.n + (pl.with_cmask ? 1 : 0);
     if (npl > 25) FAIL(c, "exchange_cols: too many planes");
@@ -943,7 +976,9 @@ static int exchange_cols(evpk_ctx *c, const PairList &pl, bool compact) {
             if (nSE) HIPCHK(c, hipMemcpyAsync(recvW, sendE, sizeof(double2) * nSE, hipMemcpyDeviceToDevice, c->stream));
         }
     } else {
-        if (xp_ring(c, rb, 2 * nSW, 2 * nSE, 2 * nRE, 2 * nRW)) return 1;
+        Q.rb = rb; Q.zr = zr; Q.nSW = nSW; Q.nSE = nSE; Q.nRE = nRE; Q.nRW = nRW; Q.npr = npr;
+        if (xp_ring(c, rb, 2 * nSW, 2 * nSE, 2 * nRE, 2 * nRW, nullptr, phase)) return 1;
+        if (phase == XP_POST) { HIPCHK(c, hipGetLastError()); return 0; }
     }
     if (npr > 0) hipLaunchKernelGGL(k_cols_unpack, dim3((npr + tx - 1) / tx), dim3(tx), 0, c->stream, s, pl, W, zr, (const double2 *)recvW,
                        (const double2 *)recvE, c->west >= 0 ? 1 : 0, c->east >= 0 ? 1 : 0);
@@ -1062,7 +1097,7 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             // (tripole: the band rows of xband_swap -- up to 12 pair planes x 5 rows + the mask bytes of a slab's columns and zones)
             const size_t xb_msg = c->ns == EVPK_BND_TRIPOLE ? ((size_t)(XB_PLANES * XB_ROWS_MAX * sizeof(double2) + XB_ROWS_MAX) * ((size_t)c->wmax + 2 * ZW_MAX) + 64) & ~(size_t)15 : 0;
             x.slot[0] = 2 * std::max<size_t>(std::max<size_t>(c->cslot * sizeof(double2), fold_msg), xb_msg);
-            x.slot[1] = 2 * std::max<size_t>((size_t)c->max_nf * (s.nyl + 2) * sizeof(double), fold_msg);
+            x.slot[1] = 2 * std::max<size_t>(std::max<size_t>((size_t)c->max_nf * (s.nyl + 2) * sizeof(double), fold_msg), xb_msg);   // (zone_mirror_exchange)
             x.chan_off[0] = 0;
             x.chan_off[1] = 2 * (size_t)c->nranks * x.slot[0];
             x.box_bytes = x.chan_off[1] + 2 * (size_t)c->nranks * x.slot[1];
@@ -1140,6 +1175,7 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
         {
             const char *xe = getenv("EVPK_XBAND");
             if (const char *e = getenv("EVPK_XB_FUSE")) c->xb_fuse = atoi(e) != 0;
+            if (const char *e = getenv("EVPK_XB_MERGE")) c->xb_merge = atoi(e) != 0;
             bool ok = c->band_mode && c->nranks > 1 && c->prefetch && c->band_fused && !(xe && atoi(xe) == 0) &&
                       minw >= 2 * ZW_MAX && s.nyl >= XB_ROWS_MAX + 1;
             if (ok) {
@@ -2144,16 +2180,36 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         return hipStreamWaitEvent(c->stream, c->evI, 0) != hipSuccess;
     };
     // refresh the ghost zones of state buffer `SBUF` from the neighbours (it must hold the current state)
-    auto zone_exchange = [&](int SBUF) -> int {
+    // with_mirror (x-slab ranks on a tripole grid, another pair follows): the refresh of the mirror slab travels in the same round --
+    // both exchanges are posted before either is waited for (peer-mapped: the mirror messages on the second channel, whose pages and
+    // counters the zone messages do not touch; RCCL: one group), so that a pair of ranks meets once per refresh instead of twice
+    auto zone_exchange = [&](int SBUF, bool with_mirror = false) -> int {
         bound_begin(c->stream);
-        if (exchange_cols(c, state_pairs(SBUF), c->zcompact)) return 1;
+        if (with_mirror && c->xband && c->xb_merge && !c->relay) {
+            XbXchg X;
+            ColsXchg Q;
+            const PairList pl = state_pairs(SBUF);
+            if (xband_state(c, SBUF, c->stream, XP_POST, &X, c->ipc ? 1 : -1)) return 1;
+            if (exchange_cols(c, pl, c->zcompact, XP_POST, &Q)) return 1;
+            if (!c->ipc) NCCLCHK(c, ncclGroupStart());
+            int rc = exchange_cols(c, pl, c->zcompact, XP_DONE, &Q);
+            rc |= xband_state(c, SBUF, c->stream, XP_DONE, &X);
+            if (!c->ipc && ncclGroupEnd() != ncclSuccess) FAIL(c, "zone + mirror exchange: ncclGroupEnd failed");
+            if (rc) return 1;
+            if (exchange_cols(c, pl, c->zcompact, XP_UNPACK, &Q)) return 1;
+            if (xband_state(c, SBUF, c->stream, XP_UNPACK, &X)) return 1;
+            c->xb_swaps++;
+        } else {
+            if (exchange_cols(c, state_pairs(SBUF), c->zcompact)) return 1;
+            with_mirror = false;
+        }
         bound_end(c->stream);
         c->zone_exchanges++;
         c->zone_bytes += (long long)(NSTATE / 2) * c->zW * 16 *
                          ((c->west >= 0 ? (c->zcompact ? c->zn[0] : s.nyl + 2) : 0) + (c->east >= 0 ? (c->zcompact ? c->zn[1] : s.nyl + 2) : 0));
         c->zone_left = c->zM;
         c->inner_ok = true;
-        c->m_need = 1;              // (x-slab tripole: the mirror slab is due as well)
+        c->m_need = with_mirror ? 0 : 1;              // (x-slab tripole: the mirror slab is due as well)
         return 0;
     };
     for (int n = 0; n < nsub;) {
@@ -2342,7 +2398,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
                 // the zones are used up (in a split round this overlaps the interior strips), or the evp is complete
                 if (c->zone_left < 1 || pair_ends_evp) {
                     if (!split && join()) FAIL(c, "hipStreamWaitEvent failed");
-                    if (zone_exchange(c->cur ? F_STATE1 : F_STATE0)) return 1;
+                    if (zone_exchange(c->cur ? F_STATE1 : F_STATE0, !pair_ends_evp && nsub - n >= 2 && c->p.ndte - c->ksub >= 2)) return 1;
                 }
             }
             continue;
