@@ -493,3 +493,126 @@ def test_two_rank_tripole_mirror_slab_gloo(m):
             p.terminate()
     for rank, bad in res:
         assert not bad, f"rank {rank}: {bad}"
+
+
+def _vmirror_worker(rank, world, port, m, widths, q):
+    """The round-4 form of the protocol above for ANY decomposition: the mirror strip of rank r is a VIRTUAL slab of r's own width
+    w that starts at global column nx - i0 - w + 2 (evpk_connect), so that the image of my local column c is its local column
+    w - c whatever the slab widths; its columns -- like the columns of my own ghost zones -- are fetched from whichever ranks own
+    them (cyclic in x).  Every rank publishes its own physical columns (an all-gather stands for the point-to-point messages
+    the library sends: one per partner); the E-W zones take all rows, the mirror strip its top 2m + 3 rows only."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          OMP_NUM_THREADS="2")
+        import torch
+        import torch.distributed as dist
+        from cice5_amd import blocks, constants as C, synth
+        from oracle import orc
+        from tests import util
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        nx, ny, ndte = int(sum(widths)), 40, 24
+        W = 2 * m + 1
+        nylM = max(4, 2 * m + 1)
+        starts = np.concatenate([[1], 1 + np.cumsum(widths)]).astype(np.int64)        # slab_i0, 1-based
+        w, i0, wmax = int(widths[rank]), int(starts[rank]), int(max(widths))
+        m0 = nx - i0 - w + 2                                                            # the mirror slab's first global column
+        L = w + 2 * W
+        case = synth.SynthCase(nx=nx, ny=ny, land="continents", ns_boundary=C.BND_TRIPOLE)
+        dx = blocks.create_distrb_cart(2 * L, ny, 2 * L, ny, ew_boundary_type="open", ns_boundary_type="tripole")
+        Iw, Jw = blocks.block_index_windows(dx)
+        col = Iw[0].astype(np.int64)                                                    # 0 .. 2L+1
+        gcolumn = np.where(col <= L, i0 - W - 1 + col, m0 - W - 1 + (col - L))
+        gw = (gcolumn - 1) % nx + 1                                                     # cyclic
+        owner = np.searchsorted(starts, gw, side="right") - 1
+        local = gw - starts[owner]                                                      # 0-based column inside its owner's slab
+        I, J = np.broadcast_arrays(gcolumn[None, :], Jw[0][:, None])
+        f = synth.make_block_fields(synth.SynthCase(nx=2 * L, ny=ny, ns_boundary=C.BND_TRIPOLE), dx)
+        cache = {}
+        for name in synth.GRID_FIELDS + synth.INPUT_FIELDS + synth.MASK_FIELDS:
+            f[name][0] = case.field(name, I, J, cache)
+        xmin = synth.global_min_dx(case)
+        p = orc.make_params(3600.0, ndte, xmin)
+        state = ["uvel", "vvel"] + util.SIGMA
+        axis = [int(k) for k in np.nonzero((gw == nx // 2) | (gw == nx))[0] if 1 <= k <= 2 * L]
+        shape = (1, ny + 2, 2 * L + 2)
+        pre = {}
+
+        def patch(ptr, loc, kind, fill, phase):      # the fold's axis columns: see _xband_worker
+            if loc != C.LOC_NECORNER or kind != C.KIND_VECTOR:
+                return
+            a = np.ctypeslib.as_array(ptr, shape=shape)
+            if phase == 0:
+                pre["top"] = a[0, ny, axis].copy()
+            else:
+                a[0, ny, axis] = -pre["top"]
+
+        keep = orc.set_halo_callback(patch)
+        zone_cols = [k for k in range(1, L + 1) if not (W + 1 <= k <= W + w)]            # my strip's two ghost zones
+        mirror_cols = list(range(L + 1, 2 * L + 1))                                      # every column of the mirror strip
+        rows = slice(ny - nylM, ny + 2)
+        partners = set()
+        for launch in range(ndte // 2):
+            orc.evp(dx, p, f, nsub=2)
+            if (launch + 1) % m:
+                continue
+            mine = torch.zeros((len(state), ny + 2, wmax), dtype=torch.float64)
+            for k, n in enumerate(state):
+                mine[k, :, :w] = torch.from_numpy(f[n][0][:, W + 1:W + w + 1].copy())
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            for k, n in enumerate(state):
+                for c in zone_cols:
+                    f[n][0][:, c] = every[owner[c]][k, :, local[c]].numpy()
+                for c in mirror_cols:
+                    f[n][0][rows, c] = every[owner[c]][k, rows, local[c]].numpy()
+            partners |= {int(owner[c]) for c in mirror_cols}
+        orc.set_halo_callback(None)
+        del keep
+        d1 = blocks.create_distrb_cart(nx, ny, 12, 10, ns_boundary_type="tripole")
+        f1 = synth.make_block_fields(case, d1)
+        for launch in range(ndte // 2):
+            orc.evp(d1, p, f1, nsub=2)
+        bad = []
+        for name in state:
+            G = blocks.gather_global(d1, f1[name])[:, i0 - 1:i0 - 1 + w]
+            Lc = f[name][0][1:ny + 1, W + 1:W + w + 1]
+            if not np.array_equal(G, Lc):
+                jj, ii = np.nonzero(G != Lc)
+                bad.append((name, int((G != Lc).sum()), int(jj.min()) + 1, int(ii.min()) + 1, int(ii.max()) + 1))
+        assert np.abs(f["uvel"]).max() > 1e-3
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bad, sorted(partners)))
+    except Exception:
+        q.put((rank, ["EXC " + traceback.format_exc()], []))
+
+
+@pytest.mark.parametrize("widths,m", [((28, 20), 2), ((16, 16, 16), 3), ((20, 16, 12), 1)])
+def test_virtual_mirror_slab_for_any_decomposition_gloo(widths, m):
+    """unequal slabs on two ranks, an odd rank count (the middle rank mirrors onto itself), both: the virtual mirror slab of
+    evpk_connect (round 4), zones and mirror rows fetched from their owners -- bit for bit the single-domain evp on every
+    rank's own columns; and who supplies a mirror slab: more than one rank as soon as the slabs are not mirror images"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = len(widths)
+    procs = [ctx.Process(target=_vmirror_worker, args=(r, world, port, m, widths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in procs:
+        res.append(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()
+    for rank, bad, partners in res:
+        assert not bad, f"rank {rank}: {bad}"
+    by_rank = {r: p for r, _, p in res}
+    if widths == (16, 16, 16):
+        assert 1 in by_rank[1] and len(by_rank[1]) == 3        # the middle rank's own columns, its zones from both neighbours
+    if widths == (28, 20):
+        assert by_rank[0] == [0, 1] and by_rank[1] == [0, 1]
