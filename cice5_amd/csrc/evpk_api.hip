@@ -271,6 +271,7 @@ struct evpk_ctx {
     size_t xb_cap = 0;
     int w_bound = 0;
     bool xb_fuse = true, xb_merge = true;
+    bool finish_fused = true;     // EVPK_FINISH_FUSED=0: k_finish, halo, k_to_tgrid2 on one rank as well
     int m_need = 1, xb_swaps = 0;     // m_need: the mirror slab's state must be fetched before the next pair launch
     struct XbPeer { int rank; XbSeg seg; };
     std::vector<XbPeer> xb_to, xb_from;   // whose mirror slabs hold columns of mine (runs of MY columns); who holds columns of my M (runs of M's)
@@ -1505,6 +1506,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (const char *bf = getenv("EVPK_BAND_FUSED")) c->band_fused = atoi(bf) != 0;
+    if (const char *ff = getenv("EVPK_FINISH_FUSED")) c->finish_fused = atoi(ff) != 0;
     if (const char *ds = getenv("EVPK_DEVICE_STRIPS")) c->dev_strips_env = atoi(ds) != 0;
     if (const char *tr = getenv("EVPK_TRIPLE")) c->triple_env = atoi(tr) != 0 ? 1 : 0;
     c->dbg_file = getenv("EVPK_DEBUG_CLOCKS");
@@ -2521,10 +2523,15 @@ extern "C" int evpk_finish(evpk_ctx *c) {
     const dim3 g2 = grid2d(s, B2D);
     const int SB = c->cur ? F_STATE1 : F_STATE0;
     if (c->ns == EVPK_BND_TRIPOLE && !c->eap && halo_stress12(c, SB + S_SP)) return 1;        // ice_dyn_evp.F90:454-479 (eap has none)
-    hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
-    // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)
-    if (halo(c, F_WORK3, 2, true, true, 0.0)) return 1;
-    hipLaunchKernelGGL(k_to_tgrid2, g2, B2D, 0, c->stream, s);
+    if (c->nranks == 1 && !c->force_exchange && c->finish_fused) {
+        // one rank: evp_finish and u2tgrid_vector in one launch, the ghost values of the work pair computed where they are read
+        hipLaunchKernelGGL(k_finish_tgrid, g2, B2D, 0, c->stream, s, c->p, c->cur, c->ew == EVPK_BND_CYCLIC ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
+        // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)
+        if (halo(c, F_WORK3, 2, true, true, 0.0)) return 1;
+        hipLaunchKernelGGL(k_to_tgrid2, g2, B2D, 0, c->stream, s);
+    }
     HIPCHK(c, hipGetLastError());
     return 0;
 }

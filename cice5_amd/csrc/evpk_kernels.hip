@@ -3245,6 +3245,55 @@ __global__ void k_finish(Slab s, DevParams p, int cur) {
     FD(s, F_WORK4, k) = yT;
 }
 
+// evp_finish AND the two U->T averages of u2tgrid_vector after it (ice_dyn_evp.F90:487-506) in one pass -- one rank, no exchange.
+// u2tgrid_vector averages strocnxT/yT over the U cells (i, j), (i-1, j), (i, j-1), (i-1, j-1): the west ghost column is the
+// cyclic image of column nx (or the fill value 0), the south ghost row the fill value, the north ghost row is not read -- what
+// the halo update of the two work planes between k_finish and k_to_tgrid2 delivers can be computed where it is needed.  A tile of
+// 64 x 4 threads evaluates evp_finish for its own cells and for the 64 + 4 + 1 cells of its south and west rim into the LDS,
+// then averages: the work planes are neither written nor read, one launch instead of six (finish, four halo steps, to_tgrid).
+__device__ __forceinline__ void finish_cell(const Slab &s, const DevParams &p, int SB, int i, int j, bool cyclic, bool store, double &xT, double &yT) {
+    xT = 0.0; yT = 0.0;
+    if (i == 0 && cyclic) i = s.nxl;                                              // (ice_HaloUpdate, E-W: ghost column 0 <- column nx)
+    if (i < 1 || i > s.nxl || j < 1 || j > s.nyl) return;                         // fill value of the halo update / not a U cell
+    if (!s.iceumask[mcell(s, i, j)]) return;
+    const size_t k = cell(s, i, j);
+    const double u = FD(s, SB + S_U, k), v = FD(s, SB + S_V, k);
+    const double du = FD(s, F_UOCN, k) - u, dv = FD(s, F_VOCN, k) - v;
+    const double aiu = FD(s, F_AIU, k), fm = FD(s, F_FM, k);
+    double vrel = p.rhow * FD(s, F_CW, k) * sqrt(du * du + dv * dv);              // :818-819
+    vrel = vrel * aiu;                                                             // :827
+    const double sg = copysign(1.0, fm);
+    const double sx = vrel * (du * p.cosw - dv * p.sinw * sg);                     // :828-831
+    const double sy = vrel * (dv * p.cosw + du * p.sinw * sg);
+    if (store) { FD(s, F_STROCNX, k) = sx; FD(s, F_STROCNY, k) = sy; }
+    xT = sx / aiu;                                                                 // :840-841
+    yT = sy / aiu;
+}
+__global__ void k_finish_tgrid(Slab s, DevParams p, int cur, int cyclic) {
+    TILE_SKIP(s.act_any)
+    __shared__ double X[TILE_Y + 1][TILE_X + 1], Y[TILE_Y + 1][TILE_X + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i = blockIdx.x * blockDim.x + tx, j = blockIdx.y * blockDim.y + ty;
+    const int SB = cur ? F_STATE1 : F_STATE0;
+    const bool cyc = cyclic != 0;
+    const bool own = (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl);
+    double xT, yT;
+    finish_cell(s, p, SB, i, j, cyc, own, xT, yT);                                 // (thread i = 0: the west ghost column's value)
+    X[ty + 1][tx + 1] = xT; Y[ty + 1][tx + 1] = yT;
+    if (tx == 0) { finish_cell(s, p, SB, i - 1, j, cyc, false, xT, yT); X[ty + 1][0] = xT; Y[ty + 1][0] = yT; }
+    if (ty == 0) { finish_cell(s, p, SB, i, j - 1, cyc, false, xT, yT); X[0][tx + 1] = xT; Y[0][tx + 1] = yT; }
+    if (tx == 0 && ty == 0) { finish_cell(s, p, SB, i - 1, j - 1, cyc, false, xT, yT); X[0][0] = xT; Y[0][0] = yT; }
+    __syncthreads();
+    if (!own) return;
+    const size_t k = cell(s, i, j), kw = cell(s, i - 1, j), ks = cell(s, i, j - 1), ksw = cell(s, i - 1, j - 1);
+    const double u0 = FD(s, F_UAREA, k), u1 = FD(s, F_UAREA, kw), u2 = FD(s, F_UAREA, ks), u3 = FD(s, F_UAREA, ksw);
+    const double ta = FD(s, F_TAREA, k);
+#define TG_(A) (0.25 * (((A[ty + 1][tx + 1] * u0 + A[ty + 1][tx] * u1) + A[ty][tx + 1] * u2) + A[ty][tx] * u3) / ta)
+    FD(s, F_STROCNXT, k) = TG_(X);
+    FD(s, F_STROCNYT, k) = TG_(Y);
+#undef TG_
+}
+
 // ------------------------------------------------------------------------------------
 // principal_stress (ice_dyn_shared.F90:853-893): normalised principal stresses of the NE corner,
 // from the resident sigma_1 planes and prs_sig
