@@ -2525,7 +2525,7 @@ extern "C" int evpk_finish(evpk_ctx *c) {
     if (c->ns == EVPK_BND_TRIPOLE && !c->eap && halo_stress12(c, SB + S_SP)) return 1;        // ice_dyn_evp.F90:454-479 (eap has none)
     if (c->nranks == 1 && !c->force_exchange && c->finish_fused) {
         // one rank: evp_finish and u2tgrid_vector in one launch, the ghost values of the work pair computed where they are read
-        hipLaunchKernelGGL(k_finish_tgrid, g2, B2D, 0, c->stream, s, c->p, c->cur, c->ew == EVPK_BND_CYCLIC ? 1 : 0);
+        hipLaunchKernelGGL(k_finish_tgrid, g2, B2D, 0, c->stream, s, c->p, c->cur, c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_finish, g2, B2D, 0, c->stream, s, c->p, c->cur);        // :487-503
         // u2tgrid_vector (:505-506, ice_grid.F90:1886-1910)

@@ -3269,20 +3269,37 @@ __device__ __forceinline__ void finish_cell(const Slab &s, const DevParams &p, i
     xT = sx / aiu;                                                                 // :840-841
     yT = sy / aiu;
 }
-__global__ void k_finish_tgrid(Slab s, DevParams p, int cur, int cyclic) {
+// ... and on a tripole grid the NE-corner update of the work pair also REWRITES the top physical row: U points of row ny lie on
+// the fold, the update leaves the mean of a point and the image of its mirror point there, the negated value on the two axis
+// columns nx/2 and nx (serial/ice_boundary.F90:818-824 and the copy :3752-3776; k_fold_apply, loc = 1, sgn = -1 for a vector)
+__device__ __forceinline__ void finish_cell_folded(const Slab &s, const DevParams &p, int SB, int i, int j, bool cyclic, bool tripole, bool store,
+                                                   double &xT, double &yT) {
+    finish_cell(s, p, SB, i, j, cyclic, store, xT, yT);
+    if (!tripole || j != s.nyl) return;
+    const int nx = s.nxl, h = nx / 2;                                               // (one rank: the slab is the whole grid)
+    const int g = (i == 0 && cyclic) ? nx : i;
+    if (g < 1 || g > nx) return;
+    const double sgn = -1.0;
+    if (g == h || g == nx) { xT = sgn * xT; yT = sgn * yT; return; }
+    double bx, by;
+    finish_cell(s, p, SB, nx - g, j, cyclic, false, bx, by);
+    if (g < h) { xT = sgn * (sgn * (0.5 * (xT + sgn * bx))); yT = sgn * (sgn * (0.5 * (yT + sgn * by))); }
+    else       { xT = sgn * (0.5 * (bx + sgn * xT)); yT = sgn * (0.5 * (by + sgn * yT)); }
+}
+__global__ void k_finish_tgrid(Slab s, DevParams p, int cur, int cyclic, int tripole) {
     TILE_SKIP(s.act_any)
     __shared__ double X[TILE_Y + 1][TILE_X + 1], Y[TILE_Y + 1][TILE_X + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int i = blockIdx.x * blockDim.x + tx, j = blockIdx.y * blockDim.y + ty;
     const int SB = cur ? F_STATE1 : F_STATE0;
-    const bool cyc = cyclic != 0;
+    const bool cyc = cyclic != 0, tri = tripole != 0;
     const bool own = (i >= 1 && i <= s.nxl && j >= 1 && j <= s.nyl);
     double xT, yT;
-    finish_cell(s, p, SB, i, j, cyc, own, xT, yT);                                 // (thread i = 0: the west ghost column's value)
+    finish_cell_folded(s, p, SB, i, j, cyc, tri, own, xT, yT);                                 // (thread i = 0: the west ghost column's value)
     X[ty + 1][tx + 1] = xT; Y[ty + 1][tx + 1] = yT;
-    if (tx == 0) { finish_cell(s, p, SB, i - 1, j, cyc, false, xT, yT); X[ty + 1][0] = xT; Y[ty + 1][0] = yT; }
-    if (ty == 0) { finish_cell(s, p, SB, i, j - 1, cyc, false, xT, yT); X[0][tx + 1] = xT; Y[0][tx + 1] = yT; }
-    if (tx == 0 && ty == 0) { finish_cell(s, p, SB, i - 1, j - 1, cyc, false, xT, yT); X[0][0] = xT; Y[0][0] = yT; }
+    if (tx == 0) { finish_cell_folded(s, p, SB, i - 1, j, cyc, tri, false, xT, yT); X[ty + 1][0] = xT; Y[ty + 1][0] = yT; }
+    if (ty == 0) { finish_cell_folded(s, p, SB, i, j - 1, cyc, tri, false, xT, yT); X[0][tx + 1] = xT; Y[0][tx + 1] = yT; }
+    if (tx == 0 && ty == 0) { finish_cell_folded(s, p, SB, i - 1, j - 1, cyc, tri, false, xT, yT); X[0][0] = xT; Y[0][0] = yT; }
     __syncthreads();
     if (!own) return;
     const size_t k = cell(s, i, j), kw = cell(s, i - 1, j), ks = cell(s, i, j - 1), ksw = cell(s, i - 1, j - 1);
