@@ -277,7 +277,7 @@ def main():
         # leg below, in the oracle, over the same blocks; the prognostic state compared bit for bit on every cell the reference
         # leaves defined.  The oracle is the checker here, never the thing measured.
         nv = min(a.cpu_subcycles, a.ndte)
-        names = ["uvel", "vvel"] + list(synth.STRESS_FIELDS)
+        names = ["uvel", "vvel"] + list(synth.STRESS_FIELDS) + ["strocnx", "strocny", "strocnxT", "strocnyT"]      # (the last four: evp_finish, u2tgrid_vector)
         solver.init_evp(a.dt)          # the host arrays are still the uploaded inputs; state back at rest
         ctx.upload(f)
         ctx.prep(); ctx.subcycle(nv); ctx.finish()
@@ -334,15 +334,17 @@ def main():
 
 def verify(d, got, ref, names, nsub, st, cpu):
     """bit comparison of the device result with the oracle's: (u, v) on all cells of every block (ghost cells halo-updated),
-    the stresses on physical + N/E ghost T cells (ice_dyn_shared.F90:528-537), as tests/util.compare does"""
+    the stresses on physical + N/E ghost T cells (ice_dyn_shared.F90:528-537), the ocean stresses of evp_finish on physical cells,
+    as tests/util.compare does"""
     allc = np.zeros((d.nblocks, d.ny_block, d.nx_block), dtype=bool)
-    ne = np.zeros_like(allc)
+    ne, phys = np.zeros_like(allc), np.zeros_like(allc)
     for n, b in enumerate(d.local_blocks):
         allc[n, :b.jhi + 1, :b.ihi + 1] = True
         ne[n, b.jlo - 1:b.jhi + 1, b.ilo - 1:b.ihi + 1] = True
+        phys[n, b.jlo - 1:b.jhi, b.ilo - 1:b.ihi] = True
     bad, cells = {}, 0
     for n in names:
-        m = allc if n in ("uvel", "vvel") else ne
+        m = allc if n in ("uvel", "vvel") else (phys if n.startswith("strocn") else ne)
         a, b_ = got[n][m], ref[n][m]
         neq = ~((a == b_) | (np.isnan(a) & np.isnan(b_)))
         cells += int(m.sum())
