@@ -134,3 +134,48 @@ def test_numpy_eap_equals_libm_build_of_the_c_oracle():
             for n in synth.EAP_STATE + synth.EAP_HISTORY:
                 assert np.array_equal(fn[n][ne], fo[n][ne]), (call, n, int((fn[n][ne] != fo[n][ne]).sum()))
         assert np.abs(fo["uvel"]).max() > 1e-3 and np.abs(fo["a11_1"] - 0.5).max() > 1e-6
+
+
+@pytest.mark.parametrize("nx,ny,trcr_depend,seed,amp", [(48, 40, (0, 1, 2 + 1), 0, 0.0), (48, 40, (0, 1, 2 + 1), 1, 0.45),
+                                                        (60, 36, (0, 1, 1, 2, 2 + 2, 0), 2, 0.3), (40, 44, (1, 2 + 1, 2), 3, 0.48)])
+def test_numpy_horizontal_remap_equals_c_oracle(nx, ny, trcr_depend, seed, amp):
+    """row f-3: horizontal_remap -- make_masks, construct_fields with its limited gradients, departure_points, locate_triangles,
+    triangle_coordinates, transport_integrals, update_fields -- read a second time (tests/npremap.py) against the C oracle, bit for
+    bit, integral orders 1 - 3 and both departure-point rules.  amp = 0: the smooth velocities of util.remap_case; else velocities
+    drawn per cell up to `amp` cell widths per step (the departure line crosses the edge, triangles in the side cells, negative
+    areas: every branch of locate_triangles that l_fixed_area = .false. can reach), tracers of all three types"""
+    from cice5_amd import constants as C
+    from tests import npremap
+    case, d, f, mm, tm, (ttype, depend, has) = util.remap_case(nx, ny, nx, ny, trcr_depend=trcr_depend)
+    dt = 3600.0
+    if amp:
+        rng = np.random.default_rng(seed)
+        for n, sc in (("uvel", f["dxu"]), ("vvel", f["dyu"])):
+            a = rng.uniform(-amp, amp, f[n].shape) * sc / dt * (f["umask"] != 0)
+            a[rng.random(a.shape) < 0.15] = 0.0
+            w = np.ascontiguousarray(a)
+            orc.halo_r8(d, w, C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+            f[n][...] = w
+    g = {k: v[0] for k, v in f.items() if isinstance(v, np.ndarray) and v.ndim == 3}
+    if amp:       # the rough field must reach the rare branches: triangles of group 3 (a departure point beside the edge's cells) and negative areas
+        dpx, dpy, stop = npremap.departure_points(g["uvel"], g["vvel"], g["dxu"], g["dyu"], g["HTN"], g["HTE"], dt, True)
+        assert not stop
+        for a in (dpx, dpy):
+            npremap.halo_cyclic(a)
+        for north in (False, True):
+            T = npremap.locate_triangles(north, dpx, dpy, g["dxu"], g["dyu"], 3)
+            assert all((T.area[k] != 0).sum() > 20 for k in range(5)) and (T.area[2] < 0).any() and (T.area[3] < 0).any()
+    phys = (slice(None), slice(1, -1), slice(1, -1))
+    results = []
+    for order, midpt in ((3, True), (2, False), (1, True), (3, False)):
+        mo, to, mn, tn = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+        assert orc.horizontal_remap(d, dt, f, mo, to, ttype, depend, has, integral_order=order, l_dp_midpt=midpt) == 0
+        assert npremap.horizontal_remap(g, mn[0], tn[0], dt, ttype, depend, has, order=order, midpt=midpt) == 0
+        assert np.array_equal(mn[0][phys], mo[0][phys]), (order, midpt, int((mn[0][phys] != mo[0][phys]).sum()))
+        assert np.array_equal(tn[0][:, :, 1:-1, 1:-1], to[0][:, :, 1:-1, 1:-1]), (order, midpt)
+        assert np.abs(mo - mm).max() > 1e-3
+        results.append(to.copy())
+    assert np.abs(results[0] - results[1]).max() > 0 and np.abs(results[0] - results[2]).max() > 0       # the options do change the result
+    # out of bounds departure points are refused by both
+    assert orc.horizontal_remap(d, 3.0e6, f, mm.copy(), tm.copy(), ttype, depend, has) == 1
+    assert npremap.horizontal_remap(g, mm.copy()[0], tm.copy()[0], 3.0e6, ttype, depend, has) == 1
