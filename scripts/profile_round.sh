@@ -1,5 +1,7 @@
 #!/bin/bash
-# One GPU box, everything the profiles/ directory of a round is made of.  usage: scripts/profile_round.sh <tag> [quick]
+# One GPU box, everything the profiles/ directory of a round is made of.  The pass labels its numbers with the hash of the csrc/ files
+# of the snapshot and measures the libevpk.so of the snapshot: build first, and leave csrc/ alone until gpurun has sent the tree (a
+# call can queue for minutes before it takes the snapshot -- round 4 lost a pass to an edit made in that window).  usage: scripts/profile_round.sh <tag> [quick]
 # Output: gpurun_out/<tag>/  (copy the summaries into profiles/<tag>/).  rocprofv3 gets the program itself after `--`;
 # the counter passes carry --kernel-trace only (no other trace domain beside --pmc).
 cd "$(dirname "$0")/.." || exit 1
