@@ -395,9 +395,15 @@ def update_fields(mm, fe, fn, tarear, tm=None, tfe=None, tfn=None, ttype=None, d
     return False
 
 
-def horizontal_remap(g, mm, tm, dt, ttype, depend, has, order=3, midpt=True):
+LOC_CENTER, LOC_NECORNER, KIND_SCALAR, KIND_VECTOR = 1, 2, 1, 2                   # ice_constants.F90: field_loc_*, field_type_*
+
+
+def horizontal_remap(g, mm, tm, dt, ttype, depend, has, order=3, midpt=True, halo_update=None):
     """:309-850 on one block: mm (ncat + 1, ny + 2, nx + 2), tm (ncat, ntrace, ny + 2, nx + 2) in place; g: uvel, vvel, dxu, dyu,
-    HTN, HTE, hm, tarear.  Returns 0, 1 (departure points out of bounds) or 2 (negative mass)."""
+    HTN, HTE, hm, tarear.  Returns 0, 1 (departure points out of bounds) or 2 (negative mass).
+    halo_update(a, field_loc, field_type) replaces the cyclic / open update (a tripole domain: the caller passes the halo routine
+    that IS pinned by reference output) -- the locations and types are those of :564-613"""
+    halo = halo_update if halo_update is not None else (lambda a, loc, kind: halo_cyclic(a))
     ncat = mm.shape[0] - 1
     mmask = [(mm[n] > puny).astype(np.float64) for n in range(ncat + 1)]                         # make_masks
     tmask = [[((mm[n] > puny) & (np.abs(tm[n - 1][nt]) > puny)).astype(np.float64) if has[nt] else np.zeros_like(mm[n])
@@ -410,12 +416,17 @@ def horizontal_remap(g, mm, tm, dt, ttype, depend, has, order=3, midpt=True):
     dpx, dpy, stop = departure_points(g["uvel"], g["vvel"], g["dxu"], g["dyu"], g["HTN"], g["HTE"], dt, midpt)
     if stop:
         return 1
-    for a in [dpx, dpy] + mc + mx + my:
-        halo_cyclic(a)
+    for a in (dpx, dpy):
+        halo(a, LOC_NECORNER, KIND_VECTOR)
+    for a in mc:
+        halo(a, LOC_CENTER, KIND_SCALAR)
+    for a in mx + my:
+        halo(a, LOC_CENTER, KIND_VECTOR)
     for n in range(1, ncat + 1):
-        for arr in (tc[n], tx[n], ty[n]):
-            for nt in range(arr.shape[0]):
-                halo_cyclic(arr[nt])
+        for nt in range(tc[n].shape[0]):
+            halo(tc[n][nt], LOC_CENTER, KIND_SCALAR)
+            halo(tx[n][nt], LOC_CENTER, KIND_VECTOR)
+            halo(ty[n][nt], LOC_CENTER, KIND_VECTOR)
     flux = {}
     for north in (False, True):
         T = locate_triangles(north, dpx, dpy, g["dxu"], g["dyu"], order)

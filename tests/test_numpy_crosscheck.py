@@ -179,3 +179,41 @@ def test_numpy_horizontal_remap_equals_c_oracle(nx, ny, trcr_depend, seed, amp):
     # out of bounds departure points are refused by both
     assert orc.horizontal_remap(d, 3.0e6, f, mm.copy(), tm.copy(), ttype, depend, has) == 1
     assert npremap.horizontal_remap(g, mm.copy()[0], tm.copy()[0], 3.0e6, ttype, depend, has) == 1
+
+
+def test_numpy_horizontal_remap_equals_c_oracle_on_a_tripole_domain():
+    """the second reading of horizontal_remap with the pinned halo routine plugged in: which of dpx / dpy, mc, mx / my, tc, tx / ty
+    is a scalar, which a vector, which sits on the NE corner (ice_transport_remap.F90:564-613) only shows across the fold"""
+    from cice5_amd import constants as C
+    from tests import npremap
+    nx, ny, dt = 48, 40, 3600.0
+    case, d, f, mm, tm, (ttype, depend, has) = util.remap_case(nx, ny, nx, ny, ns="tripole", trcr_depend=(0, 1, 2 + 1))
+    rng = np.random.default_rng(11)
+    for n, sc in (("uvel", f["dxu"]), ("vvel", f["dyu"])):
+        w = np.ascontiguousarray(rng.uniform(-0.4, 0.4, f[n].shape) * sc / dt * (f["umask"] != 0))
+        orc.halo_r8(d, w, C.LOC_NECORNER, C.KIND_VECTOR, 0.0)
+        f[n][...] = w
+    g = {k: v[0] for k, v in f.items() if isinstance(v, np.ndarray) and v.ndim == 3}
+    kinds = []
+
+    def halo_update(a, loc, kind):
+        t = np.ascontiguousarray(a[None])
+        orc.halo_r8(d, t, loc, kind, 0.0)
+        a[...] = t[0]
+        kinds.append((loc, kind))
+
+    assert (npremap.LOC_CENTER, npremap.LOC_NECORNER, npremap.KIND_SCALAR, npremap.KIND_VECTOR) == \
+        (C.LOC_CENTER, C.LOC_NECORNER, C.KIND_SCALAR, C.KIND_VECTOR)
+    mo, to, mn, tn = mm.copy(), tm.copy(), mm.copy(), tm.copy()
+    assert orc.horizontal_remap(d, dt, f, mo, to, ttype, depend, has) == 0
+    assert npremap.horizontal_remap(g, mn[0], tn[0], dt, ttype, depend, has, halo_update=halo_update) == 0
+    phys = (slice(None), slice(1, -1), slice(1, -1))
+    assert np.array_equal(mn[0][phys], mo[0][phys]) and np.array_equal(tn[0][:, :, 1:-1, 1:-1], to[0][:, :, 1:-1, 1:-1])
+    top = (slice(None), slice(-4, -1), slice(1, -1))
+    assert np.abs(mo[0][top] - mm[0][top]).max() > 1e-3                                   # ice moved next to the fold
+    assert (C.LOC_CENTER, C.KIND_VECTOR) in kinds and (C.LOC_NECORNER, C.KIND_VECTOR) in kinds
+    # ... and a wrong field type WOULD show there: the same run with every field updated as a scalar differs
+    mw, tw = mm.copy(), tm.copy()
+    assert npremap.horizontal_remap(g, mw[0], tw[0], dt, ttype, depend, has,
+                                    halo_update=lambda a, loc, kind: halo_update(a, loc, C.KIND_SCALAR)) in (0, 2)
+    assert not (np.array_equal(mw[0][phys], mo[0][phys]) and np.array_equal(tw[0][:, :, 1:-1, 1:-1], to[0][:, :, 1:-1, 1:-1]))
