@@ -161,7 +161,7 @@ typedef struct {
     int32_t compact_metrics;           /* 1: the kernels rebuild the eight metric planes from HTN / HTE (evpk_geom) */
     int32_t transport;                 /* EVPK_XP_*: what carries the exchanges between ranks */
     int32_t band_row_exchanges;        /* x-slab ranks on a tripole grid: refreshes of the mirror slab in the last evpk_subcycle call -- one message
-                                          per rank that owns columns of it (the mirror rank with equal slabs, up to three ranks otherwise), posted
+                                          per rank that owns columns of it, ghost zones included (the mirror rank and its neighbours with equal slabs: up to three ranks), posted
                                           together with the ghost-zone exchange; the fold itself runs inside the pair launches (band_pair) */
     float kernel3_ms;                  /* the same as kernel2_ms for the three-subcycle pipeline kernel (k_subcycle3w) */
     int32_t kernel3_launches, kernel3_timed;
