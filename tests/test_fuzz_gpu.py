@@ -100,6 +100,7 @@ def test_random_configuration(seed, monkeypatch):
             for ff in (fo, fg):
                 for name in ("strairxT", "strairyT"):
                     ff[name][...] = np.where(ff["aice"] > 0.0, base[name], 0.0)
+        fin = util.clone(fo) if call == 0 else None        # (kept for the second runs below, should this draw differ)
         nt, nu, _ = orc.evp(d, p, fo)
         if k["resident"] and call:             # the state stays on the device: inputs only, then the staged calls
             s.ctx.upload_inputs(fg)
@@ -110,7 +111,19 @@ def test_random_configuration(seed, monkeypatch):
         desc = {a: b for a, b in k.items() if a != "rng"}
         assert (st.icellt, st.icellu) == (nt, nu), (desc, call)
         bad = util.compare(d, fg, fo)
-        assert not bad, (desc, call, bad[:4])
+        if bad and call == 0:
+            # One draw in ~17 000 differed in round 4 and never again (profiles/r04_v6/fuzz.txt): say which side moves, should it recur
+            # -- the oracle once more from the same inputs, the device once more in a fresh context, then where the values differ
+            f2 = util.clone(fin)
+            orc.evp(d, p, f2)
+            f3 = util.clone(fin)
+            s3 = dyn.EvpDynamics(d, f3, ndte=k["ndte"], revised_evp=k["revised"], xmin=xmin, cosw=cosw, sinw=sinw, tilt_from_slope=k["tilt"],
+                                 wind_on_ugrid=k["ugrid_wind"], device_strength=k["strength"], pin_host=k["pin"], sparse_io=k["sparse"])
+            s3.init_evp(dt); s3.evp(dt); s3.close()
+            where = [(n, [tuple(int(v) for v in ix) for ix in np.argwhere(fg[n] != fo[n])[:4]]) for n, _, _ in bad[:4]]
+            bad = bad[:4] + [("oracle repeats itself", not util.compare(d, f2, fo)), ("device repeats itself", not util.compare(d, f3, fg)),
+                             ("second device run equals the oracle", not util.compare(d, f3, fo)), ("where (block, j, i)", where)]
+        assert not bad, (desc, call, bad)
     s.close()
 
 
