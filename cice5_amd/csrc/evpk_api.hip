@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -383,6 +384,12 @@ struct evpk_ctx {
     std::vector<int> kev_kind, kev_count;   // per timed span: subcycles per launch of its kernels (1, 2, 3), launches inside it
     int time_kernels = 1;          // EVPK_TIME_KERNELS: 0 none, 1 HIP events around launches 3..8 of every 20 (default), 2 every launch
     int nkev = 0;
+    // EVPK_VERIFY_DELIVERY (diagnostic): every plane a download writes IN PLACE into a caller's page-locked array is delivered a second
+    // time through the staging buffer + hipMemcpy and the two are compared on the host, value for value.  1: a difference is an error
+    // that names plane, block, cell and 4-KiB page; 2: the caller's array is repaired from the staged copy and the event counted
+    int verify_delivery = 0;
+    long long dv_checked = 0, dv_bad = 0, dv_planes = 0;
+    std::vector<double> dv_host;
     bool force_exchange = false;   // EVPK_FORCE_EXCHANGE=1: single rank takes the multi-rank pack/exchange/unpack path (tests)
     std::string err;
 };
@@ -437,30 +444,135 @@ extern "C" const char *evpk_last_error(const evpk_ctx *c) { return c ? c->err.c_
 // A host array registered with evpk_pin_host is read / written IN PLACE by the gather / scatter kernels over PCIe
 // (zero copy): no staging copy, and a download touches only the cells it delivers, so the round trip that keeps the
 // caller's other cells is not needed.  Unregistered arrays take the staged path below.
+//
+// The library keeps its OWN table of what it may touch in place (round 5): an array is read / written through its device
+// alias only if the whole of it lies inside a range that evpk_pin_host registered (and evpk_unpin_host has not released)
+// or that evpk_host_alloc handed out -- never because the HIP runtime happens to know the address from some other
+// registration (a stale one that overlaps a recycled heap address would otherwise silently take the zero-copy path).
+// A registered range is hardened as far as an unprivileged process can: MADV_NOHUGEPAGE on its pages (no khugepaged
+// collapse of the heap pages under an in-flight kernel) and mlock (best effort).  hipHostRegister'ed memory is mirrored by
+// the driver through MMU notifiers, not hard-pinned: memory that must never move comes from evpk_host_alloc
+// (hipHostMalloc: allocated and pinned by the driver).  EVPK_PIN_HARDEN=0 skips the two advisories.
+struct PinRange {
+    uintptr_t lo = 0, hi = 0;       // [lo, hi) as registered
+    char *dev = nullptr;            // device alias of lo
+    bool owned = false;             // evpk_host_alloc
+    bool locked = false;            // mlock succeeded on its pages
+};
+static std::mutex g_pin_mu;
+static std::vector<PinRange> g_pins;
+static long g_page = 0;
+static inline uintptr_t page_lo(uintptr_t a) { return a & ~(uintptr_t)(g_page - 1); }
+static inline uintptr_t page_hi(uintptr_t a) { return (a + g_page - 1) & ~(uintptr_t)(g_page - 1); }
+
 extern "C" int evpk_pin_host(void *ptr, size_t bytes) {
     if (!ptr || !bytes) return 1;
-    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
-    if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (!g_page) g_page = sysconf(_SC_PAGESIZE) > 0 ? sysconf(_SC_PAGESIZE) : 4096;
+    const uintptr_t lo = (uintptr_t)ptr, hi = lo + bytes;
+    for (const PinRange &r : g_pins)
+        if (lo < r.hi && r.lo < hi) return 1;           // overlaps a live registration: refuse (unpin first)
+    PinRange r;
+    r.lo = lo; r.hi = hi;
+    const char *hard = getenv("EVPK_PIN_HARDEN");
+    if (!hard || atoi(hard) != 0) {
+        const uintptr_t pl = page_lo(lo), ph = page_hi(hi);
+        (void)madvise((void *)pl, ph - pl, MADV_NOHUGEPAGE);
+        r.locked = (mlock((void *)pl, ph - pl) == 0);
+    }
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    void *dp = nullptr;
+    if (e == hipSuccess) {
+        e = hipHostGetDevicePointer(&dp, ptr, 0);
+        if (e != hipSuccess) (void)hipHostUnregister(ptr);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (r.locked) (void)munlock((void *)page_lo(lo), page_hi(hi) - page_lo(lo));
+        return 1;
+    }
+    r.dev = (char *)dp;
+    g_pins.push_back(r);
     return 0;
 }
 
 extern "C" int evpk_unpin_host(void *ptr) {
     if (!ptr) return 1;
-    const hipError_t e = hipHostUnregister(ptr);
-    if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t k = 0; k < g_pins.size(); k++) {
+        if (g_pins[k].lo != (uintptr_t)ptr || g_pins[k].owned) continue;
+        const PinRange r = g_pins[k];
+        g_pins.erase(g_pins.begin() + k);
+        const hipError_t e = hipHostUnregister(ptr);
+        if (e != hipSuccess) (void)hipGetLastError();
+        if (r.locked) {
+            // pages shared with another live registration (heap arrays are not page aligned) stay locked
+            uintptr_t pl = page_lo(r.lo), ph = page_hi(r.hi);
+            for (const PinRange &o : g_pins) {
+                if (o.owned) continue;
+                if (page_hi(o.hi) > pl && page_lo(o.lo) <= pl) pl = std::min(ph, page_hi(o.hi));
+                if (page_lo(o.lo) < ph && page_hi(o.hi) >= ph) ph = std::max(pl, page_lo(o.lo));
+            }
+            if (ph > pl) (void)munlock((void *)pl, ph - pl);
+        }
+        return e == hipSuccess ? 0 : 1;
+    }
+    return 1;       // not a range evpk_pin_host registered
+}
+
+// Page-locked host memory allocated AND pinned by the driver (hipHostMalloc), mapped into the device address space: the
+// home for arrays of a host model that can choose where they live (allocatable module arrays, the Python mirror's fields).
+// Such memory cannot migrate, be collapsed into huge pages or be swapped under a kernel that reads / writes it in place.
+extern "C" int evpk_host_alloc(size_t bytes, void **out) {
+    if (!out || !bytes) return 1;
+    *out = nullptr;
+    void *p = nullptr, *dp = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return 1; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    PinRange r;
+    r.lo = (uintptr_t)p; r.hi = r.lo + bytes; r.dev = (char *)dp; r.owned = true;
+    g_pins.push_back(r);
+    *out = p;
     return 0;
 }
 
-// device-visible alias of a registered host array -- or the pointer itself if the caller's array already lives in device
-// memory (a host model that keeps its fields on the GPU: OpenMP target / OpenACC `use_device` data) -- else nullptr
-static void *mapped_alias(const void *host) {
+extern "C" int evpk_host_free(void *ptr) {
+    if (!ptr) return 1;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t k = 0; k < g_pins.size(); k++) {
+        if (g_pins[k].lo != (uintptr_t)ptr || !g_pins[k].owned) continue;
+        g_pins.erase(g_pins.begin() + k);
+        if (hipHostFree(ptr) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        return 0;
+    }
+    return 1;
+}
+
+// 1 if [ptr, ptr + bytes) lies inside a live evpk_pin_host / evpk_host_alloc range (the library will move it in place), else 0
+extern "C" int evpk_host_is_mapped(const void *ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    const uintptr_t lo = (uintptr_t)ptr, hi = lo + bytes;
+    for (const PinRange &r : g_pins)
+        if (lo >= r.lo && hi <= r.hi) return 1;
+    return 0;
+}
+
+// device-visible alias of a host array the library registered or allocated -- or the pointer itself if the caller's array
+// already lives in device memory (a host model that keeps its fields on the GPU: OpenMP target / OpenACC `use_device`
+// data) -- else nullptr: the staged path
+static void *mapped_alias(const void *host, size_t bytes) {
+    if (!host) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        const uintptr_t lo = (uintptr_t)host, hi = lo + bytes;
+        for (const PinRange &r : g_pins)
+            if (lo >= r.lo && hi <= r.hi) return r.dev + (lo - r.lo);
+    }
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (at.type == hipMemoryTypeDevice) return const_cast<void *>(host);
-    if (at.type != hipMemoryTypeHost) return nullptr;
-    void *dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, const_cast<void *>(host), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return dp;
+    return nullptr;
 }
 
 // ---- host<->device transfer of one field -------------------------------------------------
@@ -468,7 +580,7 @@ static void *mapped_alias(const void *host) {
 static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char *act = nullptr) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    const double *src = (const double *)mapped_alias(host);
+    const double *src = (const double *)mapped_alias(host, n * sizeof(double));
     if (!src) {
         HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         src = c->stage;
@@ -483,7 +595,7 @@ static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char 
 static int upload_m(evpk_ctx *c, const int32_t *host, int32_t *dev_plane) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
-    const int32_t *src = (const int32_t *)mapped_alias(host);
+    const int32_t *src = (const int32_t *)mapped_alias(host, n * sizeof(int32_t));
     if (!src) {
         HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         src = (const int32_t *)c->stage;
@@ -495,14 +607,92 @@ static int upload_m(evpk_ctx *c, const int32_t *host, int32_t *dev_plane) {
     return 0;
 }
 
+// EVPK_VERIFY_DELIVERY: c->stage holds the sentinel everywhere except where the scatter kernel of this plane has just written the
+// values it ALSO wrote in place into the caller's page-locked array `host`; fetch it with a plain copy, wait for both, compare.
+static constexpr uint32_t DV_SENTINEL32 = 0x7ff4a5a5u;      // (as a pair of words: a signalling NaN no kernel of this library produces)
+static int verify_plane(evpk_ctx *c, void *host, size_t elem, size_t n, int f, const char *kind) {
+    c->dv_host.resize((n * elem + 7) / 8);
+    HIPCHK(c, hipMemcpyAsync(c->dv_host.data(), c->stage, n * elem, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t nblk = (size_t)c->nyb * c->nxb;
+    long long bad = 0, seen = 0;
+    size_t first = 0;
+    if (const char *inj = getenv("EVPK_VERIFY_INJECT")) {
+        // test hook: plane number <inj> of this context's checked planes "loses" the in-place write of its first delivered value
+        if (atoll(inj) == c->dv_planes) {
+            for (size_t k = 0; k < n; k++) {
+                const bool del = elem == 8 ? reinterpret_cast<const uint64_t *>(c->dv_host.data())[k] != (((uint64_t)DV_SENTINEL32 << 32) | DV_SENTINEL32)
+                                           : reinterpret_cast<const uint32_t *>(c->dv_host.data())[k] != DV_SENTINEL32;
+                if (!del) continue;
+                if (elem == 8) reinterpret_cast<uint64_t *>(host)[k] ^= 0x7ull; else reinterpret_cast<uint32_t *>(host)[k] ^= 0x7u;
+                break;
+            }
+        }
+    }
+    c->dv_planes++;
+    auto differs = [&](size_t k) -> bool {
+        if (elem == 8) {
+            const uint64_t d = reinterpret_cast<const uint64_t *>(c->dv_host.data())[k];
+            if (d == (((uint64_t)DV_SENTINEL32 << 32) | DV_SENTINEL32)) return false;
+            seen++;
+            return d != reinterpret_cast<const volatile uint64_t *>(host)[k];
+        }
+        const uint32_t d = reinterpret_cast<const uint32_t *>(c->dv_host.data())[k];
+        if (d == DV_SENTINEL32) return false;
+        seen++;
+        return d != reinterpret_cast<const volatile uint32_t *>(host)[k];
+    };
+    for (size_t k = 0; k < n; k++)
+        if (differs(k)) { if (!bad++) first = k; }
+    c->dv_checked += seen;
+    if (!bad) return 0;
+    c->dv_bad += bad;
+    const size_t blk = first / nblk, j = (first % nblk) / c->nxb + 1, i = first % c->nxb + 1;
+    const uintptr_t addr = (uintptr_t)host + first * elem;
+    char msg[400];
+    if (elem == 8) {
+        const double hv = reinterpret_cast<const double *>(host)[first], dv = c->dv_host[first];
+        snprintf(msg, sizeof(msg), "delivery check: %s %d, block %zu, (i,j) = (%zu,%zu), host address %#lx (4-KiB page %#lx): the caller's page-locked array "
+                 "holds %.17g, the device delivered %.17g; %lld of %lld delivered values of the plane differ", kind, f, blk + 1, i, j,
+                 (unsigned long)addr, (unsigned long)(addr >> 12), hv, dv, bad, seen);
+    } else {
+        snprintf(msg, sizeof(msg), "delivery check: %s plane, block %zu, (i,j) = (%zu,%zu), host address %#lx (4-KiB page %#lx): the caller's page-locked array "
+                 "holds %d, the device delivered %d; %lld of %lld delivered values differ", kind, blk + 1, i, j, (unsigned long)addr,
+                 (unsigned long)(addr >> 12), reinterpret_cast<const int32_t *>(host)[first], reinterpret_cast<const int32_t *>(c->dv_host.data())[first], bad, seen);
+    }
+    if (const char *log = getenv("EVPK_VERIFY_LOG")) {
+        if (FILE *fp = fopen(log, "a")) { fprintf(fp, "%s\n", msg); fclose(fp); }
+    }
+    if (c->verify_delivery >= 2) {      // repair: the staged copy is the device's word
+        for (size_t k = 0; k < n; k++) {
+            if (elem == 8) {
+                const uint64_t d = reinterpret_cast<const uint64_t *>(c->dv_host.data())[k];
+                if (d != (((uint64_t)DV_SENTINEL32 << 32) | DV_SENTINEL32)) reinterpret_cast<uint64_t *>(host)[k] = d;
+            } else {
+                const uint32_t d = reinterpret_cast<const uint32_t *>(c->dv_host.data())[k];
+                if (d != DV_SENTINEL32) reinterpret_cast<uint32_t *>(host)[k] = d;
+            }
+        }
+        return 0;
+    }
+    c->err = msg;
+    return 1;
+}
+
 // staged downloads start from the caller's bytes so that cells the reference leaves untouched keep their values
 static int download_f(evpk_ctx *c, double *host, int f, int mode, const unsigned char *act = nullptr) {
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    if (double *dst = (double *)mapped_alias(host)) {
+    if (double *dst = (double *)mapped_alias(host, n * sizeof(double))) {
         hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, dst, mode, act);
         HIPCHK(c, hipGetLastError());
+        if (c->verify_delivery && dst != host) {
+            HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->stage, (int)DV_SENTINEL32, 2 * n, c->stream));
+            hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, c->stage, mode, act);
+            HIPCHK(c, hipGetLastError());
+            return verify_plane(c, host, sizeof(double), n, f, "field");
+        }
         return 0;
     }
     HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -517,9 +707,15 @@ static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int 
     if (!host) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    if (int32_t *dst = (int32_t *)mapped_alias(host)) {
+    if (int32_t *dst = (int32_t *)mapped_alias(host, n * sizeof(int32_t))) {
         hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, dst, mode);
         HIPCHK(c, hipGetLastError());
+        if (c->verify_delivery && dst != host) {
+            HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->stage, (int)DV_SENTINEL32, n, c->stream));
+            hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, (int32_t *)c->stage, mode);
+            HIPCHK(c, hipGetLastError());
+            return verify_plane(c, host, sizeof(int32_t), n, -1, "mask");
+        }
         return 0;
     }
     HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -1176,6 +1372,11 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
         {
             const char *xe = getenv("EVPK_XBAND");
             if (const char *e = getenv("EVPK_XB_FUSE")) c->xb_fuse = atoi(e) != 0;
+            // the merged refresh over RCCL (one ncclGroupStart / End around the sends and receives of the ghost zones AND the mirror slab,
+            // several messages per peer in one group) has never run between two devices (1-GPU boxes: the multi-rank tests use the
+            // peer-mapped transport): until a multi-GPU pass of tests/test_multirank_gpu.py has covered it, RCCL ranks meet twice per
+            // refresh as in round 3 unless EVPK_XB_MERGE=1 asks for the merged form
+            if (c->comm && c->nranks > 1) c->xb_merge = false;
             if (const char *e = getenv("EVPK_XB_MERGE")) c->xb_merge = atoi(e) != 0;
             bool ok = c->band_mode && c->nranks > 1 && c->prefetch && c->band_fused && !(xe && atoi(xe) == 0) &&
                       minw >= 2 * ZW_MAX && s.nyl >= XB_ROWS_MAX + 1;
@@ -1439,6 +1640,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     }
     { const char *e = getenv("EVPK_PREFETCH"); c->prefetch = !(e && atoi(e) == 0); }
     { const char *e = getenv("EVPK_TILE"); c->tile_force = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+    { const char *e = getenv("EVPK_VERIFY_DELIVERY"); c->verify_delivery = e ? atoi(e) : 0; }
     c->nsimd = 4 * prop.multiProcessorCount;
 
     // neighbours on the slab ring
@@ -1610,7 +1812,7 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
         const double *hosts[3] = {in->aicen, in->vicen, in->aice0};
         for (int a = 0; a < 3; a++) {
             const int nc = a < 2 ? ncat : 1;
-            const double *src = (const double *)mapped_alias(hosts[a]);
+            const double *src = (const double *)mapped_alias(hosts[a], sizeof(double) * c->stage_n * nc);
             if (!src) {
                 HIPCHK(c, hipMemcpyAsync(c->stage_itd, hosts[a], sizeof(double) * c->stage_n * nc, hipMemcpyHostToDevice, c->stream));
                 src = c->stage_itd;
@@ -2014,7 +2216,7 @@ extern "C" int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st) {
     for (int q = 0; q < 8; q++) {
         const double *h = q < 4 ? st->a11_c[q] : st->a12_c[q - 4];
         if (!h) continue;
-        const double *dev = (const double *)mapped_alias(h);
+        const double *dev = (const double *)mapped_alias(h, sizeof(double) * n);
         if (!dev) {
             HIPCHK(c, hipMemcpyAsync(c->stage, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
             dev = c->stage;
@@ -2039,8 +2241,14 @@ extern "C" int evpk_eap_download(evpk_ctx *c, evpk_eap_state *st) {
     for (int q = 0; q < 19; q++) {
         if (!host[q]) continue;
         // T-cell fields: the physical cells and the N / E ghost T cells the reference computes too (ice_dyn_shared.F90:528-537)
-        if (double *dst = (double *)mapped_alias(host[q])) {
+        if (double *dst = (double *)mapped_alias(host[q], sizeof(double) * n)) {
             hipLaunchKernelGGL(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), dst, (int)MODE_NE);
+            if (c->verify_delivery && dst != host[q]) {
+                HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->stage, (int)DV_SENTINEL32, 2 * n, c->stream));
+                hipLaunchKernelGGL(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), c->stage, (int)MODE_NE);
+                HIPCHK(c, hipGetLastError());
+                if (verify_plane(c, host[q], sizeof(double), n, q, "eap member")) return 1;
+            }
             continue;
         }
         HIPCHK(c, hipMemcpyAsync(c->stage, host[q], n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -2611,7 +2819,7 @@ extern "C" int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2) {
 
 // ---- ice_HaloUpdate / ice_HaloUpdate_stress of a caller's block array on the device (SURVEY S8 row a3 as an entry point) ----
 static int halo_io_ptr(evpk_ctx *c, const double *host, size_t n, double **dev, bool *staged, double **pool, size_t *pool_n, bool upload) {
-    *dev = (double *)mapped_alias(host);
+    *dev = (double *)mapped_alias(host, sizeof(double) * n);
     *staged = (*dev == nullptr);
     if (*staged) {
         if (*pool_n < n) {
@@ -2666,7 +2874,7 @@ extern "C" int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nblk = (size_t)c->nyb * c->nxb, n = (size_t)c->nblocks * nblk;
     // both arrays through one staging pool when they are plain host memory: [a1 | a2]
-    double *d1 = (double *)mapped_alias(a1), *d2 = (double *)mapped_alias(a2);
+    double *d1 = (double *)mapped_alias(a1, sizeof(double) * n), *d2 = (double *)mapped_alias(a2, sizeof(double) * n);
     const bool staged1 = (d1 == nullptr), staged2 = (d2 == nullptr);
     if (staged1 || staged2) {
         if (c->tp_stage_n < 2 * n) {
@@ -2817,7 +3025,7 @@ extern "C" int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, doubl
     if (halo(c, F_SIG1, 1, false, true, 0.0, -1, nullptr, false, -1, 0, 2)) return 1;
     if (halo(c, F_SIG2, 1, false, true, 0.0, -1, nullptr, false, -1, 0, 3)) return 1;
     // the work array: in place where the caller's memory is visible to the device, else through a staging copy
-    double *dev = (double *)mapped_alias(works);
+    double *dev = (double *)mapped_alias(works, sizeof(double) * n);
     const bool staged = (dev == nullptr);
     if (staged) {
         if (c->tp_stage_n < n) {
@@ -2912,7 +3120,7 @@ extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat,
     bool staged[5];
     size_t need = 0;
     for (int q = 0; q < 5; q++) {
-        dev5[q] = (host5[q] && n5[q]) ? (double *)mapped_alias(host5[q]) : nullptr;
+        dev5[q] = (host5[q] && n5[q]) ? (double *)mapped_alias(host5[q], sizeof(double) * n5[q]) : nullptr;
         staged[q] = host5[q] && n5[q] && !dev5[q];
         if (staged[q]) need += n5[q];
     }
@@ -2960,6 +3168,11 @@ extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat,
         hipLaunchKernelGGL(k_upw_scatter, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, (double *const *)c->uw_tab,
                            c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0, fcov);
     }
+    // F_WORK1 is evp's T-grid wind plane: k_prep1a leaves tiles without input data that were inactive at the previous evp
+    // untouched on the understanding that they hold zeros, and k_to_ugrid4 averages them into strairx of U cells on a tile border
+    // (round 4's advisor finding: the coverage's 1.0 stayed behind).  EVPK_DEBUG_KEEP_COVER=1 leaves it (the regression test's proof that it bites)
+    if (fcov >= 0 && !(getenv("EVPK_DEBUG_KEEP_COVER") && atoi(getenv("EVPK_DEBUG_KEEP_COVER"))))
+        hipLaunchKernelGGL(k_fill_plane, g2, B2D, 0, c->stream, s, (int)F_WORK1, 0.0);
     HIPCHK(c, hipGetLastError());
     for (int q = 0; q < 5; q++)
         if (staged[q]) HIPCHK(c, hipMemcpyAsync(host5[q], dev5[q], sizeof(double) * n5[q], hipMemcpyDeviceToHost, c->stream));
@@ -2982,7 +3195,7 @@ extern "C" int evpk_remap_init(evpk_ctx *c, const double *dxu, const double *dyu
     const double *src[3] = {dxu, dyu, hm};
     const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
     for (int q = 0; q < 3; q++) {
-        const double *dev = (const double *)mapped_alias(src[q]);
+        const double *dev = (const double *)mapped_alias(src[q], sizeof(double) * n);
         if (!dev) {
             HIPCHK(c, hipMemcpyAsync(c->stage, src[q], sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
             dev = c->stage;
@@ -3129,7 +3342,7 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
     size_t n5[5] = {0, 0, 0, 0, 0};
     bool staged5[5] = {false, false, false, false, false};
     if (!st) {
-        dmm = (double *)mapped_alias(mm); dtm = ntp ? (double *)mapped_alias(tm) : nullptr;
+        dmm = (double *)mapped_alias(mm, sizeof(double) * n_mm); dtm = ntp ? (double *)mapped_alias(tm, sizeof(double) * n_tm) : nullptr;
         st_mm = !dmm; st_tm = ntp && !dtm;
         if (st_mm || st_tm) {
             const size_t need = (st_mm ? n_mm : 0) + (st_tm ? n_tm : 0);
@@ -3157,7 +3370,7 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
         double **dev5[5] = {&io.aice0, &io.aicen, &io.vicen, &io.vsnon, &io.trcrn};
         size_t need = 0;
         for (int q = 0; q < 5; q++) {
-            *dev5[q] = host5[q] ? (double *)mapped_alias(host5[q]) : nullptr;
+            *dev5[q] = host5[q] ? (double *)mapped_alias(host5[q], sizeof(double) * n5[q]) : nullptr;
             staged5[q] = host5[q] && !*dev5[q];
             if (staged5[q]) need += n5[q];
         }
@@ -3333,5 +3546,6 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, c->device);
     (void)hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, c->device);
     o->device_pci = (dom << 16) | (bus << 8) | dev;
+    o->delivery_checked = c->dv_checked; o->delivery_bad = c->dv_bad;
     return 0;
 }

@@ -1019,7 +1019,7 @@ struct SubArgs {
 };
 __global__ void k_dbg_clock(unsigned long long *out) { if (threadIdx.x == 0) *out = wall_clock64(); }
 __device__ __forceinline__ void dbg_stamp(const SubArgs &a, int sid, int which) {
-    if (a.dbg && (threadIdx.x & 63) == 0) {
+    if (a.dbg && (threadIdx.x & 63) == 0 && sid < 65535) {      // (the buffer holds 65536 entries; the last one is k_dbg_clock's)
         a.dbg[(size_t)sid * 4 + which] = wall_clock64();
         if (which == 0) {
             unsigned hwid, xcc;

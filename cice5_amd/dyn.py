@@ -79,7 +79,8 @@ class EvpDynamics:
                  pin_host: bool = False, device_strength: Optional[dict] = None, defer_connect: bool = False,
                  resident: bool = False, outputs: Optional[list] = None, sparse_io: bool = False):
         """pin_host: page-lock the arrays of `fields` (evpk_pin_host) as a host model does once for its module arrays;
-        evp() then moves them in place over PCIe.  The arrays must stay the same objects until close()."""
+        evp() then moves them in place over PCIe.  The arrays must stay the same objects until close() (this object keeps
+        a reference to each, so none can be freed while it is registered)."""
         self.decomp, self.fields = decomp, fields
         self.ndte, self.revised_evp = ndte, revised_evp
         self._opts = dict(cosw=cosw, sinw=sinw, tilt_from_slope=tilt_from_slope, wind_on_ugrid=wind_on_ugrid)
@@ -97,8 +98,17 @@ class EvpDynamics:
         self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id, defer_connect=defer_connect)
         self.ctx.device_strength = device_strength is not None
         self.params: Optional[evpk.Params] = None
-        self._pinned = [a for a in fields.values() if isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
-                        and evpk.pin_host(a)] if pin_host else []
+        # pin_host = True / "register": evpk_pin_host of the caller's own arrays (hipHostRegister; what a host with static module
+        # arrays can do); "alloc": the arrays of `fields` are MOVED to page-locked memory the driver allocates (evpk_host_alloc:
+        # the dict's entries are replaced by arrays there, same contents) -- memory that cannot migrate under a kernel
+        if pin_host == "alloc":
+            for k, a in list(fields.items()):
+                if isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"] and not evpk.host_is_mapped(a):
+                    fields[k] = evpk.host_copy(a)
+            self._pinned = []
+        else:
+            self._pinned = [a for a in fields.values() if isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
+                            and evpk.pin_host(a)] if pin_host else []
 
     def connect(self, unique_id: bytes):
         """second phase of a multi-rank start (EvpDynamics(..., defer_connect=True)): collective over the ranks"""

@@ -83,7 +83,8 @@ class Stats(ct.Structure):
                 ("compact_metrics", ct.c_int32), ("transport", ct.c_int32), ("band_row_exchanges", ct.c_int32),
                 ("kernel3_ms", ct.c_float), ("kernel3_launches", ct.c_int32), ("kernel3_timed", ct.c_int32),
                 ("strip_rows3", ct.c_int32), ("nstrips3", ct.c_int32),
-                ("rccl_ranks", ct.c_int32), ("device", ct.c_int32), ("device_pci", ct.c_int32)]
+                ("rccl_ranks", ct.c_int32), ("device", ct.c_int32), ("device_pci", ct.c_int32),
+                ("delivery_checked", ct.c_int64), ("delivery_bad", ct.c_int64)]
 
 XP_NAMES = {0: "none", 1: "rccl", 2: "shm relay", 3: "ipc peer-mapped", 4: "self (forced exchange)"}
 
@@ -94,7 +95,7 @@ EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "
            "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
            "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap", "evpk_transport_remap_state",
            "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download", "evpk_halo_update", "evpk_halo_update_stress",
-           "evpk_transport_upwind_state"]
+           "evpk_transport_upwind_state", "evpk_host_alloc", "evpk_host_free", "evpk_host_is_mapped"]
 
 REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS = 11, 12        # include/evpk.h
 
@@ -133,6 +134,9 @@ def lib():
         L.evpk_slab_layout.argtypes = [ct.c_int32] * 6 + [c_i32p]
         L.evpk_pin_host.argtypes = [ct.c_void_p, ct.c_size_t]
         L.evpk_unpin_host.argtypes = [ct.c_void_p]
+        L.evpk_host_alloc.argtypes = [ct.c_size_t, ct.POINTER(ct.c_void_p)]
+        L.evpk_host_free.argtypes = [ct.c_void_p]
+        L.evpk_host_is_mapped.argtypes = [ct.c_void_p, ct.c_size_t]
         L.evpk_connect.argtypes = [ctxp, ct.c_void_p]
         L.evpk_device_check.argtypes = [ct.c_int32]
         L.evpk_transport_upwind.argtypes = [ctxp, ct.c_double, ct.c_int32, c_f64p]
@@ -164,6 +168,48 @@ def pin_host(a: np.ndarray) -> bool:
 
 def unpin_host(a: np.ndarray) -> bool:
     return lib().evpk_unpin_host(ct.c_void_p(a.ctypes.data)) == 0
+
+
+class _HostBlock:
+    """one evpk_host_alloc allocation; freed when the last array on it is gone"""
+
+    def __init__(self, nbytes: int):
+        self.ptr = ct.c_void_p()
+        if lib().evpk_host_alloc(max(nbytes, 8), ct.byref(self.ptr)) != 0:
+            raise EvpkError("evpk_host_alloc failed (no device, or out of page-locked memory)")
+        self.nbytes = nbytes
+
+    def __del__(self):
+        if self.ptr and _lib is not None:
+            _lib.evpk_host_free(self.ptr)
+            self.ptr = ct.c_void_p()
+
+
+class _HostMem:
+    """array-interface owner of a _HostBlock: np.asarray(_HostMem) is a view whose base keeps the block alive"""
+
+    def __init__(self, blk, shape, dt):
+        self.blk = blk
+        self.__array_interface__ = {"data": (blk.ptr.value, False), "shape": tuple(int(v) for v in shape), "typestr": dt.str, "version": 3}
+
+
+def host_empty(shape, dtype=np.float64) -> np.ndarray:
+    """An array on page-locked memory that the DRIVER allocated and pinned (evpk_host_alloc = hipHostMalloc, mapped into the
+    device address space): the library reads / writes it in place, and its pages cannot move under a kernel.  Freed with the
+    last view of it."""
+    dt = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    return np.asarray(_HostMem(_HostBlock(int(np.prod(shape)) * dt.itemsize), shape, dt))
+
+
+def host_copy(a: np.ndarray) -> np.ndarray:
+    b = host_empty(a.shape, a.dtype)
+    b[...] = a
+    return b
+
+
+def host_is_mapped(a: np.ndarray) -> bool:
+    return lib().evpk_host_is_mapped(ct.c_void_p(a.ctypes.data), a.nbytes) == 1
 
 
 def _p64(a: Optional[np.ndarray]):

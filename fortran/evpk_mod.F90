@@ -86,6 +86,7 @@
          real (c_float) :: kernel3_ms
          integer (c_int32_t) :: kernel3_launches, kernel3_timed, strip_rows3, nstrips3
          integer (c_int32_t) :: rccl_ranks, device, device_pci
+         integer (c_int64_t) :: delivery_checked, delivery_bad
       end type evpk_stats
 
       ! evpk_eap_state (include/evpk.h): the structure tensor at the four corners, its cell means, the EAP history fields
@@ -99,7 +100,7 @@
 
       public :: evpk_get_unique_id, evpk_create, evpk_set_params, evpk_run, &
                 evpk_get_stats, evpk_destroy, evpk_last_error, evpk_error_string, &
-                evpk_principal_stress, evpk_pin_host, evpk_unpin_host, &
+                evpk_principal_stress, evpk_pin_host, evpk_unpin_host, evpk_host_alloc, evpk_host_free, evpk_host_is_mapped, &
                 evpk_upload, evpk_prep, evpk_subcycle, evpk_finish, evpk_download, &
                 evpk_connect, evpk_device_check, evpk_restart_write, evpk_restart_read, &
                 evpk_halo_update, evpk_halo_update_stress, evpk_transport_upwind_state, &
@@ -175,6 +176,21 @@
          integer (c_int) function evpk_unpin_host (ptr) bind(C, name='evpk_unpin_host')
             import :: c_int, c_ptr
             type (c_ptr), value :: ptr
+         end function
+         ! page-locked memory allocated and pinned by the driver (hipHostMalloc): c_f_pointer(out, a, shape) makes it an array
+         integer (c_int) function evpk_host_alloc (bytes, out) bind(C, name='evpk_host_alloc')
+            import :: c_int, c_ptr, c_size_t
+            integer (c_size_t), value :: bytes
+            type (c_ptr), intent(out) :: out
+         end function
+         integer (c_int) function evpk_host_free (ptr) bind(C, name='evpk_host_free')
+            import :: c_int, c_ptr
+            type (c_ptr), value :: ptr
+         end function
+         integer (c_int) function evpk_host_is_mapped (ptr, bytes) bind(C, name='evpk_host_is_mapped')
+            import :: c_int, c_ptr, c_size_t
+            type (c_ptr), value :: ptr
+            integer (c_size_t), value :: bytes
          end function
          ! two-phase start (nranks > 1): evpk_create with unique_id = c_null_ptr, agree across ranks, then connect
          integer (c_int) function evpk_connect (ctx, id) bind(C, name='evpk_connect')

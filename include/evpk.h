@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EVPK_VERSION 4
+#define EVPK_VERSION 5
 
 /* boundary types: ice_domain.F90 domain_nml ew_boundary_type / ns_boundary_type */
 enum { EVPK_BND_CYCLIC = 0, EVPK_BND_OPEN = 1, EVPK_BND_CLOSED = 2, EVPK_BND_TRIPOLE = 3 };
@@ -169,6 +169,9 @@ typedef struct {
     int32_t rccl_ranks;                /* ncclCommCount of the context's communicator (0: no RCCL communicator) */
     int32_t device;                    /* hipGetDevice ordinal the context runs on */
     int32_t device_pci;                /* (PCI domain << 16) | (bus << 8) | device of that GPU: distinct per physical device */
+    int64_t delivery_checked;          /* EVPK_VERIFY_DELIVERY: values written in place into page-locked caller arrays that were delivered a second
+                                          time through the staged path and compared (since evpk_create) ... */
+    int64_t delivery_bad;              /* ... and how many of them differed (mode 1: the first one fails the download; mode 2: repaired) */
 } evpk_stats;
 
 enum { EVPK_XP_NONE = 0, EVPK_XP_RCCL = 1, EVPK_XP_SHM_RELAY = 2, EVPK_XP_IPC = 3, EVPK_XP_SELF = 4 };
@@ -350,12 +353,25 @@ int evpk_destroy(evpk_ctx *c);
  * ice_flux / ice_grid, ice_state.F90 / ice_flux.F90) and map it into the device address space.  evpk_upload /
  * evpk_download / evpk_run then read and write such arrays in place over PCIe instead of staging them, and a download
  * touches only the cells it delivers.  Arrays that were not registered keep working (staged copies).  Unpin before the
- * memory is freed.  Returns 0 on success. */
+ * memory is freed.  Returns 0 on success; non-zero if the range overlaps a live registration or the runtime refuses.
+ * The library moves an array in place ONLY if all of it lies inside a range registered here (and not yet released) or
+ * handed out by evpk_host_alloc -- it keeps its own table and never trusts a registration it did not make.  The pages
+ * of a registered range are advised MADV_NOHUGEPAGE and mlock'ed (best effort; EVPK_PIN_HARDEN=0 skips both):
+ * hipHostRegister mirrors the caller's pages through MMU notifiers, it does not hard-pin them.
+ * evpk_host_alloc / evpk_host_free: page-locked memory allocated and pinned BY THE DRIVER (hipHostMalloc), mapped into
+ * the device address space -- for a host that can choose where its arrays live (allocatable arrays, c_f_pointer).
+ * evpk_host_is_mapped: 1 if [ptr, ptr + bytes) would be moved in place.
+ * EVPK_VERIFY_DELIVERY=1 (diagnostic): every plane a download writes in place is delivered a second time through the
+ * staged path and compared on the host; a difference fails the call with plane, block, cell and page in
+ * evpk_last_error (=2: the caller's array is repaired and the event counted, evpk_stats.delivery_bad). */
 /* Arrays that already live in DEVICE memory (a host model whose fields are resident on the GPU: OpenMP target /
  * OpenACC use_device pointers, hipMalloc) may be passed wherever a host array is expected: the library detects them
  * (hipPointerGetAttributes) and gathers / scatters them in place, no PCIe transfer at all. */
 int evpk_pin_host(void *ptr, size_t bytes);
 int evpk_unpin_host(void *ptr);
+int evpk_host_alloc(size_t bytes, void **out);
+int evpk_host_free(void *ptr);
+int evpk_host_is_mapped(const void *ptr, size_t bytes);
 const char *evpk_last_error(const evpk_ctx *c);  /* c may be NULL: error of the last failed evpk_create */
 
 /* Host-only description of this rank's halo exchange (no GPU needed): neighbours in the

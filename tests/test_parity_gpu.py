@@ -977,6 +977,56 @@ def test_transport_upwind_state_next_to_eliminated_land_blocks(ns):
     assert (so[4][:, :, kw["nt_Tsfc"] - 1][np.broadcast_to(ghost[:, None], so[1].shape)] == 0.0).any()
 
 
+@pytest.mark.parametrize("keep_cover", [False, True])
+def test_evp_after_transport_upwind_state_on_a_resident_context(keep_cover, monkeypatch):
+    """Round 4's advisor finding: evpk_transport_upwind_state builds its land-block coverage in evp's T-grid wind plane; a later evp on
+    the same resident context whose NEW ice lies two tiles away from the old ice skips the ice-free tile beside it (k_prep1a) and
+    averages that tile's wind into strairx (k_to_ugrid4) -- the plane must hold zeros there again.  evp, transport_upwind_state, inputs
+    with a new ice patch whose edge lies on a tile border (tiles are 64 x 4 cells), evp: every output against the oracle.
+    keep_cover: the same with the restoring fill switched off (EVPK_DEBUG_KEEP_COVER) must DIFFER -- the case bites."""
+    if keep_cover:
+        monkeypatch.setenv("EVPK_DEBUG_KEEP_COVER", "1")
+    nx, ny, bsx, bsy = 120, 96, 6, 4
+    case = synth.SynthCase(nx=nx, ny=ny, land="continents", ice="full")
+    full = blocks.create_distrb_cart(nx, ny, bsx, bsy)
+    ff = synth.make_block_fields(case, full)
+    work = [int(ff["tmask"][n, b.jlo - 1:b.jhi, b.ilo - 1:b.ihi].any()) for n, b in enumerate(full.local_blocks)]
+    assert sum(work) < len(work)
+    d = blocks.create_distrb_cart(nx, ny, bsx, bsy, work_per_block=work)
+    assert d.nblocks < full.nblocks                       # eliminated land blocks: the coverage plane is built
+    f = synth.make_block_fields(case, d)
+    base = util.clone(f)
+    xmin = synth.global_min_dx(case)
+    state, kw = _upwind_state(d, util.clone(f), 11, "lvl_ponds")
+    _, J = blocks.block_index_windows(d)
+    Jg = np.stack([np.broadcast_to(J[n][:, None], (d.ny_block, d.nx_block)) for n in range(d.nblocks)])
+    keep0 = (Jg <= 23)                                    # ice in tile rows 0 .. 5
+    keep1 = keep0 | ((Jg >= 48) & (Jg <= 51))             # + a band that fills tile row 12: tile rows 11 and 13 hold no data and were
+    fo, fg = util.clone(f), util.clone(f)                 #   not active at the first evp
+    p = orc.make_params(3600.0, 12, xmin)
+    s = dyn.EvpDynamics(d, fg, ndte=12, xmin=xmin, resident=True)
+    s.init_evp(3600.0)
+    for call, keep in enumerate((keep0, keep1)):
+        for x in (fo, fg):
+            for name in ("aice", "vice", "vsno", "aice_init", "strength", "strairxT", "strairyT"):
+                x[name][...] = base[name] * keep
+        nt, nu, _ = orc.evp(d, p, fo)
+        s.evp(3600.0)
+        bad = util.compare(d, fg, fo)
+        if call == 0:
+            assert not bad, bad[:6]
+            so, sg = [a.copy() for a in state], [a.copy() for a in state]
+            orc.transport_upwind_state(d, 3600.0, fo, *so, **kw)
+            s.ctx.transport_upwind_state(3600.0, *sg, **kw)
+            assert all(np.array_equal(a, b_) for a, b_ in zip(sg[1:], so[1:]))
+    s.close()
+    assert nu > 0
+    if keep_cover:
+        assert bad and any(n in ("strairx", "uvel") for n, _, _ in bad), "the case does not exercise the stale coverage plane"
+    else:
+        assert not bad, bad[:6]
+
+
 def _remap_on_device(d, f, mm, tm, tables, dt, order, midpt, env=None, monkeypatch=None):
     """horizontal_remap through the C ABI on synthetic velocities uploaded as the resident state"""
     ttype, depend, has = tables
