@@ -42,7 +42,11 @@ def parse():
     ap.add_argument("--ice", default="polar", choices=["polar", "full"])
     ap.add_argument("--land", default="continents", choices=["continents", "rows"])
     ap.add_argument("--ns", default="tripole", choices=["open", "tripole"])
-    ap.add_argument("--xblocks", type=int, default=8, help="blocks across x (one slab each at 8 GPUs)")
+    ap.add_argument("--xblocks", type=int, default=8,
+                    help="block columns (default 8: equal x-slabs on 1, 2, 4, 8 GPUs); 0 = the multiple of --gpus that divides the grid with "
+                         "blocks closest to 450 columns.  create_distrb_cart deals ceil(xblocks / gpus) columns to a rank: counts that "
+                         "do not divide leave the last ranks short or idle (the reference's 40x30 blocks = 90 columns on 8 ranks: "
+                         "12, ..., 12, 6 -- legal, 2x imbalanced)")
     ap.add_argument("--yblocks", type=int, default=10, help="blocks across y")
     ap.add_argument("--cpu-subcycles", type=int, default=120, help="subcycles of the CPU baseline sample (0 = skip)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "shm", "ipc"],
@@ -156,10 +160,15 @@ def main():
         sys.exit(3)
 
     nx, ny = (int(v) for v in a.grid.split("x"))
-    # (block columns need not divide over the ranks: create_distrb_cart gives every rank ceil(xblocks / world) of them and the last
-    #  one the rest, ice_distribution.F90:603-640 -- it must own at least one)
-    if nx % a.xblocks or ny % a.yblocks or (world - 1) * -(-a.xblocks // world) >= a.xblocks:
-        raise SystemExit("grid / xblocks / yblocks do not divide, or a rank would own no block column")
+    # (block columns need not divide over the ranks: create_distrb_cart gives every rank ceil(xblocks / world) of them, the last
+    #  ones the rest or none at all, ice_distribution.F90:603-640; a rank without a column joins the start and no exchange)
+    if a.xblocks == 0:
+        cand = [k * world for k in range(1, nx // world + 1) if nx % (k * world) == 0]
+        if not cand:
+            raise SystemExit(f"no block-column count divides {nx} columns over {world} ranks evenly")
+        a.xblocks = min(cand, key=lambda q: abs(nx // q - 450))
+    if nx % a.xblocks or ny % a.yblocks:
+        raise SystemExit("grid / xblocks / yblocks do not divide")
     bsx, bsy = nx // a.xblocks, ny // a.yblocks
     case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[a.ns], land=a.land, ice=a.ice, dt=a.dt, ndte=a.ndte)
     d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=a.ns)
@@ -232,7 +241,8 @@ def main():
     value = n_active * a.ndte * a.steps / dt_wall
     workload = (f"{nx}x{ny} ndte={a.ndte} ice={a.ice} land={a.land} ns={a.ns} "
                 f"({a.xblocks * a.yblocks} ice_blocks blocks of {bsx}x{bsy}, x-slabs over {world} GPU)")
-    roof = roofline(r, icellt / world, icellu / world, revp=False)
+    n_ring = -(-a.xblocks // (-(-a.xblocks // world)))          # ranks that own block columns
+    roof = roofline(r, icellt / n_ring, icellu / n_ring, revp=False)
     sha = source_sha()
     traffic, tnote = a.traffic_bytes, "given on the command line" if a.traffic_bytes else None
     rocprof_ms = None
@@ -264,12 +274,14 @@ def main():
                    # what carried the exchanges, as the library itself sees it: ncclCommCount of every rank's communicator (0 = no
                    # RCCL communicator: one rank, or the ipc / shm transports) and the distinct physical GPUs under the ranks
                    "rccl_ranks": rccl_ranks, "devices": len(set(p for _, p in devs)), "device_ordinals": [o for o, _ in devs],
+                   "ranks_with_block_columns": n_ring, "block_columns_per_rank": [max(0, min(-(-a.xblocks // world), a.xblocks - q * -(-a.xblocks // world))) for q in range(world)],
                    "ghost_zone_cols": int(st.zone_cols), "zone_exchanges_per_evp": int(st.zone_exchanges), "band_row_exchanges_per_evp": int(st.band_row_exchanges),
                    "zone_bytes_sent_rank0": int(st.zone_bytes), "overlap_split_rank0": int(st.overlap_split),
                    "step": "prep + ndte x (stress+stepu, halo / fold) + stress folds + finish"},
         "roofline": roof,
     }
 
+    exit_code = 0
     t_cpu = time.perf_counter()
     if rank == 0 and world == 1 and a.cpu_subcycles > 0:
         # verify: the benched context itself against the oracle on the box the number comes from -- state back at rest, the same
@@ -287,9 +299,23 @@ def main():
         out["cpu_baseline"] = cpu_baseline(d, f, a, xmin)       # (runs the oracle in place on f: nv subcycles from the same state)
         out["verify"] = verify(d, got, f, names, nv, vst, out["cpu_baseline"])
         del got
-    elif rank == 0:
-        out["verify"] = {"bit_identical": None, "note": "N = 1 only (the oracle is a one-process checker); the multi-rank path is "
-                                                        "covered by tests/test_multirank_gpu.py against the same oracle"}
+    elif world > 1 and a.cpu_subcycles > 0:
+        # verify, N > 1: every rank puts its slab back at rest and runs one untimed evp; rank 0 runs the WHOLE grid as ONE rank on its
+        # own GPU (the path the N = 1 line verifies against the oracle) and compares every rank's blocks with it, bit for bit
+        v = verify_multirank(a, case, d, f, solver, xmin, local_rank, rank, world, dist)
+        if rank == 0:
+            out["verify"] = v
+    # what the line claims about its ranks is part of the exit code: one RCCL rank and one physical GPU per process (EVPK_FORCE_DEVICE
+    # puts all ranks on one GPU on purpose: tests), and a result that equals the one-rank run
+    if rank == 0 and world > 1:
+        want_dev = 1 if os.environ.get("EVPK_FORCE_DEVICE") is not None else world
+        checks = {"devices": out["config"]["devices"] == want_dev,
+                  "rccl_ranks": (out["config"]["rccl_ranks"] == world) if a.transport == "rccl" else True,
+                  "bit_identical": out.get("verify", {}).get("bit_identical") is not False}
+        out["checks"] = checks
+        if not all(checks.values()):
+            out["failed"] = "checks"
+            exit_code = 4
     t_cpu = time.perf_counter() - t_cpu
     t_extra = time.perf_counter()
     # (profiling runs pass --cpu-subcycles 0 and skip the extras, so that their traces hold the timed workload only)
@@ -329,7 +355,12 @@ def main():
     if solver is not None:
         solver.close()
     if world > 1:
+        code = torch.tensor([exit_code], dtype=torch.int32)
+        dist.broadcast(code, src=0)
         dist.destroy_process_group()
+        exit_code = int(code[0])
+    if exit_code:
+        sys.exit(exit_code)
 
 
 def verify(d, got, ref, names, nsub, st, cpu):
@@ -356,6 +387,64 @@ def verify(d, got, ref, names, nsub, st, cpu):
                     f"benched decomposition, {int(st.kernel3_launches)} three-subcycle + {int(st.kernel2_launches)} two-subcycle + "
                     f"{int(st.kernel_launches)} one-subcycle launches) vs the oracle (the cpu_baseline run) on the same inputs",
             "counts_match": [int(st.icellt), int(st.icellu)] == [int(cpu["icellt"]), int(cpu["icellu"])]}
+
+
+def verify_multirank(a, case, d, f, solver, xmin, device, rank, world, dist):
+    """N > 1: the benched ranks against a ONE-rank device run of the whole grid.  Every rank: state back at rest, one untimed evp
+    (all ndte subcycles, stress folds, evp_finish) on its slab, its blocks' (u, v, sigma x 12, ocean stresses) to rank 0 over the
+    control plane (gloo).  Rank 0: the same evp for the whole grid in one context on its own GPU -- the configuration whose result
+    the N = 1 bench line compares with the oracle -- and a bit comparison per block on the cells the reference leaves defined."""
+    from cice5_amd import blocks, dyn, synth
+    names = ["uvel", "vvel"] + list(synth.STRESS_FIELDS) + ["strocnx", "strocny", "strocnxT", "strocnyT"]
+    ctx = solver.ctx
+    solver.init_evp(a.dt)
+    ctx.upload(f)
+    ctx.prep(); ctx.subcycle(a.ndte); ctx.finish()
+    got = {n: np.empty_like(f[n]) for n in names}
+    ctx.download(got)
+    mine = ([b.block_id for b in d.local_blocks], got)
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0)
+    if rank != 0:
+        return None
+    d1 = blocks.create_distrb_cart(d.nx_global, d.ny_global, d.block_size_x, d.block_size_y, ns_boundary_type=d.ns_boundary)
+    f1 = synth.make_block_fields(case, d1)
+    s1 = dyn.EvpDynamics(d1, f1, ndte=a.ndte, xmin=xmin, device=device)
+    s1.init_evp(a.dt)
+    s1.ctx.upload(f1)
+    s1.ctx.prep(); s1.ctx.subcycle(a.ndte); s1.ctx.finish()
+    ref = {n: np.empty_like(f1[n]) for n in names}
+    s1.ctx.download(ref)
+    st1 = s1.ctx.stats()
+    s1.close()
+    where = {b.block_id: k for k, b in enumerate(d1.local_blocks)}
+    bad, cells, nblk = {}, 0, 0
+    for r, (ids, arrs) in enumerate(parts):
+        for k, gid in enumerate(ids):
+            b = d1.local_blocks[where[gid]]
+            nblk += 1
+            for n in names:
+                if n in ("uvel", "vvel"):
+                    sl = (slice(0, b.jhi + 1), slice(0, b.ihi + 1))
+                elif n.startswith("strocn"):
+                    sl = (slice(b.jlo - 1, b.jhi), slice(b.ilo - 1, b.ihi))
+                else:
+                    sl = (slice(b.jlo - 1, b.jhi + 1), slice(b.ilo - 1, b.ihi + 1))
+                x, y = arrs[n][k][sl], ref[n][where[gid]][sl]
+                neq = ~((x == y) | (np.isnan(x) & np.isnan(y)))
+                cells += x.size
+                if neq.any():
+                    e = bad.setdefault(n, {"cells": 0, "max_abs_diff": 0.0, "ranks": []})
+                    e["cells"] += int(neq.sum())
+                    e["max_abs_diff"] = max(e["max_abs_diff"], float(np.nanmax(np.abs(x[neq] - y[neq]))))
+                    if r not in e["ranks"]:
+                        e["ranks"].append(r)
+    return {"bit_identical": not bad and nblk == len(d1.local_blocks), "against": "1-rank device run", "mismatch": bad, "fields": names,
+            "values_compared": cells, "blocks_compared": nblk, "blocks_total": len(d1.local_blocks), "subcycles": int(a.ndte),
+            "max_abs_u": float(np.abs(ref["uvel"]).max()), "one_rank_counts": [int(st1.icellt), int(st1.icellu)],
+            "what": f"every rank: state at rest -> {a.ndte} subcycles + stress folds + evp_finish on its slab (untimed, after the timed steps); "
+                    f"rank 0: the same on the whole grid in ONE context on its own GPU (the configuration the N = 1 line verifies against the "
+                    f"oracle); (u, v) on all cells of every block, sigma on physical + N/E ghost T cells, the ocean stresses on physical cells"}
 
 
 def timed_steps(ctx, ndte, steps, warmup, fence):

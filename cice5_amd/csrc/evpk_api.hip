@@ -287,6 +287,13 @@ struct evpk_ctx {
     unsigned long long *h_counts = nullptr;      // page-locked: [0] icellt, [1] icellu, [2] number of strips (as written by the copies)
     int ns_tot2_cur = 0;
     int ew = 0, ns = 0, rank = 0, nranks = 1, west = -1, east = -1, device = 0;
+    // nranks is the RING: the ranks that own block columns (create_distrb_cart gives rank r the block columns r*nbx_pp+1 ..
+    // (r+1)*nbx_pp with nbx_pp = ceil(nblocks_x / nprocs): the last ranks may get none, ice_distribution.F90:603-640).  xranks is
+    // the host's count, the size of the transport's world.  An idle rank (rank >= nranks) joins evpk_connect -- the communicator /
+    // the start-up stages of the peer-mapped transport are collective over the host's ranks -- and every other call returns at
+    // once: it has no slab, nobody's ghost zone or mirror slab holds a column of it, so it is in no exchange.
+    int xranks = 1;
+    bool idle = false;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // interior strips of k_subcycle2 while `stream` exchanges the edge columns
     hipEvent_t evI = nullptr, evX = nullptr;
@@ -339,6 +346,10 @@ struct evpk_ctx {
     bool io_sparse_now = false;      // the last evpk_upload was a sparse one: evpk_download may skip inactive tiles too
     bool tile_mode = false;          // the pairs run k_subcycle2t (one row per wave, no march): chosen by tune_R2 when strips are scarce
     int tile_force = -1;             // EVPK_TILE=0 / 1 fixes the choice
+    // k_subcycle2r: the tile kernel that rolls north through strips of any height in passes of ROLL_NW - 2 rows, without the three
+    // redundant rows per tile (round 5).  EVPK_TILE=2 forces it, EVPK_TILE=1 the five-row tiles; else tune_R2 prices both
+    bool tile_roll = false;
+    int roll_force = -1;
     unsigned int *d_tune = nullptr;
     bool use_double = false;
     unsigned char *d_flags2 = nullptr;
@@ -407,6 +418,9 @@ struct evpk_ctx {
         hipError_t _e = (call);                                                                  \
         if (_e != hipSuccess) FAIL(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
+
+// a launch with one grid layer per local block: none when a rank has no block (grid dimension 0 is not a launch)
+#define LAUNCH_BLOCKS(kern, g, b, shm, st, ...) do { if ((g).z) hipLaunchKernelGGL(kern, g, b, shm, st, __VA_ARGS__); } while (0)
 
 #define NCCLCHK(c, call)                                                                         \
     do {                                                                                         \
@@ -561,13 +575,17 @@ extern "C" int evpk_host_is_mapped(const void *ptr, size_t bytes) {
 // device-visible alias of a host array the library registered or allocated -- or the pointer itself if the caller's array
 // already lives in device memory (a host model that keeps its fields on the GPU: OpenMP target / OpenACC `use_device`
 // data) -- else nullptr: the staged path
-static void *mapped_alias(const void *host, size_t bytes) {
+static void *mapped_alias(const void *host, size_t bytes, bool *host_in_place = nullptr) {
+    if (host_in_place) *host_in_place = false;
     if (!host) return nullptr;
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         const uintptr_t lo = (uintptr_t)host, hi = lo + bytes;
         for (const PinRange &r : g_pins)
-            if (lo >= r.lo && hi <= r.hi) return r.dev + (lo - r.lo);
+            if (lo >= r.lo && hi <= r.hi) {      // (the alias of registered memory usually IS the host address: unified addressing)
+                if (host_in_place) *host_in_place = true;
+                return r.dev + (lo - r.lo);
+            }
     }
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -578,7 +596,7 @@ static void *mapped_alias(const void *host, size_t bytes) {
 // ---- host<->device transfer of one field -------------------------------------------------
 // (asynchronous on c->stream; evpk_upload / evpk_download synchronise once at their end)
 static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char *act = nullptr) {
-    if (!host) return 0;
+    if (!host || !c->nblocks) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     const double *src = (const double *)mapped_alias(host, n * sizeof(double));
     if (!src) {
@@ -587,13 +605,13 @@ static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char 
     }
     if (!c->full_cover) hipLaunchKernelGGL(k_fill_plane, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, f, 0.0);
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    hipLaunchKernelGGL(k_gather_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, f, act);
+    LAUNCH_BLOCKS(k_gather_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, f, act);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
 static int upload_m(evpk_ctx *c, const int32_t *host, int32_t *dev_plane) {
-    if (!host) return 0;
+    if (!host || !c->nblocks) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     const int32_t *src = (const int32_t *)mapped_alias(host, n * sizeof(int32_t));
     if (!src) {
@@ -602,7 +620,7 @@ static int upload_m(evpk_ctx *c, const int32_t *host, int32_t *dev_plane) {
     }
     if (!c->full_cover) HIPCHK(c, hipMemsetAsync(dev_plane, 0, mask_elems(c->s) * sizeof(int32_t), c->stream));
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    hipLaunchKernelGGL(k_gather_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, dev_plane);
+    LAUNCH_BLOCKS(k_gather_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, src, dev_plane);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -681,22 +699,23 @@ static int verify_plane(evpk_ctx *c, void *host, size_t elem, size_t n, int f, c
 
 // staged downloads start from the caller's bytes so that cells the reference leaves untouched keep their values
 static int download_f(evpk_ctx *c, double *host, int f, int mode, const unsigned char *act = nullptr) {
-    if (!host) return 0;
+    if (!host || !c->nblocks) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    if (double *dst = (double *)mapped_alias(host, n * sizeof(double))) {
-        hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, dst, mode, act);
+    bool hostmem = false;
+    if (double *dst = (double *)mapped_alias(host, n * sizeof(double), &hostmem)) {
+        LAUNCH_BLOCKS(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, dst, mode, act);
         HIPCHK(c, hipGetLastError());
-        if (c->verify_delivery && dst != host) {
+        if (c->verify_delivery && hostmem) {
             HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->stage, (int)DV_SENTINEL32, 2 * n, c->stream));
-            hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, c->stage, mode, act);
+            LAUNCH_BLOCKS(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, c->stage, mode, act);
             HIPCHK(c, hipGetLastError());
             return verify_plane(c, host, sizeof(double), n, f, "field");
         }
         return 0;
     }
     HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, c->stage, mode);
+    LAUNCH_BLOCKS(k_scatter_f, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, f, c->stage, mode);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging buffer is reused by the next field
@@ -704,22 +723,23 @@ static int download_f(evpk_ctx *c, double *host, int f, int mode, const unsigned
 }
 
 static int download_m(evpk_ctx *c, int32_t *host, const int32_t *dev_plane, int mode) {
-    if (!host) return 0;
+    if (!host || !c->nblocks) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
-    if (int32_t *dst = (int32_t *)mapped_alias(host, n * sizeof(int32_t))) {
-        hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, dst, mode);
+    bool hostmem = false;
+    if (int32_t *dst = (int32_t *)mapped_alias(host, n * sizeof(int32_t), &hostmem)) {
+        LAUNCH_BLOCKS(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, dst, mode);
         HIPCHK(c, hipGetLastError());
-        if (c->verify_delivery && dst != host) {
+        if (c->verify_delivery && hostmem) {
             HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->stage, (int)DV_SENTINEL32, n, c->stream));
-            hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, (int32_t *)c->stage, mode);
+            LAUNCH_BLOCKS(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, (int32_t *)c->stage, mode);
             HIPCHK(c, hipGetLastError());
             return verify_plane(c, host, sizeof(int32_t), n, -1, "mask");
         }
         return 0;
     }
     HIPCHK(c, hipMemcpyAsync(c->stage, host, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, (int32_t *)c->stage, mode);
+    LAUNCH_BLOCKS(k_scatter_m, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, dev_plane, (int32_t *)c->stage, mode);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(host, c->stage, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -874,8 +894,8 @@ static int xp_allgather(evpk_ctx *c, const void *src, void *dst, size_t bytes, h
     if (!st) st = c->stream;
     if (c->relay) {
         int rc = 0;
-        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->send(r, src, bytes, st);
-        for (int r = 0; r < c->nranks; r++) if (r != c->rank) rc |= c->relay->recv(r, (char *)dst + (size_t)r * bytes, bytes, st);
+        for (int r = 0; r < c->xranks; r++) if (r != c->rank) rc |= c->relay->send(r, src, bytes, st);      // (every rank of the host: start-up only)
+        for (int r = 0; r < c->xranks; r++) if (r != c->rank) rc |= c->relay->recv(r, (char *)dst + (size_t)r * bytes, bytes, st);
         if (rc) FAIL(c, "shared-memory relay: all-gather failed");
         HIPCHK(c, hipMemcpyAsync((char *)dst + (size_t)c->rank * bytes, src, bytes, hipMemcpyDeviceToDevice, st));
         return 0;
@@ -1097,6 +1117,15 @@ static int halo_stress12(evpk_ctx *c, int f0) {
 static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp, bool last2) {
     const int nband8 = (a.nband + 7) & ~7;      // the tripole top band as the first workgroups of the launch (band_pair)
     const bool xm = a.nmir > 0 && !last2 && a.xm && (c->tile_mode || c->prefetch);      // ... then the strips of the mirror slab (x-slab ranks, XM kernels)
+    if (c->tile_mode && c->tile_roll) {      // ... rolling north through a strip of R rows: min(R + 3, ROLL_NW) waves per workgroup
+        const int nw = std::min(a.R + 3, ROLL_NW);
+        const dim3 gt(((a.nstrips + 7) / 8) * 8 + nband8 + (xm ? (a.nmir + 7) & ~7 : 0)), bt(nw * 64);
+        const size_t lds = std::max((size_t)nw * ROLL_LDS_PER_WAVE, a.nband ? sizeof(double) * BAND_LDS_DOUBLES : (size_t)0);
+        if (xm)         { if (revp) hipLaunchKernelGGL((k_subcycle2r<true, false, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2r<false, false, true>), gt, bt, lds, st, a); }
+        else if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2r<true, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2r<false, true>), gt, bt, lds, st, a); }
+        else            { if (revp) hipLaunchKernelGGL((k_subcycle2r<true, false>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2r<false, false>), gt, bt, lds, st, a); }
+        return;
+    }
     if (c->tile_mode) {      // small-slab variant: one workgroup of R + 3 waves per strip, one row per wave
         const dim3 gt(((a.nstrips + 7) / 8) * 8 + nband8 + (xm ? (a.nmir + 7) & ~7 : 0)), bt((a.R + 3) * 64);
         const size_t lds = std::max((size_t)(a.R + 3) * (4096 + 5 * 1024), a.nband ? sizeof(double) * BAND_LDS_DOUBLES : (size_t)0);
@@ -1223,7 +1252,7 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
     hipDeviceProp_t prop;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-    if (c->nranks > 1) {
+    if (c->xranks > 1) {
         if (!unique_id) FAIL(c, "nranks > 1 needs a unique id (evpk_get_unique_id on rank 0, broadcast by the host)");
         char nm[EVPK_UNIQUE_ID_BYTES + 1];
         memcpy(nm, (const char *)unique_id + 8, EVPK_UNIQUE_ID_BYTES - 8);
@@ -1236,35 +1265,51 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
                                      ? (size_t)(XB_PLANES * XB_ROWS_MAX * sizeof(double2) + XB_ROWS_MAX) * ((size_t)c->w_bound + 2 * ZW_MAX) + 64 : 0);
             c->relay = new ShmRelay();
             std::string err;
-            if (c->relay->open(nm, c->rank, c->nranks, slot, err)) FAIL(c, "%s", err.c_str());
+            if (c->relay->open(nm, c->rank, c->xranks, slot, err)) FAIL(c, "%s", err.c_str());
         } else if (strncmp((const char *)unique_id, "EVPKIPC:", 8) == 0) {
             // peer-mapped transport: start-up data through the POSIX segment (stage 1: slab starts)
             c->ipc = new IpcXp();
             std::string err;
-            if (c->ipc->open(nm, c->rank, c->nranks, err)) FAIL(c, "%s", err.c_str());
+            if (c->ipc->open(nm, c->rank, c->xranks, err)) FAIL(c, "%s", err.c_str());
             c->ipc->info(c->rank)->i0 = i0;
             c->ipc->set_stage(1);
             if (!c->ipc->wait_stage(1, err)) FAIL(c, "%s", err.c_str());
         } else {
             ncclUniqueId u;
             memcpy(&u, unique_id, sizeof(u));
-            NCCLCHK(c, ncclCommInitRank(&c->comm, c->nranks, u, c->rank));
+            NCCLCHK(c, ncclCommInitRank(&c->comm, c->xranks, u, c->rank));
         }
         // every rank learns all slab starts (the tripole fold partners follow from them)
-        c->slab_i0.resize(c->nranks + 1);
+        // (collective over ALL the host's ranks; an idle rank reports nx_global + 1, the start of nothing)
+        c->slab_i0.resize(c->xranks + 1);
         if (c->ipc) {
-            for (int r = 0; r < c->nranks; r++) c->slab_i0[r] = c->ipc->info(r)->i0;
+            for (int r = 0; r < c->xranks; r++) c->slab_i0[r] = c->ipc->info(r)->i0;
         } else {
             int *d_i0 = nullptr, *d_all = nullptr;
             HIPCHK(c, hipMalloc(&d_i0, sizeof(int)));
-            HIPCHK(c, hipMalloc(&d_all, sizeof(int) * c->nranks));
+            HIPCHK(c, hipMalloc(&d_all, sizeof(int) * c->xranks));
             HIPCHK(c, hipMemcpyAsync(d_i0, &i0, sizeof(int), hipMemcpyHostToDevice, c->stream));
             if (xp_allgather(c, d_i0, d_all, sizeof(int))) return 1;
-            HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * c->nranks, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->slab_i0.data(), d_all, sizeof(int) * c->xranks, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             (void)hipFree(d_i0); (void)hipFree(d_all);
         }
+        for (int r = c->nranks; r < c->xranks; r++)
+            if (c->slab_i0[r] != s.nxg + 1) FAIL(c, "rank %d should own no block column (%d of %d ranks do) but reports columns from %d", r, c->nranks, c->xranks, c->slab_i0[r]);
+        c->slab_i0.resize(c->nranks + 1);
         c->slab_i0[c->nranks] = s.nxg + 1;
+        if (c->idle) {
+            // the start-up stages of the peer-mapped transport are waited for by every rank; this one exports and maps nothing
+            if (c->ipc) {
+                std::string err;
+                c->ipc->set_stage(2);
+                if (!c->ipc->wait_stage(2, err)) FAIL(c, "%s", err.c_str());
+                c->ipc->set_stage(3);
+                if (!c->ipc->wait_stage(3, err)) FAIL(c, "%s", err.c_str());
+            }
+            c->connected = true;
+            return 0;
+        }
         c->wmax = 0;
         for (int r = 0; r < c->nranks; r++) {
             if (c->slab_i0[r + 1] <= c->slab_i0[r]) FAIL(c, "slabs are not ordered west to east by rank");
@@ -1296,8 +1341,8 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
             x.slot[0] = 2 * std::max<size_t>(std::max<size_t>(c->cslot * sizeof(double2), fold_msg), xb_msg);
             x.slot[1] = 2 * std::max<size_t>(std::max<size_t>((size_t)c->max_nf * (s.nyl + 2) * sizeof(double), fold_msg), xb_msg);   // (zone_mirror_exchange)
             x.chan_off[0] = 0;
-            x.chan_off[1] = 2 * (size_t)c->nranks * x.slot[0];
-            x.box_bytes = x.chan_off[1] + 2 * (size_t)c->nranks * x.slot[1];
+            x.chan_off[1] = 2 * (size_t)x.nranks * x.slot[0];
+            x.box_bytes = x.chan_off[1] + 2 * (size_t)x.nranks * x.slot[1];
             std::string err;
             {   // The receive buffers are written by kernels of OTHER devices while this device holds lines of them in
                 // its L2s: uncached (fine-grained) device memory keeps that coherent without relying on the kernel-boundary
@@ -1476,7 +1521,7 @@ extern "C" int evpk_device_check(int32_t device) {
 
 static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     if (!g) FAIL(c, "geom is NULL");
-    if (g->nblocks < 1 || g->nx_block < 3 || g->ny_block < 3) FAIL(c, "bad block shape");
+    if (g->nblocks < 0 || g->nx_block < 3 || g->ny_block < 3) FAIL(c, "bad block shape");
     if (g->nranks < 1 || g->rank < 0 || g->rank >= g->nranks) FAIL(c, "bad rank/nranks");
     if (g->ns_boundary == EVPK_BND_CYCLIC) FAIL(c, "ns_boundary_type cyclic is not supported");
     int ndev = 0;
@@ -1488,7 +1533,23 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, "device is %s, libevpk is built for gfx950 only", prop.gcnArchName);
     c->device = g->device;
     c->nxb = g->nx_block; c->nyb = g->ny_block; c->nblocks = g->nblocks;
-    c->ew = g->ew_boundary; c->ns = g->ns_boundary; c->rank = g->rank; c->nranks = g->nranks;
+    c->ew = g->ew_boundary; c->ns = g->ns_boundary; c->rank = g->rank; c->xranks = g->nranks;
+    {   // the ring of ranks that own block columns (every rank computes the same from the geometry)
+        const int bsx = g->nx_block - 2, nbx = (g->nx_global - 1) / bsx + 1, nbx_pp = (nbx - 1) / g->nranks + 1;
+        c->nranks = (nbx + nbx_pp - 1) / nbx_pp;
+        if (g->rank >= c->nranks) {
+            // no block column for this rank (e.g. 5 block columns on 4 ranks: 2, 2, 1, 0): it only takes part in evpk_connect
+            if (g->nblocks != 0) FAIL(c, "rank %d owns no block column (%d block columns on %d ranks) but was given %d blocks", g->rank, nbx, g->nranks, g->nblocks);
+            c->idle = true;
+            c->s.nxg = g->nx_global; c->s.nyg = g->ny_global; c->s.i0 = g->nx_global + 1; c->s.nxl = 0;
+            c->s.nyl = g->ny_global; c->s.j0 = 1;
+            c->cslot = (size_t)25 * ZW_MAX * (c->s.nyl + 2);            // (the relay's mailboxes are sized alike on every rank)
+            c->w_bound = std::min(nbx_pp * bsx, (int)g->nx_global);
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            if (g->unique_id) return connect_impl(c, g->unique_id);
+            return 0;
+        }
+    }
 
     // slab = bounding rectangle of the local blocks
     int i0 = 1 << 30, i1 = -1, j0 = 1 << 30, j1 = -1;
@@ -1518,7 +1579,6 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     {
         const int bsx = g->nx_block - 2, nbx = (g->nx_global - 1) / bsx + 1, nbx_pp = (nbx - 1) / g->nranks + 1;
         const int r0 = g->rank * nbx_pp * bsx + 1, r1 = std::min((g->rank + 1) * nbx_pp * bsx, (int)g->nx_global);
-        if (r0 > r1) FAIL(c, "rank %d owns no block column (%d block columns on %d ranks)", g->rank, nbx, g->nranks);
         if (i0 < r0 || i1 > r1)
             FAIL(c, "%s (blocks span i %d..%d, the rank's share is %d..%d)", g->nranks > 1 ? "multi-rank runs need x-slabs of whole columns (processor_shape slenderX1)"
                                                                                         : "single-rank context: blocks outside the grid", i0, i1, r0, r1);
@@ -1542,7 +1602,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         HIPCHK(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
         // (tripole: stream2 carries the band launches and folds beside the main launch -- few, short, urgent)
         HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking,
-                                              (g->nranks > 1 && g->ns_boundary != EVPK_BND_TRIPOLE) ? least : greatest));
+                                              (c->nranks > 1 && g->ns_boundary != EVPK_BND_TRIPOLE) ? least : greatest));
     }
     {   // hand-over events between the two streams of THIS device: a device-scope release is all they need (the system-scope
         // fence of a default event costs ~4 us per hand-over; EVPK_EVENT_SCOPE=0 restores it)
@@ -1595,10 +1655,12 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         s.act_ice = c->tile_buf + 4 * nt;
         s.act_any = c->tile_buf + 5 * nt;
     }
-    HIPCHK(c, hipMalloc(&c->d_bd, sizeof(BlockDesc) * g->nblocks));
-    HIPCHK(c, hipMemcpyAsync(c->d_bd, c->bd.data(), sizeof(BlockDesc) * g->nblocks, hipMemcpyHostToDevice, c->stream));
+    // (nblocks == 0: every block of this rank's columns was eliminated as land, ice_domain.F90:387-441 -- a slab of land that
+    //  still serves its neighbours' ghost zones; nothing is gathered or scattered: the launches over blocks are skipped)
+    HIPCHK(c, hipMalloc(&c->d_bd, sizeof(BlockDesc) * std::max(1, (int)g->nblocks)));
+    if (g->nblocks) HIPCHK(c, hipMemcpyAsync(c->d_bd, c->bd.data(), sizeof(BlockDesc) * g->nblocks, hipMemcpyHostToDevice, c->stream));
     c->stage_n = (size_t)g->nblocks * g->ny_block * g->nx_block;
-    HIPCHK(c, hipMalloc(&c->stage, sizeof(double) * c->stage_n));
+    HIPCHK(c, hipMalloc(&c->stage, sizeof(double) * std::max<size_t>(c->stage_n, 1)));
 
     // strips: 63 U columns x R U rows per wave.  Small slabs get short strips so that
     // the chip still sees enough waves.
@@ -1626,7 +1688,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         HIPCHK(c, hipMalloc(&c->d_strips2, sizeof(int) * n2));
         HIPCHK(c, hipMalloc(&c->d_strips2e, sizeof(int) * n2));
         HIPCHK(c, hipMalloc(&c->d_strips2i, sizeof(int) * n2));
-        HIPCHK(c, hipMalloc(&c->d_tune, sizeof(unsigned int) * 32));
+        HIPCHK(c, hipMalloc(&c->d_tune, sizeof(unsigned int) * 64));
         c->R2 = c->R;
         c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
     }
@@ -1639,18 +1701,18 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
         c->ov_fixed = (e != nullptr);
     }
     { const char *e = getenv("EVPK_PREFETCH"); c->prefetch = !(e && atoi(e) == 0); }
-    { const char *e = getenv("EVPK_TILE"); c->tile_force = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+    { const char *e = getenv("EVPK_TILE"); c->tile_force = e ? (atoi(e) != 0 ? 1 : 0) : -1; c->roll_force = e ? (atoi(e) == 2 ? 1 : 0) : -1; }
     { const char *e = getenv("EVPK_VERIFY_DELIVERY"); c->verify_delivery = e ? atoi(e) : 0; }
     c->nsimd = 4 * prop.multiProcessorCount;
 
     // neighbours on the slab ring
     int lay[5];
-    evpk_slab_layout(g->nx_global, g->nranks, g->rank, g->ew_boundary, i0, i1, lay);
+    evpk_slab_layout(g->nx_global, c->nranks, g->rank, g->ew_boundary, i0, i1, lay);
     c->west = lay[0]; c->east = lay[1];
     {
         const char *fe = getenv("EVPK_FORCE_EXCHANGE");
         c->force_exchange = fe && atoi(fe) != 0;
-        if (fe && atoi(fe) == 2 && g->nranks == 1) {
+        if (fe && atoi(fe) == 2 && c->xranks == 1) {
             // ... and EVPK_FORCE_EXCHANGE=2 routes that self-exchange through a ONE-rank RCCL communicator: ncclSend / ncclRecv
             // to itself inside a group and ncclAllGather, with the production buffers, counts and stream (tests: the RCCL
             // call path on a one-GPU box)
@@ -1720,7 +1782,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     const char *tk = getenv("EVPK_TIME_KERNELS");
     c->time_kernels = tk ? std::max(0, std::min(atoi(tk), 2)) : 1;
     // a multi-rank context without a unique id stays unconnected until evpk_connect (two-phase start)
-    if (g->nranks == 1 || g->unique_id) return connect_impl(c, g->unique_id);
+    if (c->xranks == 1 || g->unique_id) return connect_impl(c, g->unique_id);
     return 0;
 }
 
@@ -1738,6 +1800,7 @@ extern "C" int evpk_create(const evpk_geom *g, evpk_ctx **out) {
 }
 
 extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !p) return 1;
     if (p->ndte < 1 || !(p->dt > 0.0)) FAIL(c, "bad dt/ndte");
     DevParams &d = c->p;
@@ -1756,6 +1819,7 @@ extern "C" int evpk_set_params(evpk_ctx *c, const evpk_params *p) {
 }
 
 extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state *st) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !in) return 1;
     if (!c->have_params) FAIL(c, "evpk_set_params has not been called");
     if (!c->connected) FAIL(c, "evpk_connect has not been called (multi-rank context created without a unique id)");
@@ -1818,7 +1882,7 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
                 src = c->stage_itd;
             }
             for (int n = 0; n < nc; n++)
-                hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, src + (size_t)n * nblk, (size_t)nc * nblk,
+                LAUNCH_BLOCKS(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, src + (size_t)n * nblk, (size_t)nc * nblk,
                                    c->itd + (size_t)(a * ncat + n) * np);
         }
         HIPCHK(c, hipGetLastError());
@@ -1857,25 +1921,27 @@ static int tune_R2(evpk_ctx *c) {
     const char *e = getenv("EVPK_STRIP_ROWS");
     if (e && atoi(e) > 0) {
         c->tile_mode = (c->tile_force == 1);
-        c->R2 = std::max(1, std::min(atoi(e), c->tile_mode ? 13 : 64)); c->nry2 = (c->s.nyl + 1 + c->R2 - 1) / c->R2;
+        c->tile_roll = c->tile_mode && c->roll_force == 1;
+        c->R2 = std::max(1, std::min(atoi(e), (c->tile_mode && !c->tile_roll) ? 13 : 64)); c->nry2 = (c->s.nyl + 1 + c->R2 - 1) / c->R2;
         return 0;
     }
     // icellt of this prep is not known yet on the host; use the previous one as the trigger
     if (c->tuned_icellt >= 0 && std::llabs(c->icellt - c->tuned_icellt) * 20 <= c->tuned_icellt) return 0;
     static const int cand[] = {2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48};
     static const int tcand[] = {2, 3, 4, 5, 6, 8, 10, 13};        // tile heights of k_subcycle2t: R + 3 <= 16 waves per workgroup
-    const int ncand = (int)(sizeof(cand) / sizeof(cand[0])), ntc = (int)(sizeof(tcand) / sizeof(tcand[0]));
+    static const int rcand[] = {11, 17, 23, 29, 35, 47, 59};      // strip heights of k_subcycle2r: R + 3 = ROLL_NW + k (ROLL_NW - 2), whole passes
+    const int ncand = (int)(sizeof(cand) / sizeof(cand[0])), ntc = (int)(sizeof(tcand) / sizeof(tcand[0])), nrc = (int)(sizeof(rcand) / sizeof(rcand[0]));
     Slab &s = c->s;
-    HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int) * 32, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_tune, 0, sizeof(unsigned int) * 64, c->stream));
     const int cyc = (c->ew == EVPK_BND_CYCLIC && !c->zone_mode) ? 1 : 0;
     const int G = c->zone_mode ? c->zW - 2 : 0;
-    for (int k = 0; k < ncand + ntc; k++) {
-        const int R = k < ncand ? cand[k] : tcand[k - ncand], nry = (s.nyl + 1 + R - 1) / R, tot = c->ncx2 * nry;
+    for (int k = 0; k < ncand + ntc + nrc; k++) {
+        const int R = k < ncand ? cand[k] : (k < ncand + ntc ? tcand[k - ncand] : rcand[k - ncand - ntc]), nry = (s.nyl + 1 + R - 1) / R, tot = c->ncx2 * nry;
         hipLaunchKernelGGL(k_strip_flags2, dim3((tot + 3) / 4), dim3(256), 0, c->stream, s, c->ncx2, nry, R, cyc, G,
                            (unsigned char *)nullptr, c->d_tune + k);
     }
-    unsigned int cnt[32];
-    HIPCHK(c, hipMemcpyAsync(cnt, c->d_tune, sizeof(unsigned int) * 32, hipMemcpyDeviceToHost, c->stream));
+    unsigned int cnt[64];
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_tune, sizeof(unsigned int) * 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // Both variants in microseconds per launch, from measurements on MI355X (profiles/r02_*/tile_ab.txt): one wave alone on
     // its SIMD takes ~5.3 us per march step (a dependent fp64 chain), ~7.5 us when a second wave shares the SIMD; the first
@@ -1901,9 +1967,22 @@ static int tune_R2(evpk_ctx *c) {
         const double cost = 3.6 * per_simd + 6.0;
         if (cost < bestT * 0.999) { bestT = cost; bestH = tcand[k]; }
     }
-    c->tile_mode = c->tile_force >= 0 ? (c->tile_force == 1) : (bestT < best);
+    // the rolling tile kernel: the same wave-rows without the three redundant rows per tile, passes of ROLL_NW - 2 rows behind one
+    // another in a workgroup (two waves per SIMD and pass at least), four barriers per pass
+    double bestRo = 1e300;
+    int bestRr = rcand[0];
+    for (int k = 0; k < nrc; k++) {
+        const unsigned int nt = cnt[ncand + ntc + k];
+        if (nt == 0 || rcand[k] + 3 > s.nyl + 8) continue;
+        const int passes = 1 + (rcand[k] + 3 - ROLL_NW) / (ROLL_NW - 2);
+        const double per_simd = std::max(2.0 * passes, (double)nt * (rcand[k] + 3) / (double)c->nsimd);
+        const double cost = 3.6 * per_simd + 6.0 + 0.6 * passes;
+        if (cost < bestRo * 0.999) { bestRo = cost; bestRr = rcand[k]; }
+    }
+    c->tile_mode = c->tile_force >= 0 ? (c->tile_force == 1) : (std::min(bestT, bestRo) < best);
     if (best > 1e299 && bestT > 1e299) c->tile_mode = false;
-    c->R2 = c->tile_mode ? bestH : bestR;
+    c->tile_roll = c->tile_mode && (c->roll_force >= 0 ? (c->roll_force == 1) : (bestRo < bestT)) && bestRo < 1e299;
+    c->R2 = c->tile_mode ? (c->tile_roll ? bestRr : bestH) : bestR;
     c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
     c->tuned_icellt = -2;      // set from the counts of this prep below
     return 0;
@@ -2004,6 +2083,7 @@ static int strips1(evpk_ctx *c) {
 }
 
 extern "C" int evpk_prep(evpk_ctx *c) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c) return 1;
     if (!c->uploaded) FAIL(c, "evpk_upload has not been called");
     Slab &s = c->s;
@@ -2168,6 +2248,7 @@ extern "C" int evpk_prep(evpk_ctx *c) {
 // ---- EAP (source/ice_dyn_eap.F90), SURVEY S8 row f-4 -------------------------------------------------------------------------
 extern "C" int evpk_eap_init(evpk_ctx *c, int32_t nx_yield, int32_t ny_yield, int32_t na_yield, const double *s11r, const double *s12r,
                              const double *s22r, const double *s11s, const double *s12s, const double *s22s) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !s11r || !s12r || !s22r || !s11s || !s12s || !s22s) return 1;
     if (nx_yield < 2 || ny_yield < 2 || na_yield < 2) FAIL(c, "evpk_eap_init: table extents %d x %d x %d", nx_yield, ny_yield, na_yield);
     if (!c->connected) FAIL(c, "evpk_eap_init: the context is not connected yet (evpk_connect)");
@@ -2207,6 +2288,7 @@ static double *eap_member(evpk_ctx *c, int q) {       // the planes in the order
 }
 
 extern "C" int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !st) return 1;
     if (!c->eap) FAIL(c, "evpk_eap_upload: evpk_eap_init has not been called");
     Slab &s = c->s;
@@ -2221,7 +2303,7 @@ extern "C" int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st) {
             HIPCHK(c, hipMemcpyAsync(c->stage, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
             dev = c->stage;
         }
-        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, dev, nblk, eap_member(c, q));
+        LAUNCH_BLOCKS(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, dev, nblk, eap_member(c, q));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // (the staging buffer is reused by the next array)
     }
     hipLaunchKernelGGL(k_eap_angles, grid2d(s, B2D), B2D, 0, c->stream, s, c->E);
@@ -2230,6 +2312,7 @@ extern "C" int evpk_eap_upload(evpk_ctx *c, const evpk_eap_state *st) {
 }
 
 extern "C" int evpk_eap_download(evpk_ctx *c, evpk_eap_state *st) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !st) return 1;
     if (!c->eap) FAIL(c, "evpk_eap_download: evpk_eap_init has not been called");
     Slab &s = c->s;
@@ -2241,18 +2324,19 @@ extern "C" int evpk_eap_download(evpk_ctx *c, evpk_eap_state *st) {
     for (int q = 0; q < 19; q++) {
         if (!host[q]) continue;
         // T-cell fields: the physical cells and the N / E ghost T cells the reference computes too (ice_dyn_shared.F90:528-537)
-        if (double *dst = (double *)mapped_alias(host[q], sizeof(double) * n)) {
-            hipLaunchKernelGGL(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), dst, (int)MODE_NE);
-            if (c->verify_delivery && dst != host[q]) {
+        bool hostmem = false;
+        if (double *dst = (double *)mapped_alias(host[q], sizeof(double) * n, &hostmem)) {
+            LAUNCH_BLOCKS(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), dst, (int)MODE_NE);
+            if (c->verify_delivery && hostmem) {
                 HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->stage, (int)DV_SENTINEL32, 2 * n, c->stream));
-                hipLaunchKernelGGL(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), c->stage, (int)MODE_NE);
+                LAUNCH_BLOCKS(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), c->stage, (int)MODE_NE);
                 HIPCHK(c, hipGetLastError());
                 if (verify_plane(c, host[q], sizeof(double), n, q, "eap member")) return 1;
             }
             continue;
         }
         HIPCHK(c, hipMemcpyAsync(c->stage, host[q], n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), c->stage, (int)MODE_NE);
+        LAUNCH_BLOCKS(k_scatter_mplane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)eap_member(c, q), c->stage, (int)MODE_NE);
         HIPCHK(c, hipMemcpyAsync(host[q], c->stage, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -2713,6 +2797,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
 }
 
 extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c) return 1;
     const int rc = subcycle_impl(c, nsub);
     if (rc) {   // an error return must not leave work or event waits outstanding on either stream
@@ -2724,6 +2809,7 @@ extern "C" int evpk_subcycle(evpk_ctx *c, int32_t nsub) {
 }
 
 extern "C" int evpk_finish(evpk_ctx *c) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c) return 1;
     if (!c->prepped) FAIL(c, "evpk_prep has not been called");
     Slab &s = c->s;
@@ -2745,12 +2831,14 @@ extern "C" int evpk_finish(evpk_ctx *c) {
 }
 
 extern "C" int evpk_sync(evpk_ctx *c) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c) return 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
 extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !st) return 1;
     Slab &s = c->s;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2807,6 +2895,7 @@ extern "C" int evpk_run(evpk_ctx *c, const evpk_step_in *in, evpk_state *st) {
 }
 
 extern "C" int evpk_principal_stress(evpk_ctx *c, double *sig1, double *sig2) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !sig1 || !sig2) return 1;
     if (!c->prepped) FAIL(c, "evpk_principal_stress needs the state of a finished evp on the device");
     HIPCHK(c, hipSetDevice(c->device));
@@ -2835,6 +2924,7 @@ static int halo_io_ptr(evpk_ctx *c, const double *host, size_t n, double **dev, 
 }
 
 extern "C" int evpk_halo_update(evpk_ctx *c, double *a, int32_t nz, int32_t field_loc, int32_t field_type, double fill) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !a) return 1;
     if (!c->connected) FAIL(c, "evpk_halo_update: the context is not connected yet (evpk_connect)");
     if (nz < 0 || field_loc < 1 || field_loc > 4 || field_type < 1 || field_type > 3) FAIL(c, "evpk_halo_update: bad nz / field_loc / field_type");
@@ -2852,12 +2942,12 @@ extern "C" int evpk_halo_update(evpk_ctx *c, double *a, int32_t nz, int32_t fiel
         const int nf = std::min(chunk, np - k0);
         for (int q = 0; q < nf; q++) {
             if (!c->full_cover) hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, (int)F_STATE2 + q, fill);
-            hipLaunchKernelGGL(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dev + (size_t)(k0 + q) * nblk),
+            LAUNCH_BLOCKS(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dev + (size_t)(k0 + q) * nblk),
                                (size_t)np * nblk, (int)F_STATE2 + q);
         }
         if (halo(c, F_STATE2, nf, necorner, vector, fill, -1, nullptr, false, -1, 0, loc_x)) return 1;
         for (int q = 0; q < nf; q++)
-            hipLaunchKernelGGL(k_scatter_halo, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (int)F_STATE2 + q, dev + (size_t)(k0 + q) * nblk,
+            LAUNCH_BLOCKS(k_scatter_halo, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (int)F_STATE2 + q, dev + (size_t)(k0 + q) * nblk,
                                (size_t)np * nblk, fill, c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0,
                                (field_loc == 2 || field_loc == 3) ? 1 : 0, 0, -1);
     }
@@ -2868,6 +2958,7 @@ extern "C" int evpk_halo_update(evpk_ctx *c, double *a, int32_t nz, int32_t fiel
 }
 
 extern "C" int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !a1 || !a2) return 1;
     if (!c->connected) FAIL(c, "evpk_halo_update_stress: the context is not connected yet (evpk_connect)");
     Slab &s = c->s;
@@ -2893,16 +2984,16 @@ extern "C" int evpk_halo_update_stress(evpk_ctx *c, double *a1, const double *a2
         // which ghost cells border an eliminated land block: the coverage of the slab, halo-updated like any centre scalar
         // (beyond an open / closed boundary there is no neighbour at all: 1 = leave alone)
         hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, fC, 0.0);
-        hipLaunchKernelGGL(k_cover_f, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, fC);
+        LAUNCH_BLOCKS(k_cover_f, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, fC);
         if (halo(c, fC, 1, false, false, 1.0)) return 1;
         hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, fA, 0.0);
         hipLaunchKernelGGL(k_fill_plane, grid2d(s, B2D), B2D, 0, c->stream, s, fB, 0.0);
         fcov = fC;
     }
-    hipLaunchKernelGGL(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)d1, nblk, fA);
-    hipLaunchKernelGGL(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)d2, nblk, fB);
+    LAUNCH_BLOCKS(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)d1, nblk, fA);
+    LAUNCH_BLOCKS(k_gather_fs, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)d2, nblk, fB);
     if (c->ns == EVPK_BND_TRIPOLE && halo(c, fA, 1, false, false, 0.0, fB)) return 1;
-    hipLaunchKernelGGL(k_scatter_halo, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, fA, d1, nblk, 0.0, c->ew == EVPK_BND_CYCLIC ? 1 : 0,
+    LAUNCH_BLOCKS(k_scatter_halo, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, fA, d1, nblk, 0.0, c->ew == EVPK_BND_CYCLIC ? 1 : 0,
                        c->ns == EVPK_BND_TRIPOLE ? 1 : 0, 0, 1, fcov);
     HIPCHK(c, hipGetLastError());
     if (staged1) HIPCHK(c, hipMemcpyAsync(a1, d1, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
@@ -3005,6 +3096,7 @@ extern "C" int evpk_restart_read(evpk_ctx *c, const char *path, int64_t byte_off
 
 // ---- transport_upwind (source/ice_transport_driver.F90:634-772) on the resident velocities -------------
 extern "C" int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, double *works) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !works || narr < 1) return 1;
     if (!c->uploaded) FAIL(c, "evpk_transport_upwind: no velocities on the device (run evp first)");
     if (!c->have_lengths) FAIL(c, "evpk_transport_upwind needs HTN and HTE in evpk_geom");
@@ -3039,11 +3131,11 @@ extern "C" int evpk_transport_upwind(evpk_ctx *c, double dt, int32_t narr, doubl
     }
     const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
     for (int a = 0; a < narr; a++) {       // upwind_field (:1667-1687), one array at a time through two scratch planes
-        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dev + (size_t)a * nblk),
+        LAUNCH_BLOCKS(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)(dev + (size_t)a * nblk),
                            (size_t)narr * nblk, c->tp_a);
         hipLaunchKernelGGL(k_upwind, dim3((s.nxl + 63) / 64, (s.nyl + 3) / 4), B2D, 0, c->stream, s, dt, (int)F_SIG1, (int)F_SIG2,
                            (const double *)c->tp_a, c->tp_b);
-        hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)c->tp_b,
+        LAUNCH_BLOCKS(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)c->tp_b,
                            dev + (size_t)a * nblk, (size_t)narr * nblk);
     }
     HIPCHK(c, hipGetLastError());
@@ -3059,6 +3151,7 @@ extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat,
                                            int32_t nt_Tsfc, int32_t nt_alvl, int32_t nt_apnd, int32_t nt_fbri, int32_t tr_pond_cesm,
                                            int32_t tr_pond_lvl, int32_t tr_pond_topo, double Tocnfrz, double *aice0, double *aicen, double *vicen,
                                            double *vsnon, double *trcrn) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !aice0 || !aicen || !vicen || !vsnon || ncat < 1 || ntrcr < 0 || ntrcr_dim < ntrcr || (ntrcr > 0 && (!trcrn || !trcr_depend))) return 1;
     if (!c->uploaded) FAIL(c, "evpk_transport_upwind_state: no velocities on the device (run evp first)");
     if (!c->have_lengths) FAIL(c, "evpk_transport_upwind_state needs HTN and HTE in evpk_geom");
@@ -3151,21 +3244,21 @@ extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat,
     int fcov = -1;
     if (!c->full_cover || c->nranks > 1) {     // (collective: another rank may have an eliminated block where this one has none)
         hipLaunchKernelGGL(k_fill_plane, g2, B2D, 0, c->stream, s, (int)F_WORK1, 0.0);
-        hipLaunchKernelGGL(k_cover_f, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (int)F_WORK1);
+        LAUNCH_BLOCKS(k_cover_f, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (int)F_WORK1);
         if (halo(c, F_WORK1, 1, false, false, 1.0)) return 1;
         fcov = F_WORK1;
     }
     // aice0: physical cells only (no halo update in the reference)
-    hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dev5[0], nblk, pin);
+    LAUNCH_BLOCKS(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)dev5[0], nblk, pin);
     hipLaunchKernelGGL(k_upwind, gu, B2D, 0, c->stream, s, dt, (int)F_SIG1, (int)F_SIG2, (const double *)pin, tab[0]);
-    hipLaunchKernelGGL(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)tab[0], dev5[0], nblk);
+    LAUNCH_BLOCKS(k_scatter_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, (const double *)tab[0], dev5[0], nblk);
     for (int n = 0; n < ncat; n++) {
         for (int q = 0; q < nq; q++) {
-            hipLaunchKernelGGL(k_upw_gather, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, q, pin);
+            LAUNCH_BLOCKS(k_upw_gather, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, q, pin);
             hipLaunchKernelGGL(k_upwind, gu, B2D, 0, c->stream, s, dt, (int)F_SIG1, (int)F_SIG2, (const double *)pin, tab[q]);
         }
         if (planes_halo(c, c->uw_tab, c->uw_sgn, nq, false)) return 1;             // bound_state
-        hipLaunchKernelGGL(k_upw_scatter, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, (double *const *)c->uw_tab,
+        LAUNCH_BLOCKS(k_upw_scatter, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, u, n, (double *const *)c->uw_tab,
                            c->ew == EVPK_BND_CYCLIC ? 1 : 0, c->ns == EVPK_BND_TRIPOLE ? 1 : 0, fcov);
     }
     // F_WORK1 is evp's T-grid wind plane: k_prep1a leaves tiles without input data that were inactive at the previous evp
@@ -3183,6 +3276,7 @@ extern "C" int evpk_transport_upwind_state(evpk_ctx *c, double dt, int32_t ncat,
 // ---- transport_remap's horizontal_remap (source/ice_transport_remap.F90:309-850) on the resident velocities ----
 // grid arrays the EVP path does not hold: dxu, dyu (ice_grid) and hm (the land mask as a real); block arrays, ghost cells current
 extern "C" int evpk_remap_init(evpk_ctx *c, const double *dxu, const double *dyu, const double *hm) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !dxu || !dyu || !hm) return 1;
     if (!c->connected) FAIL(c, "evpk_remap_init: the context is not connected yet (evpk_connect)");
     Slab &s = c->s;
@@ -3200,7 +3294,7 @@ extern "C" int evpk_remap_init(evpk_ctx *c, const double *dxu, const double *dyu
             HIPCHK(c, hipMemcpyAsync(c->stage, src[q], sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
             dev = c->stage;
         }
-        hipLaunchKernelGGL(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, dev, nblk, c->rm_grid + (size_t)q * np);
+        LAUNCH_BLOCKS(k_gather_plane, g, b, 0, c->stream, s, c->d_bd, c->nxb, c->nyb, dev, nblk, c->rm_grid + (size_t)q * np);
         HIPCHK(c, hipStreamSynchronize(c->stream));      // (the staging buffer is reused by the next array)
     }
     HIPCHK(c, hipGetLastError());
@@ -3474,6 +3568,7 @@ static int remap_impl(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, doub
 extern "C" int evpk_transport_remap(evpk_ctx *c, double dt, int32_t ncat, int32_t ntrace, double *mm, double *tm, const int32_t *tracer_type,
                                     const int32_t *depend, const int32_t *has_dependents, int32_t integral_order, int32_t l_dp_midpt,
                                     int32_t l_fixed_area) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     return remap_impl(c, dt, ncat, ntrace, mm, tm, tracer_type, depend, has_dependents, integral_order, l_dp_midpt, l_fixed_area, nullptr);
 }
 
@@ -3481,6 +3576,7 @@ extern "C" int evpk_transport_remap_state(evpk_ctx *c, double dt, int32_t ncat, 
                                           double rhos_lfresh, double *aice0, double *aicen, double *vicen, double *vsnon, double *trcrn,
                                           const int32_t *tracer_type, const int32_t *depend, const int32_t *has_dependents,
                                           int32_t integral_order, int32_t l_dp_midpt) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c || !aice0 || !aicen || !vicen || !vsnon || ntrcr < 0 || (ntrcr > 0 && !trcrn) || ntrcr_dim < ntrcr) return 1;
     RemapState st{};
     st.aice0 = aice0; st.aicen = aicen; st.vicen = vicen; st.vsnon = vsnon; st.trcrn = trcrn;
@@ -3489,6 +3585,7 @@ extern "C" int evpk_transport_remap_state(evpk_ctx *c, double dt, int32_t ncat, 
 }
 
 extern "C" int evpk_calibrate(evpk_ctx *c, int32_t nrep) {
+    if (c && c->idle) return 0;       // a rank without a block column: in no exchange, nothing to compute
     if (!c) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     for (int n = 0; n < nrep; n++)   // WORK1/WORK2 pair plane: scratch, rewritten by the next prep/finish
@@ -3529,11 +3626,11 @@ extern "C" int evpk_get_stats(evpk_ctx *c, evpk_stats *o) {
     o->strip_rows = c->R; o->strip_rows2 = c->use_double ? c->R2 : 0; o->nstrips2 = c->use_double ? c->nstrips2 : 0;
     o->zone_cols = c->zone_mode ? c->zW : 0; o->zone_exchanges = c->zone_exchanges; o->zone_bytes = c->zone_bytes;
     o->overlap_split = !c->ov_fixed ? -1 : (c->overlap ? 1 : 0);
-    o->tile_kernel = (c->use_double && c->tile_mode) ? 1 : 0;
+    o->tile_kernel = (c->use_double && c->tile_mode) ? (c->tile_roll ? 2 : 1) : 0;
     o->kernel_timed = c->kernel_timed; o->kernel2_timed = c->kernel2_timed;
     o->bound_ms = c->bound_ms; o->bound_updates = c->bound_updates;
     o->compact_metrics = c->compact ? 1 : 0;
-    o->transport = c->ipc ? EVPK_XP_IPC : c->relay ? EVPK_XP_SHM_RELAY : (c->nranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
+    o->transport = c->ipc ? EVPK_XP_IPC : c->relay ? EVPK_XP_SHM_RELAY : (c->xranks > 1 ? EVPK_XP_RCCL : (c->comm ? EVPK_XP_RCCL : (c->force_exchange ? EVPK_XP_SELF : EVPK_XP_NONE)));
     o->band_row_exchanges = c->xb_swaps;
     o->kernel3_ms = c->kernel3_ms; o->kernel3_launches = c->triple_launches; o->kernel3_timed = c->kernel3_timed;
     o->strip_rows3 = c->use_triple ? c->R3 : 0; o->nstrips3 = c->use_triple ? c->nstrips3 : 0;

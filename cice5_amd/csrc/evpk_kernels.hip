@@ -2909,6 +2909,243 @@ template __global__ void k_subcycle2t<true, true>(SubArgs);
 template __global__ void k_subcycle2t<false, false, true>(SubArgs);
 template __global__ void k_subcycle2t<true, false, true>(SubArgs);
 
+// ------------------------------------------------------------------------------------
+// k_subcycle2r (round 5): k_subcycle2t that ROLLS north -- the one-row-per-wave tile WITHOUT its redundant rows.
+// A tile of k_subcycle2t computes T1 on R + 3 rows, U1 on R + 2, T2 on R + 1 for R owned rows (8, 7, 6 for 5: 1.4 x the stress
+// work), and the small slabs it serves are bound by fp64 issue, not by latency (450 x 2700: 17 K wave-rows x 1 450 instructions on
+// 1 024 SIMDs = the 42 us the launch takes).  Here a workgroup of NW waves takes a strip of R >= NW - 3 rows and works through it
+// in PASSES of the same four phases; a row that could not finish in a pass because the row above it had not started (the top
+// row has T1 only, the one below it lacks U2) is KEPT by its wave -- sigma after the first subcycle, the metrics, its str terms
+// stay in that wave's registers -- and finishes in the next pass beside NW - 2 new rows:
+//   pass p:  A  T1 of the new rows s .. t            (s = 0, t = NW - 1 in the first pass; then s = t' + 1, t = s + NW - 3)
+//            B  U1 of rows s - 1 .. t - 1            (needs T1 of the row above: LDS)
+//            C  T2 of rows s - 1 .. t - 1            (needs U1 of the row below: LDS; sigma stored)
+//            D  U2 of rows s - 2 .. t - 2            (needs T2 of the row above: LDS; (u, v) stored)
+//            rows <= t - 2 are complete: their waves take rows + NW
+// Row q of the strip lives on wave q mod NW for all four phases, so the LDS rows of k_subcycle2t serve unchanged (the row above /
+// below is the next / previous wave, cyclically).  Every pass runs NW - 2 rows through every phase: R + 3 T1 rows, R + 2 U1, R + 1
+// T2 per R owned rows of a STRIP instead of a five-row tile.  Four barriers per pass (the fourth keeps a fast wave's next T1 terms
+// out of the LDS row a slow wave's U2 still reads).  Same strips, lists, column / ghost-zone / band (jmax) rules and arithmetic as
+// k_subcycle2t and k_subcycle2p: bit-identical.
+// ------------------------------------------------------------------------------------
+constexpr int ROLL_NW = 8;                           // waves per workgroup (two workgroups per CU)
+constexpr size_t ROLL_LDS_PER_WAVE = 10 * 1024;      // X 2 KiB + Y 1 + Z 3 + Q 4
+template <bool REVP, bool LAST2, bool XM = false>
+__global__ __launch_bounds__(512, 4) void k_subcycle2r(SubArgs a) {
+    extern __shared__ double tl[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NW = blockDim.x >> 6;
+    const int nband8 = (a.nband + 7) & ~7;
+    if ((int)blockIdx.x < nband8) {                   // tripole top band of this pair (one rank; the launch asks for the LDS)
+        if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, tl);
+        return;
+    }
+    const int nmir8 = XM ? ((a.nmir + 7) & ~7) : 0;
+    const bool mir = XM && (int)blockIdx.x - nband8 < nmir8;
+    const SlabV s = slab_view(a, mir);
+    const int jmax = mir ? a.mjmax : a.jmax;
+    int wg, st;
+    if (mir) {
+        wg = (int)blockIdx.x - nband8;
+        if (wg >= a.nmir) return;                     // (the whole workgroup leaves: no barrier is left waiting)
+        st = wg;
+    } else {
+        const int bidx = (int)blockIdx.x - nband8 - nmir8;
+        const int ns = pair_nstrips(a);
+        const int chunk = a.nsdev ? (ns + 7) >> 3 : ((int)gridDim.x - nband8 - nmir8) >> 3;
+        wg = (bidx & 7) * chunk + (bidx >> 3);
+        if ((bidx >> 3) >= chunk || wg >= ns) return; // (likewise)
+        st = __builtin_amdgcn_readfirstlane(a.strips[wg]);
+        if (w == 0) dbg_stamp(a, wg, 0);
+    }
+    const int cx = st % a.ncx, ry = st / a.ncx;
+    const int R = a.R, nxl = s.nxl, nyl = s.nyl;
+    const int G = a.G;
+    const int c = cx * STRIP2_W + lane - G;
+    const int jb = ry * R + 1;
+    const bool cyc = a.wrap != 0;
+    int ci = c, cm1 = c - 1;
+    bool okc, okm;
+    if (cyc) {
+        ci = (c - 1) % nxl; if (ci < 0) ci += nxl; ci += 1;
+        cm1 = (c - 2) % nxl; if (cm1 < 0) cm1 += nxl; cm1 += 1;
+        okc = okm = true;
+    } else {
+        okc = (c >= -1 - G && c <= nxl + 2 + G);
+        okm = (cm1 >= -1 - G && cm1 <= nxl + 2 + G);
+        if (!okc) ci = 0;
+        if (!okm) cm1 = 0;
+    }
+    const bool tcol = cyc ? true : (c >= -G && c <= nxl + 2 + G);
+    const bool ucol = cyc ? true : (c >= -G && c <= nxl + 1 + G);
+    const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);
+
+    const size_t pp = (size_t)s.pitch * 16;
+    const size_t rowb = (size_t)s.rstride * 16;
+    const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
+    const int SR = a.sr, SW = a.sw;
+    char *const base = reinterpret_cast<char *>(s.F);
+    // LDS per wave: X 4 x 64 doubles (the str terms the row below needs), Y 2 x 64 ((u, v) after the first subcycle; the column to the
+    // west is the lane below), Z 6 x 64 (what the row's own later phases need of its stresses: nothing of a row is carried in
+    // registers from one stress to the next except sigma and the metrics), Q 4 x 64 double2 (the stepu inputs): 10 KiB, two
+    // workgroups of eight waves per CU
+    double *const X = tl, *const Y = tl + (size_t)NW * 256, *const Z = tl + (size_t)NW * 384;
+    const int wup = (w + 1 == NW) ? 0 : w + 1, wdn = (w == 0) ? NW - 1 : w - 1;      // the waves of the rows above / below mine
+    double *const Xw = X + (size_t)w * 256 + lane, *const Yw = Y + (size_t)w * 128 + lane, *const Zw = Z + (size_t)w * 384 + lane;
+    const double *const Xn = X + (size_t)wup * 256 + lane, *const Ys = Y + (size_t)wdn * 128 + lane;
+    double2 *const Qw = reinterpret_cast<double2 *>(tl + (size_t)NW * 768) + (size_t)w * 4 * 64;
+    auto load_q = [&](UStat &q, double &ui, double &vi, const char *rbq) {
+        const double2 va = Qw[0 * 64 + lane], oc = Qw[1 * 64 + lane], fo = Qw[2 * 64 + lane], mf = Qw[3 * 64 + lane];
+        q = UStat{va.x, va.y, oc.x, oc.y, fo.x, fo.y, mf.x, mf.y};
+        ui = 0.0; vi = 0.0;
+        if (REVP) { const double2 iv = ldp(rbq, pp, F_UVEL_INIT, lo); ui = iv.x; vi = iv.y; }      // (revised EVP only: read where it is used)
+    };
+
+    const int qmax = R + 2;                           // rows q = 0 .. R + 2 of the strip: r = jb - 1 + q
+    int q = w;                                        // the row this wave holds
+    int sp = 0, tp = (NW - 1 < qmax) ? NW - 1 : qmax; // T1 runs on rows sp .. tp in this pass
+    // the state of the held row (lives across passes while the row waits for the rows above it)
+    unsigned char m = 0;
+    double un_c = 0.0, vn_c = 0.0;
+    bool t1act = false, rowok = false;
+    Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    char *rb = base;
+    int r = jb - 1 + q;
+
+    for (;;) {
+        // ---------------- phase A: T1 of the new rows ----------------
+        if (q >= sp && q <= tp) {
+            r = jb - 1 + q;
+            rowok = (r >= 0 && r <= nyl + 1);
+            rb = base + (size_t)(rowok ? r : 0) * rowb;
+            m = 0;
+            un_c = 0.0; vn_c = 0.0;
+            double un_m = 0.0, vn_m = 0.0, uo_c = 0.0, vo_c = 0.0, uo_m = 0.0, vo_m = 0.0;
+            if (rowok) {
+                if (okc) {
+                    m = s.cmask[(size_t)r * s.pitch + C0 + ci];
+                    const double2 v = ldp(rb, pp, SR + S_U, lo); un_c = v.x; vn_c = v.y;
+                }
+                if (okm) { const double2 v = ldp(rb, pp, SR + S_U, lom); un_m = v.x; vn_m = v.y; }
+            }
+            if (r - 1 >= 0 && r - 1 <= nyl + 1) {
+                const char *rs = base + (size_t)(r - 1) * rowb;
+                if (okc) { const double2 v = ldp(rs, pp, SR + S_U, lo); uo_c = v.x; vo_c = v.y; }
+                if (okm) { const double2 v = ldp(rs, pp, SR + S_U, lom); uo_m = v.x; vo_m = v.y; }
+            }
+            t1act = tcol && (m & CM_T) != 0;
+            const bool u1need = (q <= qmax - 1) && ucol && (m & CM_U) != 0 && r >= 1 && r <= nyl;
+            Str8 o1{0, 0, 0, 0, 0, 0, 0, 0};
+            g1 = Sig{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (__any(t1act)) {
+                if (t1act) { mt = load_tmet(rb, pp, lo); g1 = load_sig(rb, pp, SR, lo); }
+            }
+            if (__any(u1need)) {      // the stepu inputs of this row serve both subcycles: global -> LDS directly
+                if (u1need) {
+                    lds_dma16(rb + (size_t)(F_VRELC >> 1) * pp + lo, Qw + 0 * 64);
+                    lds_dma16(rb + (size_t)(F_UOCN >> 1) * pp + lo, Qw + 1 * 64);
+                    lds_dma16(rb + (size_t)(F_FORCEX >> 1) * pp + lo, Qw + 2 * 64);
+                    lds_dma16(rb + (size_t)(F_UMASSDTI >> 1) * pp + lo, Qw + 3 * 64);
+                }
+            }
+            if (__any(t1act)) {
+                if (t1act) {
+                    Diag dg;
+                    stress_cell<false>(mt, un_c, un_m, uo_c, uo_m, vn_c, vn_m, vo_c, vo_m, a.ecci, a.arlx1i, a.denom1, 0.0, g1, o1, dg);
+                }
+            }
+            const double a2n = shfl_dn1(o1.s2), a7n = shfl_dn1(o1.s7), a4n = shfl_dn1(o1.s4), a8n = shfl_dn1(o1.s8);
+            Xw[0] = o1.s3; Xw[64] = o1.s6; Xw[128] = a4n; Xw[192] = a8n;
+            Zw[0] = o1.s1 + a2n; Zw[64] = o1.s5; Zw[128] = a7n;      // (for this row's U1, this pass or the next)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (this wave's LDS-DMA has landed)
+        }
+        __syncthreads();
+
+        // ---------------- phase B: U1 of rows sp - 1 .. tp - 1 ----------------
+        const bool doB = (q >= sp - 1 && q <= tp - 1 && q >= 0);
+        if (doB) {
+            const bool u1act = ucol && (m & CM_U) != 0 && r >= 1 && r <= nyl;
+            double u1_c = un_c, v1_c = vn_c;          // an inactive cell keeps its velocity
+            if (__any(u1act)) {
+                if (u1act) {
+                    double sxi, syi;
+                    UStat q1; double ui1, vi1;
+                    load_q(q1, ui1, vi1, rb);
+                    stepu_cell(q1, un_c, vn_c, ui1, vi1, (Zw[0] + Xn[0]) + Xn[128], ((Zw[64] + Xn[64]) + Zw[128]) + Xn[192],
+                               a.brlx, a.revp, a.cosw, a.sinw, u1_c, v1_c, sxi, syi);
+                }
+            }
+            Yw[0] = u1_c; Yw[64] = v1_c;              // (phases C and D of this row read them back from here; (c-1, r) is the lane below)
+        }
+        __syncthreads();
+
+        // ---------------- phase C: T2 of rows sp - 1 .. tp - 1 (from row 1 of the strip) ----------------
+        const bool doC = doB && q >= 1;
+        if (doC) {
+            const bool t2act = t1act && lane >= 1;
+            Str8 o2{0, 0, 0, 0, 0, 0, 0, 0};
+            if (__any(t2act)) {
+                if (t2act) {
+                    Sig g2 = g1;
+                    Diag dg;
+                    double tarear = 0.0;
+                    if (LAST2) tarear = *reinterpret_cast<const double *>(rb + (size_t)(F_TAREAR >> 1) * pp + lo + (F_TAREAR & 1) * 8);
+                    stress_cell<LAST2>(mt, Yw[0], Yw[-1], Ys[0], Ys[-1], Yw[64], Yw[63], Ys[64], Ys[63], a.ecci, a.arlx1i, a.denom1, tarear, g2, o2, dg);
+                    if (own && q <= R && r <= jmax) {
+                        store_sig(rb, pp, SW, lo, g2);
+                        if (cyc && c == 1) store_sig(rb, pp, SW, lo + (unsigned)nxl * 16u, g2);     // east ghost T column = image of column 1
+                        if (LAST2) {
+                            st1(rb, pp, F_DIVU, lo, dg.divu);       st1(rb, pp, F_RDGCONV, lo, dg.rdg_conv);
+                            st1(rb, pp, F_RDGSHEAR, lo, dg.rdg_shear); st1(rb, pp, F_SHEAR, lo, dg.shear);
+                            st1(rb, pp, F_PRSSIG, lo, dg.prs);
+                        }
+                    }
+                }
+            }
+            const double b2n = shfl_dn1(o2.s2), b7n = shfl_dn1(o2.s7), b4n = shfl_dn1(o2.s4), b8n = shfl_dn1(o2.s8);
+            Xw[0] = o2.s3; Xw[64] = o2.s6; Xw[128] = b4n; Xw[192] = b8n;
+            Zw[192] = o2.s1 + b2n; Zw[256] = o2.s5; Zw[320] = b7n;      // (for this row's U2)
+        }
+        __syncthreads();
+
+        // ---------------- phase D: U2 of rows sp - 2 .. tp - 2 (rows 1 .. R of the strip) ----------------
+        const bool doD = (q >= sp - 2 && q <= tp - 2 && q >= 1 && q <= R);
+        if (doD) {
+            const bool u2act = own && (m & CM_U) != 0 && r <= nyl && r <= jmax;
+            if (__any(u2act)) {
+                if (u2act) {
+                    double un, vn, sxi, syi;
+                    UStat q1; double ui1, vi1;
+                    load_q(q1, ui1, vi1, rb);
+                    stepu_cell(q1, Yw[0], Yw[64], ui1, vi1, (Zw[192] + Xn[0]) + Xn[128], ((Zw[256] + Xn[64]) + Zw[320]) + Xn[192],
+                               a.brlx, a.revp, a.cosw, a.sinw, un, vn, sxi, syi);
+                    stp(rb, pp, SW + S_U, lo, un, vn);
+                    if (cyc) {
+                        if (c == 1) stp(rb, pp, SW + S_U, lo + (unsigned)nxl * 16u, un, vn);
+                        if (c == nxl) stp(rb, pp, SW + S_U, lo - (unsigned)nxl * 16u, un, vn);
+                    }
+                    if (LAST2) { st1(rb, pp, F_STRINTX, lo, sxi); st1(rb, pp, F_STRINTY, lo, syi); }
+                }
+            }
+        }
+        if (tp >= qmax) break;                        // the strip's last row has had its T1: everything finished in this pass
+        if (q <= tp - 2) q += NW;                     // my row is complete: the next one of this wave
+        sp = tp + 1;
+        tp = (sp + NW - 3 < qmax) ? sp + NW - 3 : qmax;
+        __syncthreads();                              // (a slow wave's phase D still reads the LDS row a new T1 is about to rewrite)
+    }
+    if (w == 0 && !mir) dbg_stamp(a, wg, 1);
+}
+
+template __global__ void k_subcycle2r<false, false>(SubArgs);
+template __global__ void k_subcycle2r<true, false>(SubArgs);
+template __global__ void k_subcycle2r<false, true>(SubArgs);
+template __global__ void k_subcycle2r<true, true>(SubArgs);
+template __global__ void k_subcycle2r<false, false, true>(SubArgs);
+template __global__ void k_subcycle2r<true, false, true>(SubArgs);
+
 // strip activity for k_subcycle2: any active T / U cell in the window the strip touches
 // (columns c0..c0+63 wrapped, rows jb-1..jb+R+1)
 // cells: if given, also counts the active T / U cells on the physical cells each strip owns (icellt, icellu of the rank)

@@ -48,6 +48,7 @@ class SynthCase:
     ndte: int = 120
     lat_s: float = -78.0
     lat_n: float = 88.0
+    land_band: tuple = ()      # (i_lo, i_hi): these global columns are land on every row (a rank whose block columns are all eliminated)
 
     # ---- index helpers -------------------------------------------------------------
     def _wrap(self, I):
@@ -108,6 +109,8 @@ class SynthCase:
             f = (np.sin(3.0 * x + 1.3) * np.cos(2.0 * y) + 0.6 * np.sin(5.0 * x - 0.7 + 2.0 * np.sin(3.0 * y))
                  + 0.4 * np.cos(7.0 * y + x))
             ocean = ocean & (f < 0.55)
+        if self.land_band:
+            ocean = ocean & ~((Iw >= self.land_band[0]) & (Iw <= self.land_band[1]))
         return ocean.astype(np.float64)
 
     def uvm(self, I, J):

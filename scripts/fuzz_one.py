@@ -15,7 +15,7 @@ from tests import util, test_fuzz_gpu as t
 def run(seed, quiet):
     k = t._config(seed)
     k["sparse"] = k["sparse"] and k["resident"] and not k["ugrid_wind"]
-    k["pin"] = k["pin"] or k["sparse"]
+    k["pin"] = k["pin"] or k["sparse"] or bool(os.environ.get("EVPK_FUZZ_PIN"))      # (EVPK_FUZZ_PIN=1: every draw through page-locked arrays)
     for name in MODE_KEYS:                      # (pytest's monkeypatch restores the environment between draws)
         os.environ.pop(name, None)
     MODE_KEYS.clear()

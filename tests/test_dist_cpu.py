@@ -78,7 +78,7 @@ def _fold_rows(nx, B1, B2, necorner, sgn):
     return sgn * sym[src], sgn * B1[src]
 
 
-def _worker(rank, world, port, ns, q):
+def _worker(rank, world, port, ns, q, bsx=12):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -90,10 +90,24 @@ def _worker(rank, world, port, ns, q):
         from tests import util
 
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        nx, ny, bsx, bsy, ndte = 48, 40, 12, 10, 30
+        nx, ny, bsy, ndte = 48, 40, 10, 30
         case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[ns], land="continents")
         d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=ns)
         f = synth.make_block_fields(case, d)
+        # the ring is made of the ranks that own block columns: create_distrb_cart deals ceil(nbx / nprocs) columns to a rank and
+        # the last ranks may get none (ice_distribution.F90:603-640) -- such a rank joins the start (process group here, evpk_connect
+        # in the library) and the global reductions of the host, and no exchange
+        nbx = nx // bsx
+        nact = -(-nbx // (-(-nbx // world)))
+        if rank >= nact:
+            assert d.nblocks == 0 and d.slab() == (1, 0, 1, 0)
+            tot = torch.tensor([0, 0], dtype=torch.int64)
+            dist.all_reduce(tot)
+            dist.barrier()
+            dist.destroy_process_group()
+            q.put((rank, []))
+            return
+        world_host, world = world, nact
         i0, i1, j0, j1 = d.slab()
         assert (j0, j1) == (1, ny) and i1 - i0 + 1 == nx // world
         lay = evpk.slab_layout(nx, world, rank, d.ew_boundary, i0, i1)
@@ -195,13 +209,14 @@ def _worker(rank, world, port, ns, q):
         q.put((rank, ["EXC " + traceback.format_exc()]))
 
 
-@pytest.mark.parametrize("ns", ["open", "tripole"])
-def test_two_rank_slab_exchange_gloo(ns):
+@pytest.mark.parametrize("ns,world,bsx", [("open", 2, 12), ("tripole", 2, 12), ("open", 3, 24), ("tripole", 3, 24)])
+def test_two_rank_slab_exchange_gloo(ns, world, bsx):
+    """world = 3 with two block columns: ranks 0 and 1 form the ring, rank 2 owns nothing and only joins the collectives"""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ns, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ns, q, bsx)) for r in range(world)]
     for p in procs:
         p.start()
     res = []

@@ -50,7 +50,7 @@ def _config(seed):
 def test_random_configuration(seed, monkeypatch):
     k = _config(seed)
     k["sparse"] = k["sparse"] and k["resident"] and not k["ugrid_wind"]      # sparse transfers: resident state, page-locked arrays
-    k["pin"] = k["pin"] or k["sparse"]
+    k["pin"] = k["pin"] or k["sparse"] or bool(os.environ.get("EVPK_FUZZ_PIN"))      # (EVPK_FUZZ_PIN=1: every draw through page-locked arrays)
     for name, v in k["mode"].items():
         monkeypatch.setenv(name, v)
     case = synth.SynthCase(nx=k["nx"], ny=k["ny"], ns_boundary=C.BND_NAMES[k["ns"]], ew_boundary=C.BND_NAMES[k["ew"]],

@@ -60,8 +60,14 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q, uidq=None):
         from oracle import orc
         from tests import util
 
-        case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[ns], land="continents")
-        d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=ns)
+        band = tuple(int(v) for v in env["TEST_LAND_BAND"].split(",")) if env.get("TEST_LAND_BAND") else ()
+        case = synth.SynthCase(nx=nx, ny=ny, ns_boundary=C.BND_NAMES[ns], land="continents", land_band=band)
+        work = None
+        if band:       # land-block elimination (ice_domain.F90:387-441): blocks without an ocean cell are dropped, on every rank alike
+            dfull = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns)
+            tm = synth.make_block_fields(case, dfull)["tmask"]
+            work = [int(tm[n, b.jlo - 1:b.jhi, b.ilo - 1:b.ihi].any()) for n, b in enumerate(dfull.local_blocks)]
+        d = blocks.create_distrb_cart(nx, ny, bsx, bsy, nprocs=world, rank=rank, ns_boundary_type=ns, work_per_block=work)
         f = synth.make_block_fields(case, d)
         xmin = synth.global_min_dx(case)
         xp = env.get("TEST_XP", "shm")
@@ -83,7 +89,7 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q, uidq=None):
         else:
             s.init_evp(3600.0)
         # reference: whole domain, same block size, in this process
-        d1 = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns)
+        d1 = blocks.create_distrb_cart(nx, ny, bsx, bsy, ns_boundary_type=ns, work_per_block=work)
         f1 = synth.make_block_fields(case, d1)
         if eap:
             synth.add_eap_state(f1)
@@ -212,7 +218,7 @@ def _worker(rank, world, tag, ns, nx, ny, bsx, bsy, ndte, env, q, uidq=None):
         s.close()
         if int(st.transport) != {"shm": 2, "ipc": 3, "rccl": 1}[xp]:
             bad.append(("transport", int(st.transport)))
-        q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()), time.time() - t0,
+        q.put((rank, bad[:6], int(st.icellu), int(st.kernel2_launches), float(np.abs(f["uvel"]).max()) if d.nblocks else 0.0, time.time() - t0,
                int(st.zone_cols), int(st.zone_exchanges), int(st.band_row_exchanges)))
     except Exception:
         q.put((rank, ["EXC " + traceback.format_exc()], 0, 0, 0.0, 0.0, 0, 0, 0))
@@ -454,3 +460,50 @@ def test_random_unequal_slabs_on_a_tripole_grid(seed):
     xp = XPS[seed % 2]
     print("config:", world, nx, ny, bsx, bsy, ndte, env, xp)
     _run(world, "tripole", nx, ny, bsx, bsy, ndte=ndte, env=env, xp=xp)
+
+
+@pytest.mark.parametrize("ns,world", [("tripole", 2), ("open", 3)])
+def test_bench_line_of_a_multirank_run_verifies_itself(ns, world):
+    """`python bench.py --gpus N`: after the timed steps every rank runs one untimed evp from rest and rank 0 compares all of it,
+    bit for bit, with a ONE-rank device run of the whole grid on its own GPU (`verify.against = "1-rank device run"`); what the
+    line says about its ranks (`devices`, `rccl_ranks`) and the comparison are part of the exit code.  Here: the ranks share the
+    box's GPU(s) as the other cases of this file do, over the peer-mapped transport."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    shared = not _per_rank(world)
+    if shared:
+        env["EVPK_FORCE_DEVICE"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--transport", "ipc",
+                        "--grid", "720x400", "--xblocks", "6", "--yblocks", "2", "--ndte", "24", "--ns", ns, "--dt", "1800"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    line = json.loads(lines[-1])
+    v = line["verify"]
+    assert r.returncode == 0, (r.returncode, line.get("checks"), v)
+    assert v["bit_identical"] is True and v["against"] == "1-rank device run" and v["blocks_compared"] == 12 and v["max_abs_u"] > 1e-3
+    assert v["values_compared"] > 18 * 720 * 400
+    assert line["checks"] == {"devices": True, "rccl_ranks": True, "bit_identical": True}
+    assert line["n_gpus"] == world and line["config"]["devices"] == (1 if shared else world) and line["value"] > 0
+
+
+@pytest.mark.parametrize("xp", XPS)
+@pytest.mark.parametrize("ns,world,nx,bsx", [("open", 4, 200, 40), ("tripole", 4, 200, 40), ("open", 3, 128, 64), ("tripole", 5, 240, 80)])
+def test_ranks_without_a_block_column(ns, world, nx, bsx, xp):
+    """create_distrb_cart deals ceil(nblocks_x / nprocs) block columns to a rank and the last ranks may get none (ice_distribution.F90:
+    603-640: 5 columns on 4 ranks = 2, 2, 1, 0; 2 on 3 = 1, 1, 0; 3 on 5 = 1, 1, 1, 0, 0) and carries on.  Such a rank takes part in
+    evpk_connect and returns from everything else; the others form the ring (uneven slabs; the tripole fold from a virtual mirror slab)."""
+    res = _run(world, ns, nx, 64, bsx, 32, ndte=14, xp=xp)
+    idle = [r for r in res if r[2] == 0 and r[3] == 0]
+    nbx = nx // bsx
+    assert len(idle) == world - -(-nbx // (-(-nbx // world)))
+
+
+@pytest.mark.parametrize("ns", ["open", "tripole"])
+def test_a_rank_whose_blocks_are_all_eliminated_land(ns):
+    """three ranks, three block columns, the middle one land on every row: rank 1 is handed NO block (land-block elimination,
+    ice_domain.F90:387-441) but its columns exist -- its slab is land, its neighbours' ghost zones read land from it, it takes part in
+    every exchange of the ring; also with the transports of rows f-3 (bound_state next to the eliminated blocks)"""
+    res = _run(3, ns, 120, 64, 40, 32, ndte=14, env={"TEST_LAND_BAND": "41,80", "TEST_UPWIND_STATE": "1"}, xp="ipc")
+    assert sorted(r[2] > 0 for r in res) == [False, True, True]

@@ -351,6 +351,51 @@ def test_tile_kernel_equals_oracle(H, monkeypatch):
         s.close()
 
 
+@pytest.mark.parametrize("R", ["", "5", "6", "11", "12", "23", "40"])
+def test_rolling_tile_kernel_equals_oracle(R, monkeypatch):
+    """k_subcycle2r (EVPK_TILE=2; round 5): the one-row-per-wave tile that rolls north through a strip of R rows in passes of six, the
+    rows that cannot finish in a pass kept by their waves -- no redundant rows per tile.  Against the oracle on the cases of the tile
+    kernel's test: R = one pass (5), one row into the second pass (6), whole passes (11, 23), ragged last passes (12, 40), tuned ('')."""
+    monkeypatch.setenv("EVPK_TILE", "2")
+    if R:
+        monkeypatch.setenv("EVPK_STRIP_ROWS", R)
+    seen = []
+    real = dyn.EvpDynamics.close
+
+    def close(self):
+        seen.append(int(self.ctx.stats().tile_kernel))
+        real(self)
+
+    monkeypatch.setattr(dyn.EvpDynamics, "close", close)
+    _both(320, 384, 320, 384, ndte=30)                                         # config 2
+    _both(360, 300, 15, 300, land="continents", ndte=24, ncalls=2)             # config 3
+    _both(100, 116, 32, 40, land="continents", ndte=31)                        # padded blocks, odd ndte
+    _both(130, 60, 130, 60, ice="full", ndte=18, revised_evp=True)
+    _both(48, 40, 12, 10, ns="tripole", land="continents", ndte=40, ncalls=2)
+    _both(260, 140, 65, 35, ns="tripole", ice="full", ndte=14)
+    assert seen and all(v == 2 for v in seen), seen
+    if R in ("", "11", "40"):
+        for m in ("1", "4"):
+            monkeypatch.setenv("EVPK_FORCE_EXCHANGE", "1")
+            monkeypatch.setenv("EVPK_ZONE_M", m)
+            _both(200, 96, 50, 48, land="continents", ndte=31, ncalls=2)
+            _both(200, 96, 50, 48, ns="tripole", ice="full", ndte=12)
+        monkeypatch.delenv("EVPK_FORCE_EXCHANGE")
+        monkeypatch.delenv("EVPK_ZONE_M")
+        case = synth.SynthCase(nx=64, ny=48, ew_boundary=C.BND_OPEN)               # open E-W boundary, subcycles in pieces
+        d = blocks.create_distrb_cart(64, 48, 16, 16, ew_boundary_type="open")
+        f = synth.make_block_fields(case, d)
+        xmin = synth.global_min_dx(case)
+        fo, fg = util.clone(f), util.clone(f)
+        orc.evp(d, orc.make_params(3600.0, 30, xmin), fo)
+        s = dyn.EvpDynamics(d, fg, ndte=30, xmin=xmin)
+        s.init_evp(3600.0)
+        s.ctx.upload(fg); s.ctx.prep(); s.ctx.subcycle(7); s.ctx.subcycle(12); s.ctx.subcycle(11); s.ctx.finish(); s.ctx.download(fg)
+        assert s.ctx.stats().tile_kernel == 2
+        assert not util.compare(d, fg, fo)
+        s.close()
+
+
 def test_tile_kernel_is_chosen_for_small_slabs_only():
     """the tuner takes the tile variant where strips are scarce (gx1, 360x300) and the marching one on the headline grid"""
     for (nx, ny, bsx, bsy, want) in ((320, 384, 320, 384, 1), (360, 300, 60, 300, 1)):
@@ -358,7 +403,7 @@ def test_tile_kernel_is_chosen_for_small_slabs_only():
         s = dyn.EvpDynamics(d, f, ndte=4, xmin=synth.global_min_dx(case))
         s.init_evp(3600.0)
         s.evp(3600.0)
-        assert s.ctx.stats().tile_kernel == want, (nx, ny)
+        assert (s.ctx.stats().tile_kernel > 0) == bool(want), (nx, ny)
         s.close()
 
 
