@@ -2120,6 +2120,17 @@ __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
                                      (__attribute__((address_space(3))) void *)lds_slot, 16, 0, 0);
 }
 
+// The same with the address as the hardware takes it -- a scalar base (SGPR pair) + a 32-bit lane offset -- and the LDS byte address of
+// the slot in M0: one instruction.  The builtin form above costs three VALU instructions per transfer in k_subcycle2p (a 64-bit vector
+// add for the address, a vector add and a v_readfirstlane for M0: 54 of the 1 393 vector instructions of a march step, round 5).  M0 is
+// written behind the compiler's back: use it only on paths where every LDS-DMA goes through this function.
+// (the slot's offset is an immediate of the s_add that makes M0: one SGPR -- the wave's LDS base -- serves all slots; with a value per
+// slot the compiler hoisted eighteen of them out of the march, spilled them and read them back with v_readlane)
+template <int SLOT>
+__device__ __forceinline__ void lds_dma16s(const char *sbase, unsigned voff, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_base), "n"(SLOT * 1024) : "memory", "scc");
+}
+
 // CM (compact metrics): slots 2,3 hold (HTN,HTE) at columns c and c-1 instead of the four metric pairs in slots 2..5
 // what the pair kernels use of a slab, in scalar registers: the rank's own (kernel arguments) or, for the workgroups that advance
 // the mirror slab (XM), the struct in device memory -- read lane-uniformly so that it stays in SGPRs
@@ -2148,7 +2159,9 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     __shared__ double2 smem[4 * PF_SLOTS * 64];
     static_assert(sizeof(double2) * 4 * PF_SLOTS * 64 >= sizeof(double) * BAND_LDS_DOUBLES, "the band workgroups use the same LDS");
     const int lane = threadIdx.x & 63;
-    double2 *const L = smem + (size_t)(threadIdx.x >> 6) * PF_SLOTS * 64;     // this wave's slots
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double2 *const L = smem + (size_t)wv * PF_SLOTS * 64;     // this wave's slots
+    const unsigned Lb = (unsigned)(size_t)(__attribute__((address_space(3))) void *)L;      // ... as an LDS byte address (uniform)
     const int nband8 = (a.nband + 7) & ~7;
     if ((int)blockIdx.x < nband8) {              // tripole top band of this pair of subcycles (one rank): see band_pair
         if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, reinterpret_cast<double *>(smem));
@@ -2199,6 +2212,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);
 
     const size_t pp = (size_t)s.pitch * 16;
+    const unsigned pp32 = (unsigned)s.pitch * 16u;       // (a row of all planes is < 4 GiB: plane offsets inside a row fit 32 bits)
     const size_t rowb = (size_t)s.rstride * 16;
     const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
     const int SR = a.sr;
@@ -2211,26 +2225,28 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     auto issue = [&](int rn, unsigned char mt_, unsigned char mu_, unsigned char mt_next) {
         if (rowok(rn)) {
             const char *rbn = base + (size_t)rn * rowb;
-            if (okc) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lo, L + 0 * 64);
-            if (okm) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lom, L + 1 * 64);
+            if (okc) lds_dma16s<0>(rbn + (size_t)((unsigned)((SR + S_U) >> 1) * pp32), lo, Lb);
+            if (okm) lds_dma16s<1>(rbn + (size_t)((unsigned)((SR + S_U) >> 1) * pp32), lom, Lb);
             const bool ta = tcol && (mt_ & CM_T) != 0;
             if (CM) {   // HTN of this row is also the south length of the next row: fetch it if either is active
                 const bool th = tcol && ((mt_ | mt_next) & CM_T) != 0;
-                if (__any(th)) { if (th) lds_dma16(rbn + (size_t)(F_HTN >> 1) * pp + lo, L + 2 * 64); }
+                if (__any(th)) { if (th) lds_dma16s<2>(rbn + (size_t)((unsigned)(F_HTN >> 1) * pp32), lo, Lb); }
             }
             if (__any(ta)) {
                 if (ta) {
                     if (CM) {
-                        if (okm) lds_dma16(rbn + (size_t)(F_HTN >> 1) * pp + lom, L + 3 * 64);
+                        if (okm) lds_dma16s<3>(rbn + (size_t)((unsigned)(F_HTN >> 1) * pp32), lom, Lb);
                     } else {
-                        lds_dma16(rbn + (size_t)(F_CXP >> 1) * pp + lo, L + 2 * 64);
-                        lds_dma16(rbn + (size_t)(F_CXM >> 1) * pp + lo, L + 3 * 64);
-                        lds_dma16(rbn + (size_t)(F_DXT >> 1) * pp + lo, L + 4 * 64);
-                        lds_dma16(rbn + (size_t)(F_DXHY >> 1) * pp + lo, L + 5 * 64);
+                        lds_dma16s<2>(rbn + (size_t)((unsigned)(F_CXP >> 1) * pp32), lo, Lb);
+                        lds_dma16s<3>(rbn + (size_t)((unsigned)(F_CXM >> 1) * pp32), lo, Lb);
+                        lds_dma16s<4>(rbn + (size_t)((unsigned)(F_DXT >> 1) * pp32), lo, Lb);
+                        lds_dma16s<5>(rbn + (size_t)((unsigned)(F_DXHY >> 1) * pp32), lo, Lb);
                     }
-                    lds_dma16(rbn + (size_t)(F_TINYAREA >> 1) * pp + lo, L + 6 * 64);
-#pragma unroll
-                    for (int q = 0; q < 6; q++) lds_dma16(rbn + (size_t)((SR + S_SP) / 2 + q) * pp + lo, L + (7 + q) * 64);
+                    lds_dma16s<6>(rbn + (size_t)((unsigned)(F_TINYAREA >> 1) * pp32), lo, Lb);
+                    const unsigned sp0 = (unsigned)((SR + S_SP) / 2) * pp32;
+                    lds_dma16s<7>(rbn + (size_t)sp0, lo, Lb);               lds_dma16s<8>(rbn + (size_t)(sp0 + pp32), lo, Lb);
+                    lds_dma16s<9>(rbn + (size_t)(sp0 + 2 * pp32), lo, Lb);  lds_dma16s<10>(rbn + (size_t)(sp0 + 3 * pp32), lo, Lb);
+                    lds_dma16s<11>(rbn + (size_t)(sp0 + 4 * pp32), lo, Lb); lds_dma16s<12>(rbn + (size_t)(sp0 + 5 * pp32), lo, Lb);
                 }
             }
         }
@@ -2239,11 +2255,11 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         if (__any(ua)) {
             if (ua) {
                 const char *rbu = base + (size_t)ru_ * rowb;
-                lds_dma16(rbu + (size_t)(F_VRELC >> 1) * pp + lo, L + 13 * 64);
-                lds_dma16(rbu + (size_t)(F_UOCN >> 1) * pp + lo, L + 14 * 64);
-                lds_dma16(rbu + (size_t)(F_FORCEX >> 1) * pp + lo, L + 15 * 64);
-                lds_dma16(rbu + (size_t)(F_UMASSDTI >> 1) * pp + lo, L + 16 * 64);
-                if (REVP) lds_dma16(rbu + (size_t)(F_UVEL_INIT >> 1) * pp + lo, L + 17 * 64);
+                lds_dma16s<13>(rbu + (size_t)((unsigned)(F_VRELC >> 1) * pp32), lo, Lb);
+                lds_dma16s<14>(rbu + (size_t)((unsigned)(F_UOCN >> 1) * pp32), lo, Lb);
+                lds_dma16s<15>(rbu + (size_t)((unsigned)(F_FORCEX >> 1) * pp32), lo, Lb);
+                lds_dma16s<16>(rbu + (size_t)((unsigned)(F_UMASSDTI >> 1) * pp32), lo, Lb);
+                if (REVP) lds_dma16s<17>(rbu + (size_t)((unsigned)(F_UVEL_INIT >> 1) * pp32), lo, Lb);
             }
         }
     };
@@ -2304,8 +2320,10 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
             if (okm) { const double2 q = L[1 * 64 + lane]; un_m = q.x; vn_m = q.y; }
         }
         const bool t1act = tcol && (m & CM_T) != 0;
-        Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // (sigma, the metrics and the stepu inputs of a lane are read only where that lane's own cell is active -- the same test on the
+        //  same mask byte, also a step later as g1p / mtp / qp: lanes without get no zeros, 30 vector moves per step less, round 5)
+        Sig g1;
+        TMet mt;
         double hn = 0.0, he = 0.0, hw = 0.0, tiny_c = 0.0, str_c = 0.0;
         if (CM) {
             const bool th = tcol && ((m | m_n1) & CM_T) != 0 && rok;
@@ -2328,7 +2346,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
             }
         }
         const bool u1act = (t >= 1) && ucol && (mp & CM_U) != 0 && (r - 1 >= 1) && (r - 1 <= nyl);
-        UStat q1{0, 0, 0, 0, 0, 0, 0, 0};
+        UStat q1;
         double ui1 = 0.0, vi1 = 0.0;
         if (__any(u1act)) {
             if (u1act) {
@@ -2775,6 +2793,7 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);
 
     const size_t pp = (size_t)s.pitch * 16;
+    const unsigned pp32 = (unsigned)s.pitch * 16u;
     const size_t rowb = (size_t)s.rstride * 16;
     const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
     const int SR = a.sr, SW = a.sw;
@@ -2784,6 +2803,7 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     // the stepu inputs of this wave's row (four pairs + uvel_init): global -> LDS directly, no registers while the two stresses
     // are computed (round 4: the kernel is compiled for 128 VGPRs and spilled 8 with them live from the start)
     double2 *const Qw = reinterpret_cast<double2 *>(tl + (size_t)NW * 512) + (size_t)w * 5 * 64;
+    const unsigned Qb = (unsigned)(size_t)(__attribute__((address_space(3))) void *)Qw;      // (LDS byte address, uniform: w is)
 
     const int r = jb - 1 + w;                         // this wave's row
     const bool rowok = (r >= 0 && r <= nyl + 1);
@@ -2815,11 +2835,11 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     }
     if (__any(u1act)) {      // the stepu inputs of this row serve both subcycles; fetched beside the T planes, into the LDS
         if (u1act) {
-            lds_dma16(rb + (size_t)(F_VRELC >> 1) * pp + lo, Qw + 0 * 64);
-            lds_dma16(rb + (size_t)(F_UOCN >> 1) * pp + lo, Qw + 1 * 64);
-            lds_dma16(rb + (size_t)(F_FORCEX >> 1) * pp + lo, Qw + 2 * 64);
-            lds_dma16(rb + (size_t)(F_UMASSDTI >> 1) * pp + lo, Qw + 3 * 64);
-            if (REVP) lds_dma16(rb + (size_t)(F_UVEL_INIT >> 1) * pp + lo, Qw + 4 * 64);
+            lds_dma16s<0>(rb + (size_t)((unsigned)(F_VRELC >> 1) * pp32), lo, Qb);
+            lds_dma16s<1>(rb + (size_t)((unsigned)(F_UOCN >> 1) * pp32), lo, Qb);
+            lds_dma16s<2>(rb + (size_t)((unsigned)(F_FORCEX >> 1) * pp32), lo, Qb);
+            lds_dma16s<3>(rb + (size_t)((unsigned)(F_UMASSDTI >> 1) * pp32), lo, Qb);
+            if (REVP) lds_dma16s<4>(rb + (size_t)((unsigned)(F_UVEL_INIT >> 1) * pp32), lo, Qb);
         }
     }
     auto load_q = [&](UStat &q, double &ui, double &vi) {
@@ -2981,7 +3001,7 @@ __global__ __launch_bounds__(512, 4) void k_subcycle2r(SubArgs a) {
     const bool ucol = cyc ? true : (c >= -G && c <= nxl + 1 + G);
     const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);
 
-    const size_t pp = (size_t)s.pitch * 16;
+    const size_t pp0 = (size_t)s.pitch * 16;
     const size_t rowb = (size_t)s.rstride * 16;
     const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
     const int SR = a.sr, SW = a.sw;
@@ -2995,39 +3015,39 @@ __global__ __launch_bounds__(512, 4) void k_subcycle2r(SubArgs a) {
     double *const Xw = X + (size_t)w * 256 + lane, *const Yw = Y + (size_t)w * 128 + lane, *const Zw = Z + (size_t)w * 384 + lane;
     const double *const Xn = X + (size_t)wup * 256 + lane, *const Ys = Y + (size_t)wdn * 128 + lane;
     double2 *const Qw = reinterpret_cast<double2 *>(tl + (size_t)NW * 768) + (size_t)w * 4 * 64;
+    const unsigned Qb = (unsigned)(size_t)(__attribute__((address_space(3))) void *)Qw;      // (LDS byte address, uniform: w is)
     auto load_q = [&](UStat &q, double &ui, double &vi, const char *rbq) {
         const double2 va = Qw[0 * 64 + lane], oc = Qw[1 * 64 + lane], fo = Qw[2 * 64 + lane], mf = Qw[3 * 64 + lane];
         q = UStat{va.x, va.y, oc.x, oc.y, fo.x, fo.y, mf.x, mf.y};
         ui = 0.0; vi = 0.0;
-        if (REVP) { const double2 iv = ldp(rbq, pp, F_UVEL_INIT, lo); ui = iv.x; vi = iv.y; }      // (revised EVP only: read where it is used)
+        if (REVP) { const double2 iv = ldp(rbq, pp0, F_UVEL_INIT, lo); ui = iv.x; vi = iv.y; }      // (revised EVP only: read where it is used)
     };
 
     const int qmax = R + 2;                           // rows q = 0 .. R + 2 of the strip: r = jb - 1 + q
     int q = w;                                        // the row this wave holds
     int sp = 0, tp = (NW - 1 < qmax) ? NW - 1 : qmax; // T1 runs on rows sp .. tp in this pass
     // the state of the held row (lives across passes while the row waits for the rows above it)
-    unsigned char m = 0;
-    double un_c = 0.0, vn_c = 0.0;
-    bool t1act = false, rowok = false;
-    Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    char *rb = base;
-    int r = jb - 1 + q;
+    Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // sigma after the first subcycle: the one thing a row keeps in registers between its stresses
 
     for (;;) {
+        // (the plane offsets inside a row -- some twenty products with the pitch -- are made again in every pass: as loop invariants the
+        //  compiler kept them all in scalar registers, spilled 34 of those and fetched them back lane by lane)
+        size_t pp = pp0;
+        asm volatile("" : "+s"(pp));
+        const unsigned pp32 = (unsigned)pp;
         // ---------------- phase A: T1 of the new rows ----------------
+        // (the mask byte, the old velocity and the metrics of the held row are re-read where a later phase needs them -- they come out
+        //  of the L2 -- instead of living in registers across the passes: the register budget is the tile kernel's)
+        const int r = jb - 1 + q;
+        const bool rowok = (r >= 0 && r <= nyl + 1);
+        char *const rb = base + (size_t)(rowok ? r : 0) * rowb;
+        const unsigned char m = (rowok && okc && q <= qmax) ? s.cmask[(size_t)r * s.pitch + C0 + ci] : (unsigned char)0;
+        const bool t1act = tcol && (m & CM_T) != 0;
         if (q >= sp && q <= tp) {
-            r = jb - 1 + q;
-            rowok = (r >= 0 && r <= nyl + 1);
-            rb = base + (size_t)(rowok ? r : 0) * rowb;
-            m = 0;
-            un_c = 0.0; vn_c = 0.0;
+            double un_c = 0.0, vn_c = 0.0;
             double un_m = 0.0, vn_m = 0.0, uo_c = 0.0, vo_c = 0.0, uo_m = 0.0, vo_m = 0.0;
             if (rowok) {
-                if (okc) {
-                    m = s.cmask[(size_t)r * s.pitch + C0 + ci];
-                    const double2 v = ldp(rb, pp, SR + S_U, lo); un_c = v.x; vn_c = v.y;
-                }
+                if (okc) { const double2 v = ldp(rb, pp, SR + S_U, lo); un_c = v.x; vn_c = v.y; }
                 if (okm) { const double2 v = ldp(rb, pp, SR + S_U, lom); un_m = v.x; vn_m = v.y; }
             }
             if (r - 1 >= 0 && r - 1 <= nyl + 1) {
@@ -3035,19 +3055,19 @@ __global__ __launch_bounds__(512, 4) void k_subcycle2r(SubArgs a) {
                 if (okc) { const double2 v = ldp(rs, pp, SR + S_U, lo); uo_c = v.x; vo_c = v.y; }
                 if (okm) { const double2 v = ldp(rs, pp, SR + S_U, lom); uo_m = v.x; vo_m = v.y; }
             }
-            t1act = tcol && (m & CM_T) != 0;
             const bool u1need = (q <= qmax - 1) && ucol && (m & CM_U) != 0 && r >= 1 && r <= nyl;
             Str8 o1{0, 0, 0, 0, 0, 0, 0, 0};
             g1 = Sig{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (__any(t1act)) {
                 if (t1act) { mt = load_tmet(rb, pp, lo); g1 = load_sig(rb, pp, SR, lo); }
             }
             if (__any(u1need)) {      // the stepu inputs of this row serve both subcycles: global -> LDS directly
                 if (u1need) {
-                    lds_dma16(rb + (size_t)(F_VRELC >> 1) * pp + lo, Qw + 0 * 64);
-                    lds_dma16(rb + (size_t)(F_UOCN >> 1) * pp + lo, Qw + 1 * 64);
-                    lds_dma16(rb + (size_t)(F_FORCEX >> 1) * pp + lo, Qw + 2 * 64);
-                    lds_dma16(rb + (size_t)(F_UMASSDTI >> 1) * pp + lo, Qw + 3 * 64);
+                    lds_dma16s<0>(rb + (size_t)((unsigned)(F_VRELC >> 1) * pp32), lo, Qb);
+                    lds_dma16s<1>(rb + (size_t)((unsigned)(F_UOCN >> 1) * pp32), lo, Qb);
+                    lds_dma16s<2>(rb + (size_t)((unsigned)(F_FORCEX >> 1) * pp32), lo, Qb);
+                    lds_dma16s<3>(rb + (size_t)((unsigned)(F_UMASSDTI >> 1) * pp32), lo, Qb);
                 }
             }
             if (__any(t1act)) {
@@ -3067,6 +3087,8 @@ __global__ __launch_bounds__(512, 4) void k_subcycle2r(SubArgs a) {
         const bool doB = (q >= sp - 1 && q <= tp - 1 && q >= 0);
         if (doB) {
             const bool u1act = ucol && (m & CM_U) != 0 && r >= 1 && r <= nyl;
+            double un_c = 0.0, vn_c = 0.0;
+            if (rowok && okc) { const double2 v = ldp(rb, pp, SR + S_U, lo); un_c = v.x; vn_c = v.y; }
             double u1_c = un_c, v1_c = vn_c;          // an inactive cell keeps its velocity
             if (__any(u1act)) {
                 if (u1act) {
@@ -3088,6 +3110,7 @@ __global__ __launch_bounds__(512, 4) void k_subcycle2r(SubArgs a) {
             Str8 o2{0, 0, 0, 0, 0, 0, 0, 0};
             if (__any(t2act)) {
                 if (t2act) {
+                    const TMet mt = load_tmet(rb, pp, lo);
                     Sig g2 = g1;
                     Diag dg;
                     double tarear = 0.0;

@@ -37,6 +37,7 @@
       private
       public :: evp
       public :: evpk_npinned      ! (diagnostic) host arrays page-locked for in-place PCIe transfers
+      public :: evpk_pin_module_arrays
       public :: evpk_resident_state, evpk_state_changed_on_host, evpk_device_strength
       public :: evpk_bound_seconds, evpk_loop_seconds
       public :: evpk_download_all, evpk_sparse_io
@@ -66,6 +67,16 @@
 
       integer (kind=int_kind) :: evpk_npinned = 0
 
+      ! .true. (default): the host model's module arrays (ice_state / ice_flux: static, they cannot be moved) are registered with
+      ! evpk_pin_host at the first call and then read / written IN PLACE over PCIe.  The registration is hardened (MADV_NOHUGEPAGE,
+      ! mlock) but hipHostRegister mirrors the pages through MMU notifiers, it does not hard-pin them; the environment variable
+      ! EVPK_VERIFY_DELIVERY=1 makes the library deliver every in-place plane a second time through its staging buffer and compare
+      ! (evpk_stats%delivery_checked / delivery_bad).  .false.: nothing of the host model is registered -- every array moves
+      ! through the library's staging copies (hipMemcpy: slower, no dependence on the pages staying where they are).
+      ! The arrays this module itself owns (tmass, aiu, umass, icetmask, the int32 mask copies) live on memory the DRIVER
+      ! allocates and pins (evpk_host_alloc = hipHostMalloc) either way.
+      logical (kind=log_kind) :: evpk_pin_module_arrays = .true.
+
       ! uvel, vvel, the twelve stresses and iceumask are written by evp only (ice_dyn_evp.F90:336-410; readers:
       ! transport, history, restart), so after the first call the copy on the device is current and only the inputs
       ! are uploaded.  Whoever writes them elsewhere (a restart read after the first step, ...) sets
@@ -77,15 +88,15 @@
       logical (kind=log_kind) :: ctx_ready = .false.
 
       ! LOGICAL arrays are not C-interoperable: int32 copies (ice_kinds_mod.F90:20-21)
-      integer (c_int32_t), dimension(:,:,:), allocatable, target :: &
-         tmask_i, umask_i, iceumask_i
+      integer (c_int32_t), dimension(:,:,:), pointer :: &
+         tmask_i => null(), umask_i => null(), iceumask_i => null()     ! (evpk_host_alloc: page-locked by the driver)
 
       integer (c_int32_t), dimension(:), allocatable, target :: &
          g_ilo, g_ihi, g_jlo, g_jhi, g_iglob, g_jglob
 
       ! outputs of the library that the reference keeps as locals of evp (allocated once: page-locked below)
-      real (kind=dbl_kind), dimension (:,:,:), allocatable, target :: &
-         tmass, aiu, umass
+      real (kind=dbl_kind), dimension (:,:,:), pointer :: &
+         tmass => null(), aiu => null(), umass => null()                ! (evpk_host_alloc)
       integer (kind=int_kind), dimension (:,:,:), allocatable, target :: &
          icetmask
 
@@ -133,9 +144,7 @@
          g_jglob(iblk) = this_block%j_glob(this_block%jlo)
       enddo
 
-      allocate (tmask_i   (nx_block,ny_block,max_blocks), &
-                umask_i   (nx_block,ny_block,max_blocks), &
-                iceumask_i(nx_block,ny_block,max_blocks))
+      call host_alloc_i4 (tmask_i);  call host_alloc_i4 (umask_i);  call host_alloc_i4 (iceumask_i)
       tmask_i = 0
       umask_i = 0
       where (tmask) tmask_i = 1
@@ -189,6 +198,40 @@
       real (kind=dbl_kind), dimension (*), intent(in), target :: a
       loc_r8 = c_loc(a)
       end function loc_r8
+
+      ! a (nx_block, ny_block, max_blocks) array of this module on memory the driver allocates and pins (evpk_host_alloc); ordinary
+      ! memory if the library refuses (it is then moved through the staging copies)
+      subroutine host_alloc_r8 (a)
+      use ice_blocks, only: nx_block, ny_block
+      use ice_domain_size, only: max_blocks
+      real (kind=dbl_kind), dimension (:,:,:), pointer :: a
+      type (c_ptr) :: p
+      integer (c_size_t) :: n
+      n = int(nx_block, c_size_t) * int(ny_block, c_size_t) * int(max(max_blocks, 1), c_size_t) * 8_c_size_t
+      if (evpk_host_alloc (n, p) == 0) then
+         call c_f_pointer (p, a, (/ nx_block, ny_block, max_blocks /))
+         evpk_npinned = evpk_npinned + 1
+      else
+         allocate (a(nx_block,ny_block,max_blocks))
+      endif
+      a = 0.0_dbl_kind
+      end subroutine host_alloc_r8
+
+      subroutine host_alloc_i4 (a)
+      use ice_blocks, only: nx_block, ny_block
+      use ice_domain_size, only: max_blocks
+      integer (c_int32_t), dimension (:,:,:), pointer :: a
+      type (c_ptr) :: p
+      integer (c_size_t) :: n
+      n = int(nx_block, c_size_t) * int(ny_block, c_size_t) * int(max(max_blocks, 1), c_size_t) * 4_c_size_t
+      if (evpk_host_alloc (n, p) == 0) then
+         call c_f_pointer (p, a, (/ nx_block, ny_block, max_blocks /))
+         evpk_npinned = evpk_npinned + 1
+      else
+         allocate (a(nx_block,ny_block,max_blocks))
+      endif
+      a = 0
+      end subroutine host_alloc_i4
 
       subroutine pin_r8 (a, n)
       real (kind=dbl_kind), dimension (*), intent(in), target :: a
@@ -267,9 +310,10 @@
 
       if (.not. ctx_ready) call evpk_setup
 
-      if (.not. allocated(tmass)) &
-         allocate (tmass(nx_block,ny_block,max_blocks), aiu(nx_block,ny_block,max_blocks), &
-                   umass(nx_block,ny_block,max_blocks), icetmask(nx_block,ny_block,max_blocks))
+      if (.not. associated(tmass)) then
+         call host_alloc_r8 (tmass);  call host_alloc_r8 (aiu);  call host_alloc_r8 (umass)
+         allocate (icetmask(nx_block,ny_block,max_blocks))
+      endif
 
       !-----------------------------------------------------------------
       ! scalars of set_evp_parameters (ice_dyn_shared.F90:185-259), read
@@ -392,7 +436,7 @@
       st%uvel_init = loc_r8(uvel_init);  st%vvel_init = loc_r8(vvel_init)
       st%icetmask = c_null_ptr
 
-      if (.not. pinned) then
+      if (.not. pinned .and. evpk_pin_module_arrays) then
          ! The arrays handed over live as long as the run: page-lock them once, so that the library moves them in
          ! place over PCIe instead of through staging copies (a refusal leaves the staged path in use).
          call pin_r8 (aice, size(aice));  call pin_r8 (vice, size(vice));  call pin_r8 (vsno, size(vsno));  call pin_r8 (aice_init, size(aice_init))
@@ -407,9 +451,8 @@
          call pin_r8 (prs_sig, size(prs_sig));  call pin_r8 (strintx, size(strintx));  call pin_r8 (strinty, size(strinty))
          call pin_r8 (strocnx, size(strocnx));  call pin_r8 (strocny, size(strocny));  call pin_r8 (strocnxT, size(strocnxT));  call pin_r8 (strocnyT, size(strocnyT))
          call pin_r8 (strairx, size(strairx));  call pin_r8 (strairy, size(strairy));  call pin_r8 (strtltx, size(strtltx));  call pin_r8 (strtlty, size(strtlty))
-         call pin_r8 (fm, size(fm));  call pin_r8 (tmass, size(tmass));  call pin_r8 (aiu, size(aiu));  call pin_r8 (umass, size(umass))
+         call pin_r8 (fm, size(fm))
          call pin_r8 (uvel_init, size(uvel_init));  call pin_r8 (vvel_init, size(vvel_init))
-         rc = evpk_pin_host (c_loc(iceumask_i), int(size(iceumask_i), c_size_t) * 4_c_size_t)
          pinned = .true.
       endif
 

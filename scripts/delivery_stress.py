@@ -111,10 +111,11 @@ while True:
         del tmp, ok
         fg = util.clone(fg)
         pin = False
-    s = dyn.EvpDynamics(d, fg, ndte=a.ndte, xmin=xmin, pin_host=pin)
-    s.init_evp(3600.0)
-    ref = util.clone(fg)                      # plain arrays: the staged delivery lands here
+    s = None
     try:
+        s = dyn.EvpDynamics(d, fg, ndte=a.ndte, xmin=xmin, pin_host=pin)
+        s.init_evp(3600.0)
+        ref = util.clone(fg)                  # plain arrays: the staged delivery lands here
         s.evp(3600.0)
         s.ctx.download(ref)
     except evpk.EvpkError as e:
@@ -124,7 +125,8 @@ while True:
         nstale_err += 1
         if nstale_err <= 3:
             print(f"stale registration, iter {it}: {str(e)[:200]}", flush=True)
-        s.close()
+        if s is not None:
+            s.close()
         continue
     if a.oracle:
         from oracle import orc

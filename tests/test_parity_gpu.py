@@ -1031,7 +1031,7 @@ def test_evp_after_transport_upwind_state_on_a_resident_context(keep_cover, monk
     keep_cover: the same with the restoring fill switched off (EVPK_DEBUG_KEEP_COVER) must DIFFER -- the case bites."""
     if keep_cover:
         monkeypatch.setenv("EVPK_DEBUG_KEEP_COVER", "1")
-    nx, ny, bsx, bsy = 120, 96, 6, 4
+    nx, ny, bsx, bsy = 320, 96, 8, 4                      # (five tile columns: tiles on the slab's rim are never skipped)
     case = synth.SynthCase(nx=nx, ny=ny, land="continents", ice="full")
     full = blocks.create_distrb_cart(nx, ny, bsx, bsy)
     ff = synth.make_block_fields(case, full)
