@@ -516,12 +516,14 @@ def evp_incl_pcie(d, f, a, xmin, device):
     """whole evp(dt) calls INCLUDING the PCIe transfers, as a host model sees them (never `value`):
     pageable / page_locked: evpk_run, every array up and down every call (27 + 36 arrays of 78 MB);
     resident_every_step_outputs: the state stays on the device, inputs up, the eight arrays a host model reads every step
-    down (uvel, vvel, rdg_conv, rdg_shear, divu, shear, strocnxT/yT), page-locked; + sparse: only the tiles with ice move."""
+    down (uvel, vvel, rdg_conv, rdg_shear, divu, shear, strocnxT/yT), page-locked; + sparse: only the tiles with ice move
+    (evpk_params.sparse_io = 1: aice, vice, vsno whole; sparse2 = 2: aice alone whole)."""
     from cice5_amd import dyn
     res = {}
     for key, kw in (("pageable_host_arrays", dict(pin_host=False)), ("page_locked_host_arrays", dict(pin_host=True)),
                     ("resident_every_step_outputs", dict(pin_host=True, resident=True, outputs=dyn.EVERY_STEP_OUTPUTS)),
-                    ("resident_every_step_outputs_sparse", dict(pin_host=True, resident=True, outputs=dyn.EVERY_STEP_OUTPUTS, sparse_io=True))):
+                    ("resident_every_step_outputs_sparse", dict(pin_host=True, resident=True, outputs=dyn.EVERY_STEP_OUTPUTS, sparse_io=1)),
+                    ("resident_every_step_outputs_sparse2", dict(pin_host=True, resident=True, outputs=dyn.EVERY_STEP_OUTPUTS, sparse_io=2))):
         s = dyn.EvpDynamics(d, f, ndte=a.ndte, xmin=xmin, device=device, **kw)
         s.init_evp(a.dt)
         s.evp(a.dt)

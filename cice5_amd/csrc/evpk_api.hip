@@ -398,6 +398,7 @@ struct evpk_ctx {
     // EVPK_VERIFY_DELIVERY (diagnostic): every plane a download writes IN PLACE into a caller's page-locked array is delivered a second
     // time through the staging buffer + hipMemcpy and the two are compared on the host, value for value.  1: a difference is an error
     // that names plane, block, cell and 4-KiB page; 2: the caller's array is repaired from the staged copy and the event counted
+    bool xfer_fused = true;        // EVPK_XFER_FUSED=0: one gather / scatter launch per array instead of up to XFER_MAX arrays per launch
     int verify_delivery = 0;
     long long dv_checked = 0, dv_bad = 0, dv_planes = 0;
     std::vector<double> dv_host;
@@ -595,7 +596,8 @@ static void *mapped_alias(const void *host, size_t bytes, bool *host_in_place = 
 
 // ---- host<->device transfer of one field -------------------------------------------------
 // (asynchronous on c->stream; evpk_upload / evpk_download synchronise once at their end)
-static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char *act = nullptr) {
+static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char *act = nullptr);
+static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char *act) {
     if (!host || !c->nblocks) return 0;
     const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
     const double *src = (const double *)mapped_alias(host, n * sizeof(double));
@@ -695,6 +697,38 @@ static int verify_plane(evpk_ctx *c, void *host, size_t elem, size_t n, int f, c
     }
     c->err = msg;
     return 1;
+}
+
+// ---- several arrays per launch (k_gather_multi / k_scatter_multi): arrays the device sees in place are collected, the others go one
+// by one through the staging buffer as before.  EVPK_XFER_FUSED=0: one launch per array everywhere
+struct XferBatch {
+    evpk_ctx *c;
+    XferList L{};
+    const unsigned char *act = nullptr;
+    bool up = true;
+    int flush() {
+        if (!L.n) return 0;
+        const dim3 b(64), g((c->nxb + 63) / 64, c->nyb, c->nblocks);
+        if (up) LAUNCH_BLOCKS(k_gather_multi, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, L, act);
+        else LAUNCH_BLOCKS(k_scatter_multi, g, b, 0, c->stream, c->s, c->d_bd, c->nxb, c->nyb, L, act);
+        L.n = 0;
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+};
+static int upload_f(evpk_ctx *c, const double *host, int f, const unsigned char *act);
+// upload of one field through the batch when its array is visible to the device, else at once through the staging buffer
+static int upload_fb(XferBatch &B, const double *host, int f, const unsigned char *act) {
+    evpk_ctx *c = B.c;
+    if (!host || !c->nblocks) return 0;
+    const size_t n = (size_t)c->nblocks * c->nyb * c->nxb;
+    double *src = c->xfer_fused ? (double *)mapped_alias(host, n * sizeof(double)) : nullptr;
+    if (!src) return upload_f(c, host, f, act);
+    if (B.L.n && (B.act != act || B.L.n == XFER_MAX)) { if (B.flush()) return 1; }
+    if (!c->full_cover) hipLaunchKernelGGL(k_fill_plane, grid2d(c->s, B2D), B2D, 0, c->stream, c->s, f, 0.0);
+    B.act = act; B.up = true;
+    B.L.f[B.L.n] = f; B.L.mode[B.L.n] = 0; B.L.host[B.L.n] = src; B.L.n++;
+    return 0;
 }
 
 // staged downloads start from the caller's bytes so that cells the reference leaves untouched keep their values
@@ -1703,6 +1737,7 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     { const char *e = getenv("EVPK_PREFETCH"); c->prefetch = !(e && atoi(e) == 0); }
     { const char *e = getenv("EVPK_TILE"); c->tile_force = e ? (atoi(e) != 0 ? 1 : 0) : -1; c->roll_force = e ? (atoi(e) == 2 ? 1 : 0) : -1; }
     { const char *e = getenv("EVPK_VERIFY_DELIVERY"); c->verify_delivery = e ? atoi(e) : 0; }
+    { const char *e = getenv("EVPK_XFER_FUSED"); c->xfer_fused = !(e && atoi(e) == 0); }
     c->nsimd = 4 * prop.multiProcessorCount;
 
     // neighbours on the slab ring
@@ -1836,14 +1871,24 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
             HIPCHK(c, hipMalloc(&c->io_act, (size_t)s.ntx * s.nty));
         }
         if (!in->aice || !in->vice || !in->vsno) FAIL(c, "a required input pointer is NULL");
-        if (upload_f(c, in->aice, F_AICE) || upload_f(c, in->vice, F_VICE) || upload_f(c, in->vsno, F_VSNO)) return 1;
-        hipLaunchKernelGGL(k_io_tiles, grid2d(s, B2D), B2D, 0, c->stream, s, c->p, c->io_raw);
+        // sparse_io = 1: aice, vice, vsno whole (one launch); = 2: aice alone -- vice and vsno are zero where aice is (the host's
+        // promise: CICE's zap_small_areas / cleanup_itd keep it so) and travel in the active tiles like the other inputs
+        const int aice_only = (c->p.sparse_io >= 2) ? 1 : 0;
+        {
+            XferBatch WB;
+            WB.c = c;
+            if (upload_fb(WB, in->aice, F_AICE, nullptr)) return 1;
+            if (!aice_only && (upload_fb(WB, in->vice, F_VICE, nullptr) || upload_fb(WB, in->vsno, F_VSNO, nullptr))) return 1;
+            if (WB.flush()) return 1;
+        }
+        hipLaunchKernelGGL(k_io_tiles, grid2d(s, B2D), B2D, 0, c->stream, s, c->p, c->io_raw, aice_only);
         hipLaunchKernelGGL(k_io_tiles_dilate, dim3((s.ntx + 63) / 64, s.nty), dim3(64), 0, c->stream, s, (const unsigned char *)c->io_raw, c->io_act);
         HIPCHK(c, hipGetLastError());
         act = c->io_act;
     }
     c->io_sparse_now = sparse;
     c->up_dirty = true;
+    const bool vsparse = sparse && c->p.sparse_io >= 2;
     struct { const double *h; int f; bool need; } ip[] = {
         {in->aice, F_AICE, true}, {in->vice, F_VICE, true}, {in->vsno, F_VSNO, true}, {in->aice_init, F_AICE_INIT, true},
         {in->uocn, F_UOCN, true}, {in->vocn, F_VOCN, true}, {in->Cdn_ocn, F_CW, true}, {in->strength, F_STRENGTH, false},
@@ -1851,11 +1896,14 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
         // wind: either T-grid stress (t2ugrid_vector) or U-grid stress (ACCESS); both land in STRAIRXT/YT
         {c->p.wind_on_ugrid ? in->strax : in->strairxT, F_STRAIRXT, true},
         {c->p.wind_on_ugrid ? in->stray : in->strairyT, F_STRAIRYT, true}};
+    XferBatch UB;
+    UB.c = c;
     for (auto &e : ip) {
         if (!e.h) { if (e.need) FAIL(c, "a required input pointer is NULL"); continue; }
-        if (sparse && (e.f == F_AICE || e.f == F_VICE || e.f == F_VSNO)) continue;      // (uploaded whole above)
-        if (upload_f(c, e.h, e.f, act)) return 1;
+        if (sparse && (e.f == F_AICE || (!vsparse && (e.f == F_VICE || e.f == F_VSNO)))) continue;      // (uploaded whole above)
+        if (upload_fb(UB, e.h, e.f, act)) return 1;
     }
+    if (UB.flush()) return 1;
     c->strength_dev = (in->strength == nullptr);
     if (c->strength_dev && c->p.kstrength == 1) {
         // thickness distribution for ice_strength on the device: (nx_block, ny_block, ncat, nblocks) arrays, one plane per category
@@ -1893,18 +1941,19 @@ extern "C" int evpk_upload(evpk_ctx *c, const evpk_step_in *in, const evpk_state
         return 0;
     }
     if (!st->uvel || !st->vvel || !st->iceumask) FAIL(c, "uvel/vvel/iceumask is NULL");
-    if (upload_f(c, st->uvel, F_STATE0 + S_U)) return 1;
-    if (upload_f(c, st->vvel, F_STATE0 + S_V)) return 1;
+    if (upload_fb(UB, st->uvel, F_STATE0 + S_U, nullptr)) return 1;
+    if (upload_fb(UB, st->vvel, F_STATE0 + S_V, nullptr)) return 1;
     for (int q = 0; q < 4; q++) {
         if (!st->stressp[q] || !st->stressm[q] || !st->stress12[q]) FAIL(c, "a stress pointer is NULL");
-        if (upload_f(c, st->stressp[q], F_STATE0 + S_SP + q)) return 1;
-        if (upload_f(c, st->stressm[q], F_STATE0 + S_SM + q)) return 1;
-        if (upload_f(c, st->stress12[q], F_STATE0 + S_S12 + q)) return 1;
+        if (upload_fb(UB, st->stressp[q], F_STATE0 + S_SP + q, nullptr)) return 1;
+        if (upload_fb(UB, st->stressm[q], F_STATE0 + S_SM + q, nullptr)) return 1;
+        if (upload_fb(UB, st->stress12[q], F_STATE0 + S_S12 + q, nullptr)) return 1;
     }
     if (upload_m(c, st->iceumask, s.iceumask)) return 1;
     // strintx/y, strocnx/y are inout in evp_prep2 (kept where iceumask stays true until the loop rewrites them)
-    if (upload_f(c, st->strintx, F_STRINTX) || upload_f(c, st->strinty, F_STRINTY)) return 1;
-    if (upload_f(c, st->strocnx, F_STROCNX) || upload_f(c, st->strocny, F_STROCNY)) return 1;
+    if (upload_fb(UB, st->strintx, F_STRINTX, nullptr) || upload_fb(UB, st->strinty, F_STRINTY, nullptr)) return 1;
+    if (upload_fb(UB, st->strocnx, F_STROCNX, nullptr) || upload_fb(UB, st->strocny, F_STROCNY, nullptr)) return 1;
+    if (UB.flush()) return 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cur = 0;
     c->uploaded = true;
@@ -1981,7 +2030,10 @@ static int tune_R2(evpk_ctx *c) {
     }
     c->tile_mode = c->tile_force >= 0 ? (c->tile_force == 1) : (std::min(bestT, bestRo) < best);
     if (best > 1e299 && bestT > 1e299) c->tile_mode = false;
-    c->tile_roll = c->tile_mode && (c->roll_force >= 0 ? (c->roll_force == 1) : (bestRo < bestT)) && bestRo < 1e299;
+    // (measured, profiles/r05_v1/roll_ab.txt: the rolling kernel computes 26 % fewer rows and delivers the same rows per microsecond --
+    //  six of its eight waves work in a phase, four barriers per pass: the small slabs are bound by the latency of a workgroup's phase
+    //  chain, not by the arithmetic -- so the tuner never takes it; EVPK_TILE=2 does)
+    c->tile_roll = c->tile_mode && c->roll_force == 1 && bestRo < 1e299;
     c->R2 = c->tile_mode ? (c->tile_roll ? bestRr : bestH) : bestR;
     c->nry2 = (s.nyl + 1 + c->R2 - 1) / c->R2;
     c->tuned_icellt = -2;      // set from the counts of this prep below
@@ -2847,11 +2899,19 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
     // ... which is only known of an array that was also delivered after the previous evp: one that the caller fetches now
     // and then (restart, history) is delivered whole
     const unsigned char *act_all = (c->io_sparse_now && c->prepped) ? s.act_any : nullptr;
+    XferBatch DB;
+    DB.c = c; DB.up = false;
+    const size_t nall = (size_t)c->nblocks * c->nyb * c->nxb;
     auto dl = [&](double *h, int f, int mode, int id, bool never_sparse = false) -> int {
-        if (!h) return 0;
+        if (!h || !c->nblocks) return 0;
         const unsigned char *a = (!never_sparse && act_all && c->last_dl[id] == c->evp_count - 1) ? act_all : nullptr;
         c->last_dl[id] = c->evp_count;
-        return download_f(c, h, f, mode, a);
+        double *dst = (c->xfer_fused && !c->verify_delivery) ? (double *)mapped_alias(h, nall * sizeof(double)) : nullptr;
+        if (!dst) return download_f(c, h, f, mode, a);
+        if (DB.L.n && (DB.act != a || DB.L.n == XFER_MAX)) { if (DB.flush()) return 1; }
+        DB.act = a;
+        DB.L.f[DB.L.n] = f; DB.L.mode[DB.L.n] = mode; DB.L.host[DB.L.n] = dst; DB.L.n++;
+        return 0;
     };
     if (dl(st->uvel, SB + S_U, MODE_ALL, F_STATE0 + S_U)) return 1;
     if (dl(st->vvel, SB + S_V, MODE_ALL, F_STATE0 + S_V)) return 1;
@@ -2873,6 +2933,7 @@ extern "C" int evpk_download(evpk_ctx *c, evpk_state *st) {
         const bool zg = (e.f == F_STRAIRX || e.f == F_STRAIRY) && !c->p.wind_on_ugrid;
         if (dl(e.h, e.f, zg ? MODE_PHYS_ZG : MODE_PHYS, e.f, zg)) return 1;
     }
+    if (DB.flush()) return 1;
     // the strength with its ghost cells halo-updated, as evp leaves it (ice_dyn_evp.F90:311-312) -- also when it was an input
     if (download_f(c, st->strength, F_STRENGTH, MODE_ALL)) return 1;
     if (st->icetmask) {

@@ -113,6 +113,67 @@ __global__ void k_scatter_f(Slab s, const BlockDesc *bd, int nxb, int nyb, int f
     dst[((size_t)b * nyb + (j - 1)) * nxb + (i - 1)] = FD(s, f, cell(s, si, sj));
 }
 
+// Several block arrays in ONE launch (round 5): a thread moves its cell of every array of the list, all loads issued before the first
+// store -- over PCIe (page-locked caller arrays read / written in place) that keeps up to XFER_MAX reads of a lane in flight instead
+// of one per launch, and a dozen launches with their gaps become one.  Same cell rules as k_gather_f / k_scatter_f.
+constexpr int XFER_MAX = 12;
+struct XferList {
+    int n;
+    int f[XFER_MAX];             // slab field of each array
+    int mode[XFER_MAX];          // scatter: MODE_* of each array
+    double *host[XFER_MAX];      // the caller's arrays (device-visible aliases)
+};
+__global__ void k_gather_multi(Slab s, const BlockDesc *bd, int nxb, int nyb, XferList L, const unsigned char *act) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    const int si = d.iglob_lo + (i - d.ilo) - s.i0 + 1;
+    const int sj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+    if (si < 0 || si > s.nxl + 1 || sj < 0 || sj > s.nyl + 1) return;
+    if (act && !act[(sj / TILE_Y) * s.ntx + si / TILE_X]) return;
+    if (!gather_take(s, d, i, j, si, sj)) return;
+    const size_t k = ((size_t)b * nyb + (j - 1)) * nxb + (i - 1);
+    const size_t c = cell(s, si, sj);
+    double v[XFER_MAX];
+#pragma unroll
+    for (int q = 0; q < XFER_MAX; q++) if (q < L.n) v[q] = L.host[q][k];
+#pragma unroll
+    for (int q = 0; q < XFER_MAX; q++) if (q < L.n) FD(s, L.f[q], c) = v[q];
+}
+
+__global__ void k_scatter_multi(Slab s, const BlockDesc *bd, int nxb, int nyb, XferList L, const unsigned char *act) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int b = blockIdx.z;
+    if (i > nxb) return;
+    const BlockDesc d = bd[b];
+    if (act) {      // sparse download: a cell of a tile that is inactive now and was at the previous evp holds the same zero on both sides
+        const int ti = d.iglob_lo + (i - d.ilo) - s.i0 + 1, tj = d.jglob_lo + (j - d.jlo) - s.j0 + 1;
+        if (ti >= 0 && ti <= s.nxl + 1 && tj >= 0 && tj <= s.nyl + 1 && !act[(tj / TILE_Y) * s.ntx + ti / TILE_X]) return;
+    }
+    const size_t k = ((size_t)b * nyb + (j - 1)) * nxb + (i - 1);
+    double v[XFER_MAX];
+    bool take[XFER_MAX];
+#pragma unroll
+    for (int q = 0; q < XFER_MAX; q++) {
+        take[q] = false;
+        if (q < L.n) {
+            int si, sj;
+            if (L.mode[q] == MODE_PHYS_ZG) {       // physical cells delivered, ghost (and padding) cells of the block zeroed
+                const bool phys = (i >= d.ilo && i <= d.ihi && j >= d.jlo && j <= d.jhi);
+                take[q] = true; v[q] = 0.0;
+                if (phys) { (void)scatter_take(s, d, i, j, MODE_PHYS, si, sj); v[q] = FD(s, L.f[q], cell(s, si, sj)); }
+            } else if (scatter_take(s, d, i, j, L.mode[q], si, sj)) {
+                take[q] = true; v[q] = FD(s, L.f[q], cell(s, si, sj));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < XFER_MAX; q++) if (q < L.n && take[q]) L.host[q][k] = v[q];
+}
+
 __global__ void k_scatter_m(Slab s, const BlockDesc *bd, int nxb, int nyb, const int32_t *src, int32_t *dst, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y + 1;
@@ -288,14 +349,19 @@ __global__ void k_prep1a(Slab s, DevParams p, int fresh, const unsigned char *up
 
 // sparse upload: which tiles can matter to this evp -- any cell with ice (the test of evp_prep1, :331-332, or any non-zero
 // aice / tmass at all) on the freshly uploaded aice / vice / vsno, or the ghost ring
-__global__ void k_io_tiles(Slab s, DevParams p, unsigned char *raw) {
+// (aice_only: vice / vsno have not been uploaded yet -- they are zero wherever aice is, evpk_params.sparse_io = 2)
+__global__ void k_io_tiles(Slab s, DevParams p, unsigned char *raw, int aice_only) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
     bool hm = false;
     if (i <= s.nxl + 1 && j <= s.nyl + 1) {
         const size_t k = cell(s, i, j);
-        const double tmass = s.tmask[mcell(s, i, j)] ? (p.rhoi * FD(s, F_VICE, k) + p.rhos * FD(s, F_VSNO, k)) : 0.0;
-        hm = (s.tmask[mcell(s, i, j)] && FD(s, F_AICE, k) > p.a_min && tmass > p.m_min) || tmass != 0.0 || FD(s, F_AICE, k) != 0.0;
+        if (aice_only) {
+            hm = FD(s, F_AICE, k) != 0.0;
+        } else {
+            const double tmass = s.tmask[mcell(s, i, j)] ? (p.rhoi * FD(s, F_VICE, k) + p.rhos * FD(s, F_VSNO, k)) : 0.0;
+            hm = (s.tmask[mcell(s, i, j)] && FD(s, F_AICE, k) > p.a_min && tmass > p.m_min) || tmass != 0.0 || FD(s, F_AICE, k) != 0.0;
+        }
     }
     const int any = __syncthreads_or(hm ? 1 : 0);
     const bool edge = (blockIdx.x == 0 || blockIdx.x == (unsigned)s.ntx - 1 || blockIdx.y == 0 || blockIdx.y == (unsigned)s.nty - 1);
@@ -2121,9 +2187,12 @@ __device__ __forceinline__ void lds_dma16(const char *gsrc, double2 *lds_slot) {
 }
 
 // The same with the address as the hardware takes it -- a scalar base (SGPR pair) + a 32-bit lane offset -- and the LDS byte address of
-// the slot in M0: one instruction.  The builtin form above costs three VALU instructions per transfer in k_subcycle2p (a 64-bit vector
-// add for the address, a vector add and a v_readfirstlane for M0: 54 of the 1 393 vector instructions of a march step, round 5).  M0 is
-// written behind the compiler's back: use it only on paths where every LDS-DMA goes through this function.
+// the slot in M0: one instruction where the builtin form costs one to three vector instructions per transfer (a 64-bit vector add
+// for the address; a vector add and a v_readfirstlane for M0 when the wave index is not known to be uniform).  Used by the tile
+// kernels.  In k_subcycle2p it took 54 of the 1 393 vector instructions out of a march step (with the zero fills of lane-private
+// state: 1 393 -> 1 314) and changed its time by NOTHING (profiles/r05_v1/diet_ab.txt: 0.2147 against 0.2150 ms per launch,
+// alternating on one box) -- that kernel is not bound by instruction issue; it keeps the builtin.  M0 is written behind the
+// compiler's back: use this only on paths where every LDS-DMA goes through it.
 // (the slot's offset is an immediate of the s_add that makes M0: one SGPR -- the wave's LDS base -- serves all slots; with a value per
 // slot the compiler hoisted eighteen of them out of the march, spilled them and read them back with v_readlane)
 template <int SLOT>
@@ -2159,9 +2228,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     __shared__ double2 smem[4 * PF_SLOTS * 64];
     static_assert(sizeof(double2) * 4 * PF_SLOTS * 64 >= sizeof(double) * BAND_LDS_DOUBLES, "the band workgroups use the same LDS");
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    double2 *const L = smem + (size_t)wv * PF_SLOTS * 64;     // this wave's slots
-    const unsigned Lb = (unsigned)(size_t)(__attribute__((address_space(3))) void *)L;      // ... as an LDS byte address (uniform)
+    double2 *const L = smem + (size_t)(threadIdx.x >> 6) * PF_SLOTS * 64;     // this wave's slots
     const int nband8 = (a.nband + 7) & ~7;
     if ((int)blockIdx.x < nband8) {              // tripole top band of this pair of subcycles (one rank): see band_pair
         if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, reinterpret_cast<double *>(smem));
@@ -2212,7 +2279,6 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     const bool own = (lane >= 1 && lane <= STRIP2_W && c >= 1 - G && c <= nxl + G);
 
     const size_t pp = (size_t)s.pitch * 16;
-    const unsigned pp32 = (unsigned)s.pitch * 16u;       // (a row of all planes is < 4 GiB: plane offsets inside a row fit 32 bits)
     const size_t rowb = (size_t)s.rstride * 16;
     const unsigned lo = (unsigned)(C0 + ci) * 16u, lom = (unsigned)(C0 + cm1) * 16u;
     const int SR = a.sr;
@@ -2225,28 +2291,26 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     auto issue = [&](int rn, unsigned char mt_, unsigned char mu_, unsigned char mt_next) {
         if (rowok(rn)) {
             const char *rbn = base + (size_t)rn * rowb;
-            if (okc) lds_dma16s<0>(rbn + (size_t)((unsigned)((SR + S_U) >> 1) * pp32), lo, Lb);
-            if (okm) lds_dma16s<1>(rbn + (size_t)((unsigned)((SR + S_U) >> 1) * pp32), lom, Lb);
+            if (okc) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lo, L + 0 * 64);
+            if (okm) lds_dma16(rbn + (size_t)((SR + S_U) >> 1) * pp + lom, L + 1 * 64);
             const bool ta = tcol && (mt_ & CM_T) != 0;
             if (CM) {   // HTN of this row is also the south length of the next row: fetch it if either is active
                 const bool th = tcol && ((mt_ | mt_next) & CM_T) != 0;
-                if (__any(th)) { if (th) lds_dma16s<2>(rbn + (size_t)((unsigned)(F_HTN >> 1) * pp32), lo, Lb); }
+                if (__any(th)) { if (th) lds_dma16(rbn + (size_t)(F_HTN >> 1) * pp + lo, L + 2 * 64); }
             }
             if (__any(ta)) {
                 if (ta) {
                     if (CM) {
-                        if (okm) lds_dma16s<3>(rbn + (size_t)((unsigned)(F_HTN >> 1) * pp32), lom, Lb);
+                        if (okm) lds_dma16(rbn + (size_t)(F_HTN >> 1) * pp + lom, L + 3 * 64);
                     } else {
-                        lds_dma16s<2>(rbn + (size_t)((unsigned)(F_CXP >> 1) * pp32), lo, Lb);
-                        lds_dma16s<3>(rbn + (size_t)((unsigned)(F_CXM >> 1) * pp32), lo, Lb);
-                        lds_dma16s<4>(rbn + (size_t)((unsigned)(F_DXT >> 1) * pp32), lo, Lb);
-                        lds_dma16s<5>(rbn + (size_t)((unsigned)(F_DXHY >> 1) * pp32), lo, Lb);
+                        lds_dma16(rbn + (size_t)(F_CXP >> 1) * pp + lo, L + 2 * 64);
+                        lds_dma16(rbn + (size_t)(F_CXM >> 1) * pp + lo, L + 3 * 64);
+                        lds_dma16(rbn + (size_t)(F_DXT >> 1) * pp + lo, L + 4 * 64);
+                        lds_dma16(rbn + (size_t)(F_DXHY >> 1) * pp + lo, L + 5 * 64);
                     }
-                    lds_dma16s<6>(rbn + (size_t)((unsigned)(F_TINYAREA >> 1) * pp32), lo, Lb);
-                    const unsigned sp0 = (unsigned)((SR + S_SP) / 2) * pp32;
-                    lds_dma16s<7>(rbn + (size_t)sp0, lo, Lb);               lds_dma16s<8>(rbn + (size_t)(sp0 + pp32), lo, Lb);
-                    lds_dma16s<9>(rbn + (size_t)(sp0 + 2 * pp32), lo, Lb);  lds_dma16s<10>(rbn + (size_t)(sp0 + 3 * pp32), lo, Lb);
-                    lds_dma16s<11>(rbn + (size_t)(sp0 + 4 * pp32), lo, Lb); lds_dma16s<12>(rbn + (size_t)(sp0 + 5 * pp32), lo, Lb);
+                    lds_dma16(rbn + (size_t)(F_TINYAREA >> 1) * pp + lo, L + 6 * 64);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) lds_dma16(rbn + (size_t)((SR + S_SP) / 2 + q) * pp + lo, L + (7 + q) * 64);
                 }
             }
         }
@@ -2255,11 +2319,11 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
         if (__any(ua)) {
             if (ua) {
                 const char *rbu = base + (size_t)ru_ * rowb;
-                lds_dma16s<13>(rbu + (size_t)((unsigned)(F_VRELC >> 1) * pp32), lo, Lb);
-                lds_dma16s<14>(rbu + (size_t)((unsigned)(F_UOCN >> 1) * pp32), lo, Lb);
-                lds_dma16s<15>(rbu + (size_t)((unsigned)(F_FORCEX >> 1) * pp32), lo, Lb);
-                lds_dma16s<16>(rbu + (size_t)((unsigned)(F_UMASSDTI >> 1) * pp32), lo, Lb);
-                if (REVP) lds_dma16s<17>(rbu + (size_t)((unsigned)(F_UVEL_INIT >> 1) * pp32), lo, Lb);
+                lds_dma16(rbu + (size_t)(F_VRELC >> 1) * pp + lo, L + 13 * 64);
+                lds_dma16(rbu + (size_t)(F_UOCN >> 1) * pp + lo, L + 14 * 64);
+                lds_dma16(rbu + (size_t)(F_FORCEX >> 1) * pp + lo, L + 15 * 64);
+                lds_dma16(rbu + (size_t)(F_UMASSDTI >> 1) * pp + lo, L + 16 * 64);
+                if (REVP) lds_dma16(rbu + (size_t)(F_UVEL_INIT >> 1) * pp + lo, L + 17 * 64);
             }
         }
     };
@@ -2320,10 +2384,8 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
             if (okm) { const double2 q = L[1 * 64 + lane]; un_m = q.x; vn_m = q.y; }
         }
         const bool t1act = tcol && (m & CM_T) != 0;
-        // (sigma, the metrics and the stepu inputs of a lane are read only where that lane's own cell is active -- the same test on the
-        //  same mask byte, also a step later as g1p / mtp / qp: lanes without get no zeros, 30 vector moves per step less, round 5)
-        Sig g1;
-        TMet mt;
+        Sig g1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        TMet mt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         double hn = 0.0, he = 0.0, hw = 0.0, tiny_c = 0.0, str_c = 0.0;
         if (CM) {
             const bool th = tcol && ((m | m_n1) & CM_T) != 0 && rok;
@@ -2346,7 +2408,7 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
             }
         }
         const bool u1act = (t >= 1) && ucol && (mp & CM_U) != 0 && (r - 1 >= 1) && (r - 1 <= nyl);
-        UStat q1;
+        UStat q1{0, 0, 0, 0, 0, 0, 0, 0};
         double ui1 = 0.0, vi1 = 0.0;
         if (__any(u1act)) {
             if (u1act) {

@@ -93,7 +93,7 @@ class EvpDynamics:
         # host model reads every step is uvel, vvel (transport), rdg_conv, rdg_shear (ridging), strocnxT/yT (coupler), divu,
         # shear; the rest on the steps that write history or a restart; sparse_io: evpk_params.sparse_io
         self._resident, self._outputs, self._ncalls = resident, outputs, 0
-        self._opts["sparse_io"] = bool(sparse_io)
+        self._opts["sparse_io"] = int(sparse_io)      # 0, 1 (aice, vice, vsno whole), 2 (aice whole): evpk_params.sparse_io
         self._xmin = xmin
         self.ctx = evpk.Context(decomp, fields, device=device, unique_id=unique_id, defer_connect=defer_connect)
         self.ctx.device_strength = device_strength is not None

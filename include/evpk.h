@@ -90,7 +90,9 @@ typedef struct {
      * aice, vice, vsno are uploaded whole, every other input only in the 64x4-cell tiles that hold ice now or held any at
      * the previous call (+ two tiles around), and evpk_download skips tiles that are and were ice-free (they hold the same
      * zeros on both sides).  Identical results provided the T-grid inputs strairxT/yT, aice_init, strength are zero where
-     * there is no ice, as CICE leaves them; 0 (default): every cell of every array moves. */
+     * there is no ice, as CICE leaves them; 0 (default): every cell of every array moves.
+     * 2: as 1, and vice, vsno travel in the active tiles too -- only aice is uploaded whole and the tiles are taken from it alone:
+     * the host promises vice = vsno = 0 wherever aice = 0 (CICE keeps it so: zap_small_areas, cleanup_itd). */
     int32_t sparse_io;
     int32_t reserved_;
 } evpk_params;

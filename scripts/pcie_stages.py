@@ -11,7 +11,7 @@ nx, ny = 3600, 2700
 case = synth.SynthCase(nx=nx, ny=ny, land="continents", dt=450.0, ns_boundary=C.BND_NAMES["tripole"])
 d = blocks.create_distrb_cart(nx, ny, 450, 270, ns_boundary_type="tripole")
 f = synth.make_block_fields(case, d)
-for sparse in (False, True):
+for sparse in (0, 1, 2):
     s = dyn.EvpDynamics(d, f, ndte=120, pin_host=True, resident=True, outputs=dyn.EVERY_STEP_OUTPUTS, sparse_io=sparse)
     s.init_evp(450.0)
     s.evp(450.0); s.evp(450.0)
@@ -26,5 +26,5 @@ for sparse in (False, True):
         ctx.download(out); ctx.sync(); t5 = time.perf_counter()
         for k, v in (("upload_inputs", t1 - t0), ("prep", t2 - t1), ("subcycle", t3 - t2), ("finish", t4 - t3), ("download_outputs", t5 - t4), ("total", t5 - t0)):
             acc[k] = min(acc.get(k, 1e9), v)
-    print(("sparse " if sparse else "dense  ") + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in acc.items()))
+    print(("sparse_io=%d " % sparse) + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in acc.items()))
     s.close()
