@@ -29,6 +29,9 @@
 
 // single translation unit: the kernels are compiled together with the host API
 #include "evpk_kernels.hip"
+#ifdef EVPK_EXPERIMENTAL
+#include "evpk_experimental.hip"      // k_subcycle2, k_subcycle3w: measured and not adopted (make exp -> libevpk_exp.so)
+#endif
 #include "evpk_remap.hip"
 #include "evpk_eap.hip"
 
@@ -565,6 +568,15 @@ extern "C" int evpk_host_free(void *ptr) {
 }
 
 // 1 if [ptr, ptr + bytes) lies inside a live evpk_pin_host / evpk_host_alloc range (the library will move it in place), else 0
+// 1 if this build contains the measured-and-rejected kernels (k_subcycle2, k_subcycle3w: -DEVPK_EXPERIMENTAL), else 0
+extern "C" int evpk_experimental_built(void) {
+#ifdef EVPK_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int evpk_host_is_mapped(const void *ptr, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     const uintptr_t lo = (uintptr_t)ptr, hi = lo + bytes;
@@ -1184,17 +1196,24 @@ static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp
         }
 #undef EVPK_L2P
 #undef EVPK_L2X
-    } else {
+    }
+#ifdef EVPK_EXPERIMENTAL
+    else {
         if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, true>), g, b, 0, st, a); }
         else       { if (revp) hipLaunchKernelGGL((k_subcycle2<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle2<false, false>), g, b, 0, st, a); }
     }
+#endif
 }
 
 // three subcycles in one launch: one workgroup of three waves per strip (k_subcycle3w)
 static void launch_sub3(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp) {
+#ifdef EVPK_EXPERIMENTAL
     const dim3 g(((a.nstrips + 7) / 8) * 8), b(192);            // multiple of 8: XCD remap in the kernel
     if (c->compact) { if (revp) hipLaunchKernelGGL((k_subcycle3w<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle3w<false, true>), g, b, 0, st, a); }
     else            { if (revp) hipLaunchKernelGGL((k_subcycle3w<true, false>), g, b, 0, st, a); else hipLaunchKernelGGL((k_subcycle3w<false, false>), g, b, 0, st, a); }
+#else
+    (void)c; (void)a; (void)st; (void)revp;      // (never reached: evpk_create refuses EVPK_TRIPLE=1 without the kernel)
+#endif
 }
 
 // ---- ghost zones (zW columns per side) of a list of pair planes: x-slab neighbours ------------------------
@@ -1529,8 +1548,11 @@ static int connect_impl(evpk_ctx *c, const void *unique_id) {
     }
     {   // resident workgroups of the two-subcycle kernel variant this context launches (strip-height tuner)
         int nb = 0;
-        const void *fn = !c->prefetch ? (const void *)k_subcycle2<false, false>
-                                      : (c->compact ? (const void *)k_subcycle2p<false, false, true> : (const void *)k_subcycle2p<false, false, false>);
+        const void *fn =
+#ifdef EVPK_EXPERIMENTAL
+                         !c->prefetch ? (const void *)k_subcycle2<false, false> :
+#endif
+                                      (c->compact ? (const void *)k_subcycle2p<false, false, true> : (const void *)k_subcycle2p<false, false, false>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0)
             c->slots2 = nb * prop.multiProcessorCount;
     }
@@ -1808,6 +1830,11 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     if (const char *ff = getenv("EVPK_FINISH_FUSED")) c->finish_fused = atoi(ff) != 0;
     if (const char *ds = getenv("EVPK_DEVICE_STRIPS")) c->dev_strips_env = atoi(ds) != 0;
     if (const char *tr = getenv("EVPK_TRIPLE")) c->triple_env = atoi(tr) != 0 ? 1 : 0;
+#ifndef EVPK_EXPERIMENTAL
+    // k_subcycle2 (no LDS prefetch) and k_subcycle3w (three subcycles per launch) were measured and not adopted: they are not in this build
+    if (!c->prefetch) FAIL(c, "EVPK_PREFETCH=0 selects k_subcycle2, which this build of libevpk does not contain (make -C cice5_amd/csrc exp)");
+    if (c->triple_env == 1) FAIL(c, "EVPK_TRIPLE=1 selects k_subcycle3w, which this build of libevpk does not contain (make -C cice5_amd/csrc exp)");
+#endif
     c->dbg_file = getenv("EVPK_DEBUG_CLOCKS");
     if (const char *pr = getenv("EVPK_PRIO")) c->prio = atoi(pr);
     HIPCHK(c, hipMalloc(&c->d_ns2, sizeof(int) * 2));
@@ -2043,6 +2070,9 @@ static int tune_R2(evpk_ctx *c) {
 // Strip list of the three-subcycle pipeline kernel (k_subcycle3w): flags and ordered compaction on the device, the kernel reads the
 // list's length from d_ns3; the host never waits for it.  One rank without ghost zones, marching (not tile) pairs, no tripole band
 // (round 4, stage a); EVPK_TRIPLE=0 / 1 overrides.
+#ifndef EVPK_EXPERIMENTAL
+static int prep_triple(evpk_ctx *c, int) { c->use_triple = false; return 0; }      // (k_subcycle3w is not in this build)
+#else
 static int prep_triple(evpk_ctx *c, int G) {
     Slab &s = c->s;
     const bool can = c->use_double && !c->eap && c->nranks == 1 && !c->zone_mode && !c->force_exchange && !c->band_mode &&
@@ -2074,6 +2104,7 @@ static int prep_triple(evpk_ctx *c, int G) {
     c->nstrips3 = tot;                // (the true number arrives with the loop's last event, as nstrips2 does)
     return 0;
 }
+#endif
 
 // Strip list of the one-subcycle kernel (and, when the two-subcycle kernel is off, the active-cell counts): flags on the
 // device, compaction on the host.  Called by evpk_prep when only that kernel exists, else on first use after a prep.

@@ -95,7 +95,7 @@ EXPORTS = ["evpk_get_unique_id", "evpk_create", "evpk_set_params", "evpk_run", "
            "evpk_unpin_host", "evpk_connect", "evpk_device_check", "evpk_restart_write", "evpk_restart_read",
            "evpk_transport_upwind", "evpk_remap_init", "evpk_transport_remap", "evpk_transport_remap_state",
            "evpk_eap_init", "evpk_eap_upload", "evpk_eap_download", "evpk_halo_update", "evpk_halo_update_stress",
-           "evpk_transport_upwind_state", "evpk_host_alloc", "evpk_host_free", "evpk_host_is_mapped"]
+           "evpk_transport_upwind_state", "evpk_host_alloc", "evpk_host_free", "evpk_host_is_mapped", "evpk_experimental_built"]
 
 REMAP_BAD_DEPARTURE, REMAP_NEGATIVE_MASS = 11, 12        # include/evpk.h
 
@@ -137,6 +137,7 @@ def lib():
         L.evpk_host_alloc.argtypes = [ct.c_size_t, ct.POINTER(ct.c_void_p)]
         L.evpk_host_free.argtypes = [ct.c_void_p]
         L.evpk_host_is_mapped.argtypes = [ct.c_void_p, ct.c_size_t]
+        L.evpk_experimental_built.argtypes = []
         L.evpk_connect.argtypes = [ctxp, ct.c_void_p]
         L.evpk_device_check.argtypes = [ct.c_int32]
         L.evpk_transport_upwind.argtypes = [ctxp, ct.c_double, ct.c_int32, c_f64p]
@@ -206,6 +207,12 @@ def host_copy(a: np.ndarray) -> np.ndarray:
     b = host_empty(a.shape, a.dtype)
     b[...] = a
     return b
+
+
+def experimental() -> bool:
+    """True if the loaded library was built with -DEVPK_EXPERIMENTAL (make -C cice5_amd/csrc exp -> libevpk_exp.so, EVPK_LIB selects it):
+    it then contains k_subcycle2 and k_subcycle3w, the kernels that were measured and not adopted"""
+    return lib().evpk_experimental_built() == 1
 
 
 def host_is_mapped(a: np.ndarray) -> bool:

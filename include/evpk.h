@@ -374,6 +374,9 @@ int evpk_unpin_host(void *ptr);
 int evpk_host_alloc(size_t bytes, void **out);
 int evpk_host_free(void *ptr);
 int evpk_host_is_mapped(const void *ptr, size_t bytes);
+/* 1 if the library was built with -DEVPK_EXPERIMENTAL (it then contains k_subcycle2 and k_subcycle3w -- measured, not adopted -- and
+ * honours EVPK_PREFETCH=0 / EVPK_TRIPLE=1; the product build refuses them) */
+int evpk_experimental_built(void);
 const char *evpk_last_error(const evpk_ctx *c);  /* c may be NULL: error of the last failed evpk_create */
 
 /* Host-only description of this rank's halo exchange (no GPU needed): neighbours in the

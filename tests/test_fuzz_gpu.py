@@ -13,7 +13,8 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_PREFETCH": "0"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_ZONE_M": "2"},
+# ({"EVPK_TILE": "2"}: the rolling tile kernel of round 5 in place of {"EVPK_PREFETCH": "0"}, whose kernel left the product build)
+MODES = [{}, {"EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_DOUBLE": "0"}, {"EVPK_TILE": "2"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_ZONE_M": "2"},
          {"EVPK_COMPACT_METRICS": "0"}, {"EVPK_STRIP_ROWS": "3"}, {"EVPK_FORCE_EXCHANGE": "1", "EVPK_OVERLAP": "0"},
          {"EVPK_FORCE_EXCHANGE": "2"}, {"EVPK_FORCE_EXCHANGE": "2", "EVPK_ZONE_M": "1"},
          {"EVPK_TILE": "1"}, {"EVPK_TILE": "1", "EVPK_FORCE_EXCHANGE": "1"}, {"EVPK_TILE": "1", "EVPK_STRIP_ROWS": "2"}, {"EVPK_TILE": "0"}]

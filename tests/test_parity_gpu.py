@@ -13,6 +13,10 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
+# k_subcycle2 (EVPK_PREFETCH=0) and k_subcycle3w (EVPK_TRIPLE=1) were measured and not adopted: the product library does not contain them
+# (csrc/evpk_experimental.hip).  Their tests run against the other build: EVPK_LIB=cice5_amd/libevpk_exp.so python -m pytest tests -m gpu -k three_subcycle
+needs_experimental = pytest.mark.skipif(not evpk.experimental(), reason="kernels of evpk_experimental.hip: EVPK_LIB=cice5_amd/libevpk_exp.so")
+
 
 def _both(nx, ny, bsx, bsy, *, ndte=120, dt=3600.0, ncalls=1, revised_evp=False, cosw=1.0, sinw=0.0,
           tilt_from_slope=False, wind_on_ugrid=False, ns="open", nsub=None, pin_host=False, **kw):
@@ -251,6 +255,7 @@ def test_two_subcycle_kernel_equals_single(monkeypatch):
         assert not util.compare(d, outs[1], outs[0])
 
 
+@needs_experimental
 @pytest.mark.parametrize("R3", ["", "3", "7", "40"])
 def test_three_subcycle_kernel_equals_single(R3, monkeypatch):
     """k_subcycle3w (three subcycles per launch, one wave per subcycle stage, sigma and (u, v) handed from stage to stage through
@@ -287,6 +292,7 @@ def test_three_subcycle_kernel_equals_single(R3, monkeypatch):
         assert np.abs(outs[0]["uvel"]).max() > 1e-4
 
 
+@needs_experimental
 def test_three_subcycle_kernel_equals_oracle(monkeypatch):
     """the same kernel against the oracle: BASELINE config 3's grid in 24 blocks and a 3-call warm start (new / lost ice)"""
     monkeypatch.setenv("EVPK_TILE", "0")
