@@ -1076,6 +1076,8 @@ struct SubArgs {
                        // own strips, storing rows <= mjmax -- M's advance between two refreshes costs no launch of its own
     int nband;         // > 0 (tripole, one rank, cyclic E-W): the first nband8 = 8*ceil(nband/8) workgroups of the launch are the
                        // tripole top band (band_pair); the strips follow
+    int band_last;     // != 0: the band (and mirror-slab) workgroups are the LAST of the grid instead of the first, so that the strips take
+                       // the workgroup slots first and the short band workgroups run in the slots the first strips free (round 5)
     int prio;          // k_subcycle2p: != 0 -- a wave lowers its issue priority as it advances (3, 2, 1, 0 over the quarters of its march), so
                        // that of the two waves of a SIMD the one that is BEHIND wins the VALU arbitration (by default the older wave wins
                        // every time, finishes a third earlier and leaves the younger one alone on the SIMD, where a single dependent
@@ -1963,22 +1965,25 @@ __global__ __launch_bounds__(256, 2) void k_subcycle2p(SubArgs a) {      // two 
     const int lane = threadIdx.x & 63;
     double2 *const L = smem + (size_t)(threadIdx.x >> 6) * PF_SLOTS * 64;     // this wave's slots
     const int nband8 = (a.nband + 7) & ~7;
-    if ((int)blockIdx.x < nband8) {              // tripole top band of this pair of subcycles (one rank): see band_pair
-        if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, reinterpret_cast<double *>(smem));
+    const int nmir8 = XM ? ((((a.nmir + 3) >> 2) + 7) & ~7) : 0;
+    // logical workgroup index: band, mirror slab, strips -- in that order from workgroup 0, or (band_last) rotated so that the strips
+    // are dispatched first (nband8, nmir8 are multiples of 8: the XCD of a strip's workgroup does not change)
+    const int vb = a.band_last ? (int)((blockIdx.x + (unsigned)(nband8 + nmir8)) % gridDim.x) : (int)blockIdx.x;
+    if (vb < nband8) {              // tripole top band of this pair of subcycles (one rank): see band_pair
+        if (vb < a.nband) band_pair<REVP, LAST2>(a, vb, reinterpret_cast<double *>(smem));
         return;
     }
     // XM (x-slab ranks, tripole): the next workgroups advance the strips of the mirror slab (SubArgs::nmir)
-    const int nmir8 = XM ? ((((a.nmir + 3) >> 2) + 7) & ~7) : 0;
-    const bool mir = XM && (int)blockIdx.x - nband8 < nmir8;
+    const bool mir = XM && vb - nband8 < nmir8;
     const SlabV s = slab_view(a, mir);
     const int jmax = mir ? a.mjmax : a.jmax;
     int sid, st;
     if (mir) {
-        sid = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - nband8) * 4 + (int)(threadIdx.x >> 6));
+        sid = __builtin_amdgcn_readfirstlane((vb - nband8) * 4 + (int)(threadIdx.x >> 6));
         if (sid >= a.nmir) return;
         st = sid;
     } else {
-        const int bidx = (int)blockIdx.x - nband8 - nmir8;
+        const int bidx = vb - nband8 - nmir8;
         const int ns = pair_nstrips(a);
         const int chunk = a.nsdev ? (((ns + 3) >> 2) + 7) >> 3 : ((int)gridDim.x - nband8 - nmir8) >> 3;
         if ((bidx >> 3) >= chunk) return;
@@ -2270,22 +2275,23 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = blockDim.x >> 6;                   // R + 3
     const int nband8 = (a.nband + 7) & ~7;
-    if ((int)blockIdx.x < nband8) {                   // tripole top band of this pair (one rank; the launch asks for the LDS)
-        if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, tl);
+    const int nmir8 = XM ? ((a.nmir + 7) & ~7) : 0;
+    const int vb = a.band_last ? (int)((blockIdx.x + (unsigned)(nband8 + nmir8)) % gridDim.x) : (int)blockIdx.x;      // (see k_subcycle2p)
+    if (vb < nband8) {                   // tripole top band of this pair (one rank; the launch asks for the LDS)
+        if (vb < a.nband) band_pair<REVP, LAST2>(a, vb, tl);
         return;
     }
     // XM (x-slab ranks, tripole): the next workgroups advance the strips of the mirror slab (SubArgs::nmir), one each
-    const int nmir8 = XM ? ((a.nmir + 7) & ~7) : 0;
-    const bool mir = XM && (int)blockIdx.x - nband8 < nmir8;
+    const bool mir = XM && vb - nband8 < nmir8;
     const SlabV s = slab_view(a, mir);
     const int jmax = mir ? a.mjmax : a.jmax;
     int wg, st;
     if (mir) {
-        wg = (int)blockIdx.x - nband8;
+        wg = vb - nband8;
         if (wg >= a.nmir) return;                     // (the whole workgroup leaves: no barrier is left waiting)
         st = wg;
     } else {
-        const int bidx = (int)blockIdx.x - nband8 - nmir8;
+        const int bidx = vb - nband8 - nmir8;
         const int ns = pair_nstrips(a);
         const int chunk = a.nsdev ? (ns + 7) >> 3 : ((int)gridDim.x - nband8 - nmir8) >> 3;
         wg = (bidx & 7) * chunk + (bidx >> 3);
@@ -2480,21 +2486,22 @@ __global__ __launch_bounds__(512, 4) void k_subcycle2r(SubArgs a) {
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int NW = blockDim.x >> 6;
     const int nband8 = (a.nband + 7) & ~7;
-    if ((int)blockIdx.x < nband8) {                   // tripole top band of this pair (one rank; the launch asks for the LDS)
-        if ((int)blockIdx.x < a.nband) band_pair<REVP, LAST2>(a, (int)blockIdx.x, tl);
+    const int nmir8 = XM ? ((a.nmir + 7) & ~7) : 0;
+    const int vb = a.band_last ? (int)((blockIdx.x + (unsigned)(nband8 + nmir8)) % gridDim.x) : (int)blockIdx.x;      // (see k_subcycle2p)
+    if (vb < nband8) {                   // tripole top band of this pair (one rank; the launch asks for the LDS)
+        if (vb < a.nband) band_pair<REVP, LAST2>(a, vb, tl);
         return;
     }
-    const int nmir8 = XM ? ((a.nmir + 7) & ~7) : 0;
-    const bool mir = XM && (int)blockIdx.x - nband8 < nmir8;
+    const bool mir = XM && vb - nband8 < nmir8;
     const SlabV s = slab_view(a, mir);
     const int jmax = mir ? a.mjmax : a.jmax;
     int wg, st;
     if (mir) {
-        wg = (int)blockIdx.x - nband8;
+        wg = vb - nband8;
         if (wg >= a.nmir) return;                     // (the whole workgroup leaves: no barrier is left waiting)
         st = wg;
     } else {
-        const int bidx = (int)blockIdx.x - nband8 - nmir8;
+        const int bidx = vb - nband8 - nmir8;
         const int ns = pair_nstrips(a);
         const int chunk = a.nsdev ? (ns + 7) >> 3 : ((int)gridDim.x - nband8 - nmir8) >> 3;
         wg = (bidx & 7) * chunk + (bidx >> 3);

@@ -210,8 +210,10 @@ def test_hot_kernels_keep_their_register_budget():
         m = re.search(r"k_subcycle2tILb[01]ELb([01])ELb[01]E", k)              # <REVP, LAST2, XM>
         if m and m.group(1) == "0":                                          # (one row per wave, compiled for 128 VGPRs; the LAST2
             assert v["ScratchSize"] <= 64, (k, v)                            #  variants, once per evp, spill)
-        if "k_eap_sub" in k and "Lb0" in k:
+        if "k_eap_subILb0" in k:
             assert v["VGPRs"] <= 128 and v["ScratchSize"] <= 64, (k, v)
+        if "k_eap_sub_stepaILb0" in k:                                       # (the twelve subcycles of 120 that carry stepa: three waves per SIMD)
+            assert v["VGPRs"] <= 168 and v["ScratchSize"] <= 64, (k, v)
 
 
 def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
