@@ -492,7 +492,8 @@ def roofline(r, icellt, icellu, revp):
     if nsub == 3:
         kname = "evpk::k_subcycle3w (stress+stepu fused, three subcycles per launch, one wave per subcycle stage)"
     elif nsub == 2:
-        base = "evpk::k_subcycle2t" if st.tile_kernel else ("evpk::k_subcycle2" if os.environ.get("EVPK_PREFETCH") == "0" else "evpk::k_subcycle2p")
+        base = {1: "evpk::k_subcycle2t", 2: "evpk::k_subcycle2r"}.get(int(st.tile_kernel)) or \
+               ("evpk::k_subcycle2" if os.environ.get("EVPK_PREFETCH") == "0" else "evpk::k_subcycle2p")
         kname = base + " (stress+stepu fused, two subcycles per launch)"
     else:
         kname = "evpk::k_subcycle (stress+stepu fused)"

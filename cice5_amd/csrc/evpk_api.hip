@@ -367,7 +367,6 @@ struct evpk_ctx {
     int triple_launches = 0, kernel3_timed = 0;
     int prio = 1;                        // EVPK_PRIO (default 1): SubArgs.prio
     int band_last = 1;                   // EVPK_BAND_LAST (default 1): SubArgs.band_last
-    bool eap_stepa_fused = true;         // EVPK_EAP_STEPA_FUSED=0: stepa as a launch of its own after every tenth k_eap_sub
     unsigned char *up_dat = nullptr;     // per tile: the uploaded inputs hold something (k_up_tiles)
     bool up_dirty = true;                // ... and an upload has happened since it was computed
     size_t flags3_n = 0;
@@ -1162,8 +1161,15 @@ static int halo_stress12(evpk_ctx *c, int f0) {
 }
 
 // ---- launch of the two-subcycle kernel (plain or LDS-prefetch variant) ------------------------------------
-static void launch_sub2(evpk_ctx *c, const SubArgs &a, hipStream_t st, bool revp, bool last2) {
-    const int nband8 = (a.nband + 7) & ~7;      // the tripole top band as the first workgroups of the launch (band_pair)
+static void launch_sub2(evpk_ctx *c, const SubArgs &a_in, hipStream_t st, bool revp, bool last2) {
+    // The tripole band (and mirror-slab) workgroups as the LAST of the grid (round 5) -- in the marching kernel only.  There the
+    // strips of a launch take (nearly) all workgroup slots for ~200 us and 30 band workgroups of ~50 us in FRONT of them pushed
+    // the last strips into a second round: 0.2026 -> 0.1976 ms per launch, 12.85 -> 12.54 ms per evp at 3600x2700
+    // (profiles/r05_v1/band_last_ab.txt).  A tile launch is SHORTER than a band workgroup's chain of four phases and two folds:
+    // started last, the band is all that is left running (1440x1080 tripole 2.90 -> 3.40 ms per evp): there it stays first.
+    SubArgs a = a_in;
+    a.band_last = (c->band_last && !c->tile_mode) ? 1 : 0;
+    const int nband8 = (a.nband + 7) & ~7;      // the tripole top band as workgroups of the pair's own launch (band_pair)
     const bool xm = a.nmir > 0 && !last2 && a.xm && (c->tile_mode || c->prefetch);      // ... then the strips of the mirror slab (x-slab ranks, XM kernels)
     if (c->tile_mode && c->tile_roll) {      // ... rolling north through a strip of R rows: min(R + 3, ROLL_NW) waves per workgroup
         const int nw = std::min(a.R + 3, ROLL_NW);
@@ -1840,7 +1846,6 @@ static int create_impl(evpk_ctx *c, const evpk_geom *g) {
     c->dbg_file = getenv("EVPK_DEBUG_CLOCKS");
     if (const char *pr = getenv("EVPK_PRIO")) c->prio = atoi(pr);
     if (const char *bl = getenv("EVPK_BAND_LAST")) c->band_last = atoi(bl) != 0 ? 1 : 0;
-    if (const char *sf = getenv("EVPK_EAP_STEPA_FUSED")) c->eap_stepa_fused = atoi(sf) != 0;
     HIPCHK(c, hipMalloc(&c->d_ns2, sizeof(int) * 2));
     HIPCHK(c, hipMemset(c->d_ns2, 0, sizeof(int) * 2));
     HIPCHK(c, hipHostMalloc((void **)&c->h_counts, sizeof(unsigned long long) * 4, hipHostMallocDefault));
@@ -2597,7 +2602,7 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
         SubArgs a;
         a.s = s; a.ecci = c->p.ecci; a.arlx1i = c->p.arlx1i; a.denom1 = c->p.denom1; a.brlx = c->p.brlx;
         a.revp = c->p.revp; a.cosw = c->p.cosw; a.sinw = c->p.sinw;
-        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nmir = 0; a.mjmax = 0; a.nsdev = nullptr; a.xm = nullptr; a.dbg = nullptr; a.prio = c->prio; a.band_last = c->band_last;
+        a.R = c->R; a.jb0 = 0; a.G = 0; a.jmax = 1 << 30; a.nband = 0; a.nmir = 0; a.mjmax = 0; a.nsdev = nullptr; a.xm = nullptr; a.dbg = nullptr; a.prio = c->prio; a.band_last = c->band_last;      // (band_last: switched off below for the tile kernels)
         a.sr = c->cur ? F_STATE1 : F_STATE0; a.sw = c->cur ? F_STATE0 : F_STATE1;
         const bool revp = (c->p.revp == 1.0);
         // two subcycles in one launch when neither of them is the last one of this evp (ksub == ndte writes diagnostics) ...
@@ -2800,18 +2805,15 @@ static int subcycle_impl(evpk_ctx *c, int32_t nsub) {
             const size_t lds = (size_t)(c->R + 1) * 2048;
             if (ev_begin(c->stream, 1)) FAIL(c, "hipEventRecord failed");
             if (c->eap) {       // eap(dt): stress_eap + stepu in one launch (k_eap_sub), stepa every tenth subcycle (ice_dyn_eap.F90:345-447)
-                const double dtei = 1.0 / (c->p.dt / (double)c->p.ndte);                  // ice_dyn_shared.F90:209-210
-                const bool stepa = (c->ksub % 10 == 1);                                    // :411-426
-                EapSubArgs x{c->E, (last || n == nsub) ? 1 : 0, dtei};
-                if (stepa && c->eap_stepa_fused) {
-                    // stepa inside the subcycle's own launch: the new angles into the other set of angle planes, swapped behind it
-                    if (last) hipLaunchKernelGGL(k_eap_sub_stepa<true>, g, b, 0, c->stream, a, x);
-                    else hipLaunchKernelGGL(k_eap_sub_stepa<false>, g, b, 0, c->stream, a, x);
-                    c->E.angsel ^= 1;
-                } else {
-                    if (last) hipLaunchKernelGGL(k_eap_sub<true>, g, b, 0, c->stream, a, x);
-                    else hipLaunchKernelGGL(k_eap_sub<false>, g, b, 0, c->stream, a, x);
-                    if (stepa) hipLaunchKernelGGL(k_eap_stepa, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 1 + 3) / 4), B2D, 0, c->stream, s, c->E, a.sw, dtei);
+                EapSubArgs x{c->E, (last || n == nsub) ? 1 : 0};
+                if (last) hipLaunchKernelGGL(k_eap_sub<true>, g, b, 0, c->stream, a, x);
+                else hipLaunchKernelGGL(k_eap_sub<false>, g, b, 0, c->stream, a, x);
+                // (round 5: stepa INSIDE this launch -- the angle planes double buffered, the twelve stepa subcycles as a kernel of their own
+                //  at three waves per SIMD -- was built, is bit-exact and measured SLOWER: 42.1-43.0 ms per eap against 41.2-41.3,
+                //  profiles/r05_v1/eap_stepa_ab.txt; the launch of its own stays)
+                if (c->ksub % 10 == 1) {                                                    // :411-426
+                    const double dtei = 1.0 / (c->p.dt / (double)c->p.ndte);              // ice_dyn_shared.F90:209-210
+                    hipLaunchKernelGGL(k_eap_stepa, dim3((s.nxl + 1 + 63) / 64, (s.nyl + 1 + 3) / 4), B2D, 0, c->stream, s, c->E, a.sw, dtei);
                 }
             }
             else if (t1) {

@@ -18,7 +18,7 @@
 
 namespace evpk {
 
-constexpr int EAP_NPLANES = 8 + 11 + 8 + 8 + 8;   // a11_c, a12_c; history; str; the angles (4 double2 planes), twice (see angsel)
+constexpr int EAP_NPLANES = 8 + 11 + 8 + 8;       // a11_c, a12_c; history; str; the angles (4 double2 planes)
 struct EapDev {
     // the yield-curve tables s11r, s12r, s22r, s11s, s12s, s22s interleaved: entry [na][ny][nx] = eight doubles (six values + two of
     // padding, 64 bytes) -- a lookup of update_stress_rdg is a gather over a 2.3 MB table, and one cache line per lane and
@@ -29,10 +29,7 @@ struct EapDev {
     const double *tabs;
     double *pool;
     size_t nt, np;
-    int nxy, nyy, nay;
-    int angsel;                           // which of the two sets of angle planes is current: stepa inside k_eap_sub (round 5) writes the
-                                          // other one -- the redundant row and column of neighbouring strips read the current set in the
-                                          // same launch -- and the host swaps them after that launch
+    int nxy, nyy, nay, pad_;
     double invsin;                        // c1/sin(pi2/c12) * invstressconviso (:1524-1526), evaluated once on the host with the same evpk_sincos
     double invdx, invdy, invda;           // 1/dx, 1/dy, 1/da of the table axes (eap_set_steps)
     __host__ __device__ double *a11(int c) const { return pool + (size_t)c * np; }
@@ -43,8 +40,7 @@ struct EapDev {
     // per corner {gamma, a'}: functions of (a11, a12) only, which change every tenth subcycle (stepa) -- kept instead of recomputed
     // in every stress_eap (eap_tensor_angles: an atan2 and the tensor rotation); cos gamma, sin gamma are NOT kept: one sincos per
     // corner is cheaper than the 64 B per cell they cost now that the kernel is bound by its loads, and gives the same bits
-    __host__ __device__ double2 *ang(int c) const { return reinterpret_cast<double2 *>(pool + (size_t)(27 + 8 * angsel + 2 * c) * np); }
-    __host__ __device__ double2 *ang_other(int c) const { return reinterpret_cast<double2 *>(pool + (size_t)(27 + 8 * (angsel ^ 1) + 2 * c) * np); }
+    __host__ __device__ double2 *ang(int c) const { return reinterpret_cast<double2 *>(pool + (size_t)(27 + 2 * c) * np); }
 };
 enum { EH_A11 = 0, EH_A12, EH_E11, EH_E12, EH_E22, EH_Y11, EH_Y12, EH_Y22, EH_S11, EH_S12, EH_S22 };
 
@@ -312,7 +308,6 @@ __device__ __forceinline__ void eap_ffrac(double stressp, double stressm, double
 }
 
 // ---- stepa (:1664-1787): every tenth subcycle, T cells; sig = the stresses this subcycle's stress_eap left ----
-template <bool OTHER = false>      // OTHER: the new angles go to the other set of angle planes (stepa inside k_eap_sub)
 __device__ __forceinline__ void eap_stepa_cell(const EapDev &E, size_t km, const Sig &g, double dtei) {
     const double kth = 0.2 * 0.001;
     const double dteikth = 1.0 / (dtei + kth), p5kth = 0.5 * kth;
@@ -327,7 +322,7 @@ __device__ __forceinline__ void eap_stepa_cell(const EapDev &E, size_t km, const
         a12n[c] = (a12 * dtei - m12) * dteikth;
         E.a11(c)[km] = a11n[c];
         E.a12(c)[km] = a12n[c];
-        (OTHER ? E.ang_other(c) : E.ang(c))[km] = eap_tensor_angles(a11n[c], a12n[c]);
+        E.ang(c)[km] = eap_tensor_angles(a11n[c], a12n[c]);
     }
     E.hist(EH_A11)[km] = 0.25 * (a11n[0] + a11n[1] + a11n[2] + a11n[3]);
     E.hist(EH_A12)[km] = 0.25 * (a12n[0] + a12n[1] + a12n[2] + a12n[3]);
@@ -356,15 +351,12 @@ __global__ void __launch_bounds__(256) k_eap_stepa(Slab s, EapDev E, int SB, dou
 // straight-line code (selects instead of branches: 50 -> 18 branches in the loop body, the four corners of a cell interleave)
 // the kernel needs 160 VGPRs instead of 196; compiled for four waves per SIMD (128 VGPRs, 10 spilled) it runs 46.6-48.3 ms per
 // eap against 48.4-51.0 at three waves and 54.8 before (same box, strips of 8 or 16 rows alike).
-// stepa (every tenth subcycle) was a launch of its own after this one until round 5 -- it rewrites the angles that the redundant row
-// and column of the neighbouring strips read in the same launch.  STEPA: the owner of a T cell runs stepa on the stresses it has just
-// computed and writes the new angles into the OTHER set of angle planes (EapDev::angsel; the host swaps the sets after the launch);
-// the structure tensor itself (a11_c, a12_c) is read and written by the owner alone, in place.  A cell without ice keeps whatever
-// the other set holds: its angles are read again only after k_eap_reset (evp start) or k_eap_angles (upload) rewrote the current set.
+// stepa (every tenth subcycle) stays a launch of its own after this one: it rewrites the angles that the redundant row and
+// column of the neighbouring strips read in the same launch.
 // ------------------------------------------------------------------------------------
-struct EapSubArgs { EapDev E; int hist; double dtei; };
-template <bool LAST, bool STEPA>
-__device__ __forceinline__ void eap_sub_body(const SubArgs &a, const EapSubArgs &x) {
+struct EapSubArgs { EapDev E; int hist; };
+template <bool LAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_eap_sub(SubArgs a, EapSubArgs x) {
     const Slab &s = a.s;
     const EapDev &E = x.E;
     const int lane = threadIdx.x & 63;
@@ -427,7 +419,6 @@ __device__ __forceinline__ void eap_sub_body(const SubArgs &a, const EapSubArgs 
                                       [&]() { return load_sig(rb, pp, SR, lo); }, g, o, h, store && x.hist);
                 if (store) {
                     store_sig(rb, pp, SW, lo, g);
-                    if (STEPA) eap_stepa_cell<true>(E, km, g, x.dtei);                      // ice_dyn_eap.F90:411-426
                     if (LAST) { st1(rb, pp, F_SHEAR, lo, h.shear); st1(rb, pp, F_DIVU, lo, h.divu); st1(rb, pp, F_RDGCONV, lo, h.rdgconv); }
                     if (x.hist) st1(rb, pp, F_PRSSIG, lo, mt.strength);
                 }
@@ -459,12 +450,6 @@ __device__ __forceinline__ void eap_sub_body(const SubArgs &a, const EapSubArgs 
         mprev = m;
     }
 }
-// four waves per SIMD (128 VGPRs, 10 spilled) for the 108 plain subcycles of 120; the twelve that carry stepa need 46 more registers
-// and run at three waves per SIMD (168 VGPRs) rather than spill them
-template <bool LAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_eap_sub(SubArgs a, EapSubArgs x) { eap_sub_body<LAST, false>(a, x); }
-template <bool LAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_eap_sub_stepa(SubArgs a, EapSubArgs x) { eap_sub_body<LAST, true>(a, x); }
 
 // a plain plane -> one block array, cells chosen by `mode` (MODE_NE: the physical cells and the N / E ghost T cells)
 __global__ void k_scatter_mplane(Slab s, const BlockDesc *bd, int nxb, int nyb, const double *src, double *dst, int mode) {
