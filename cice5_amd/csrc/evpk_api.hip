@@ -694,7 +694,46 @@ static int verify_plane(evpk_ctx *c, void *host, size_t elem, size_t n, int f, c
                  (unsigned long)(addr >> 12), reinterpret_cast<const int32_t *>(host)[first], reinterpret_cast<const int32_t *>(c->dv_host.data())[first], bad, seen);
     }
     if (const char *log = getenv("EVPK_VERIFY_LOG")) {
-        if (FILE *fp = fopen(log, "a")) { fprintf(fp, "%s\n", msg); fclose(fp); }
+        // the whole picture of the event, for the record: which elements, where in their pages, what the kernel's memory counters say
+        if (FILE *fp = fopen(log, "a")) {
+            fprintf(fp, "%s\n", msg);
+            fprintf(fp, "  array base %#lx (page offset %lu), %zu elements of %zu bytes; differing elements (index: byte offset in its 4-KiB page, host | device):\n",
+                    (unsigned long)(uintptr_t)host, (unsigned long)((uintptr_t)host & 4095), n, elem);
+            long long shown = 0;
+            size_t run0 = 0, prev = 0;
+            bool inrun = false;
+            for (size_t k = 0; k < n; k++) {
+                bool d;
+                if (elem == 8) {
+                    const uint64_t dv = reinterpret_cast<const uint64_t *>(c->dv_host.data())[k];
+                    d = dv != (((uint64_t)DV_SENTINEL32 << 32) | DV_SENTINEL32) && dv != reinterpret_cast<const volatile uint64_t *>(host)[k];
+                    if (d && shown < 48) {
+                        fprintf(fp, "    %zu: +%lu  %.17g | %.17g\n", k, (unsigned long)(((uintptr_t)host + k * 8) & 4095), reinterpret_cast<const double *>(host)[k], c->dv_host[k]);
+                        shown++;
+                    }
+                } else {
+                    const uint32_t dv = reinterpret_cast<const uint32_t *>(c->dv_host.data())[k];
+                    d = dv != DV_SENTINEL32 && dv != reinterpret_cast<const volatile uint32_t *>(host)[k];
+                }
+                if (d) { if (!inrun) { run0 = k; inrun = true; } prev = k; }
+                else if (inrun && k > prev + 64) { fprintf(fp, "    span %zu .. %zu (%zu elements, pages %#lx .. %#lx)\n", run0, prev, prev - run0 + 1,
+                                                         (unsigned long)(((uintptr_t)host + run0 * elem) >> 12), (unsigned long)(((uintptr_t)host + prev * elem) >> 12)); inrun = false; }
+            }
+            if (inrun) fprintf(fp, "    span %zu .. %zu (%zu elements, pages %#lx .. %#lx)\n", run0, prev, prev - run0 + 1,
+                               (unsigned long)(((uintptr_t)host + run0 * elem) >> 12), (unsigned long)(((uintptr_t)host + prev * elem) >> 12));
+            if (FILE *vm = fopen("/proc/vmstat", "r")) {
+                char line[128];
+                fprintf(fp, "  vmstat:");
+                while (fgets(line, sizeof(line), vm))
+                    if (!strncmp(line, "thp_", 4) || !strncmp(line, "numa_", 5) || !strncmp(line, "pgmigrate", 9) || !strncmp(line, "compact_migrate", 15)) {
+                        line[strcspn(line, "\n")] = 0;
+                        fprintf(fp, " %s;", line);
+                    }
+                fclose(vm);
+                fprintf(fp, "\n");
+            }
+            fclose(fp);
+        }
     }
     if (c->verify_delivery >= 2) {      // repair: the staged copy is the device's word
         for (size_t k = 0; k < n; k++) {
