@@ -1223,6 +1223,7 @@ static void launch_sub2(evpk_ctx *c, const SubArgs &a_in, hipStream_t st, bool r
         const dim3 gt(((a.nstrips + 7) / 8) * 8 + nband8 + (xm ? (a.nmir + 7) & ~7 : 0)), bt((a.R + 3) * 64);
         const size_t lds = std::max((size_t)(a.R + 3) * (4096 + 5 * 1024), a.nband ? sizeof(double) * BAND_LDS_DOUBLES : (size_t)0);
         if (xm)         { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false, true>), gt, bt, lds, st, a); }
+        else if (last2 && a.R + 3 <= 8) { if (revp) hipLaunchKernelGGL(k_subcycle2t8<true>, gt, bt, lds, st, a); else hipLaunchKernelGGL(k_subcycle2t8<false>, gt, bt, lds, st, a); }      // (no scratch)
         else if (last2) { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, true>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, true>), gt, bt, lds, st, a); }
         else            { if (revp) hipLaunchKernelGGL((k_subcycle2t<true, false>), gt, bt, lds, st, a); else hipLaunchKernelGGL((k_subcycle2t<false, false>), gt, bt, lds, st, a); }
         return;
@@ -2238,8 +2239,12 @@ extern "C" int evpk_prep(evpk_ctx *c) {
                        (const unsigned char *)prev_dat, fresh);
     hipLaunchKernelGGL(k_prep1b, g2, B2D, 0, c->stream, s);
     if (halo(c, F_ICETM, 1, false, false, 0.0)) return 1;                         // :210-211
-    if (c->strength_dev)                                                          // ice_strength, :291-301
-        hipLaunchKernelGGL(k_ice_strength, g2, B2D, 0, c->stream, s, c->p, (const double *)c->itd);
+    if (c->strength_dev) {                                                        // ice_strength, :291-301
+        // (five categories -- the reference's default -- at compile time: work arrays in registers, no scratch memory; Hibler's
+        //  formula uses no work arrays at all)
+        if (c->p.kstrength != 1 || c->p.ncat == 5) { hipLaunchKernelGGL(k_ice_strength<5>, g2, B2D, 0, c->stream, s, c->p, (const double *)c->itd); }
+        else { hipLaunchKernelGGL(k_ice_strength<0>, g2, B2D, 0, c->stream, s, c->p, (const double *)c->itd); }
+    }
     // to_ugrid (:218-219) and t2ugrid_vector (:240-241; the T-grid wind sits in the work planes)
     if (!c->p.wind_on_ugrid && halo(c, F_WORK1, 2, false, true, 0.0)) return 1;
     hipLaunchKernelGGL(k_to_ugrid4, g2, B2D, 0, c->stream, s, c->p.wind_on_ugrid ? 0 : 1);

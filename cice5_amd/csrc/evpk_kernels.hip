@@ -459,6 +459,9 @@ __device__ __forceinline__ double dev_exp(double x) {
 constexpr int MAXCAT = 16;
 
 // itd: planes [0..ncat) aicen, [ncat..2 ncat) vicen, [2 ncat] aice0, each mask_elems(s) doubles, index mcell()
+// NC > 0: the number of thickness categories at compile time (NC = 5: the reference's default, ice_domain_size) -- the per-category work
+// arrays then live in registers; NC = 0: any ncat <= MAXCAT, the arrays in scratch memory (864 bytes per lane)
+template <int NC>
 __global__ void k_ice_strength(Slab s, DevParams p, const double *itd) {
     TILE_SKIP(s.act_any)
     SLAB_IJ_ALL
@@ -470,22 +473,27 @@ __global__ void k_ice_strength(Slab s, DevParams p, const double *itd) {
             str = Pstar * FD(s, F_VICE, k) * dev_exp(-Cstar * (c1 - FD(s, F_AICE, k)));
     } else if (i >= 1 && j >= 1 && FD(s, F_ICETM, k) == 1.0) {      // the T-cell list of evp_prep2 (ice_dyn_shared.F90:528-537)
         const size_t np = mask_elems(s);
-        const int ncat = p.ncat;
+        const int ncat = NC ? NC : p.ncat;
         const double Cp = p5 * p.gravit * (p.rhow - p.rhoi) * p.rhoi / p.rhow;                              // :68
         const double Gstari = c1 / Gstar, astari = c1 / astar;
-        double Gsum[MAXCAT + 2], apartic[MAXCAT + 1], hrmin[MAXCAT + 1], hrmax[MAXCAT + 1], hrexp[MAXCAT + 1], krdg[MAXCAT + 1];
+        constexpr int NA = NC ? NC : MAXCAT;
+        double Gsum[NA + 2], apartic[NA + 1], hrmin[NA + 1], hrmax[NA + 1], hrexp[NA + 1], krdg[NA + 1];
         const double a0 = itd[(size_t)(2 * ncat) * np + km];
         Gsum[0] = c0;
         apartic[0] = c0;
+        _Pragma("unroll")
         for (int n = 1; n <= ncat; n++) { apartic[n] = c0; hrmin[n] = c0; hrmax[n] = c0; hrexp[n] = c0; krdg[n] = c1; }
         Gsum[1] = (a0 > puny) ? a0 : Gsum[0];
+        _Pragma("unroll")
         for (int n = 1; n <= ncat; n++) {
             const double a = itd[(size_t)(n - 1) * np + km];
             Gsum[n + 1] = (a > puny) ? Gsum[n] + a : Gsum[n];
         }
         const double work = c1 / Gsum[ncat + 1];
+        _Pragma("unroll")
         for (int n = 0; n <= ncat; n++) Gsum[n + 1] = Gsum[n + 1] * work;
         if (p.krdg_partic == 0) {
+            _Pragma("unroll")
             for (int n = 0; n <= ncat; n++) {
                 const double g1 = Gsum[n + 1], g0 = Gsum[n];
                 if (g1 < Gstar) apartic[n] = Gstari * (g1 - g0) * (c2 - (g0 + g1) * Gstari);
@@ -493,9 +501,12 @@ __global__ void k_ice_strength(Slab s, DevParams p, const double *itd) {
             }
         } else {
             const double xtmp = c1 / (c1 - dev_exp(-astari));
+            _Pragma("unroll")
             for (int n = -1; n <= ncat; n++) Gsum[n + 1] = dev_exp(-Gsum[n + 1] * astari) * xtmp;
+            _Pragma("unroll")
             for (int n = 0; n <= ncat; n++) apartic[n] = Gsum[n] - Gsum[n + 1];
         }
+        _Pragma("unroll")
         for (int n = 1; n <= ncat; n++) {
             const double a = itd[(size_t)(n - 1) * np + km];
             if (a > puny) {
@@ -515,8 +526,10 @@ __global__ void k_ice_strength(Slab s, DevParams p, const double *itd) {
             }
         }
         double aksum = apartic[0];
+        _Pragma("unroll")
         for (int n = 1; n <= ncat; n++) aksum = aksum + apartic[n] * (c1 - c1 / krdg[n]);
         double sacc = c0;
+        _Pragma("unroll")
         for (int n = 1; n <= ncat; n++) {
             const double a = itd[(size_t)(n - 1) * np + km];
             if (a > puny && apartic[n] > c0) {
@@ -534,6 +547,8 @@ __global__ void k_ice_strength(Slab s, DevParams p, const double *itd) {
     }
     FD(s, F_STRENGTH, k) = str;
 }
+template __global__ void k_ice_strength<0>(Slab, DevParams, const double *);
+template __global__ void k_ice_strength<5>(Slab, DevParams, const double *);
 
 // the four T->U averages of evp() in one pass: umass <- tmass, aiu <- aice_init (ice_dyn_evp.F90:218-219) and,
 // unless the wind is already on the U grid, strairx/y <- work1/2 (t2ugrid_vector, :240-241)
@@ -876,33 +891,35 @@ __global__ void k_halo_tripole_ne1(Slab s, int f, int nf, int cyclic, double fil
     }
     if (t > h) return;
     // new values of column g: top row = sgn * v(src), ghost row = sgn * (row nyl-1)(src), src = nx - g (0 -> nx)
-    auto put = [&](int q, int g, double top, double ghost) {
-        FD(s, f + q, cell(s, g, nyl)) = top;
-        FD(s, f + q, cell(s, g, nyl + 1)) = ghost;
-        // E-W ghost columns of the two rows (k_halo_ew_local ran after the fold): copies of columns nx and 1
-        if (g == nx) { FD(s, f + q, cell(s, 0, nyl)) = cyclic ? top : fill; FD(s, f + q, cell(s, 0, nyl + 1)) = cyclic ? ghost : fill; }
-        if (g == 1) { FD(s, f + q, cell(s, nx + 1, nyl)) = cyclic ? top : fill; FD(s, f + q, cell(s, nx + 1, nyl + 1)) = cyclic ? ghost : fill; }
-    };
-    auto top = [&](int q, int g) {       // old top-row value of column g: an inactive cell carries the previous update's
-        const bool stale = fprev >= 0 && !(s.cmask[mcell(s, g, nyl)] & CM_U);
-        return FD(s, (stale ? fprev : f) + q, cell(s, g, nyl));
-    };
+    // (plain macros, not lambdas: the compiler kept the lambdas' closures -- references to f, fprev, nyl -- in scratch memory)
+#define TNE_PUT(q, g, topv, ghostv)                                                                                          \
+    do {                                                                                                                     \
+        FD(s, f + (q), cell(s, (g), nyl)) = (topv);                                                                          \
+        FD(s, f + (q), cell(s, (g), nyl + 1)) = (ghostv);                                                                    \
+        /* E-W ghost columns of the two rows (k_halo_ew_local ran after the fold): copies of columns nx and 1 */             \
+        if ((g) == nx) { FD(s, f + (q), cell(s, 0, nyl)) = cyclic ? (topv) : fill; FD(s, f + (q), cell(s, 0, nyl + 1)) = cyclic ? (ghostv) : fill; }          \
+        if ((g) == 1) { FD(s, f + (q), cell(s, nx + 1, nyl)) = cyclic ? (topv) : fill; FD(s, f + (q), cell(s, nx + 1, nyl + 1)) = cyclic ? (ghostv) : fill; } \
+    } while (0)
+    // old top-row value of column g: an inactive cell carries the previous update's
+#define TNE_TOP(q, g) FD(s, ((fprev >= 0 && !(s.cmask[mcell(s, (g), nyl)] & CM_U)) ? fprev : f) + (q), cell(s, (g), nyl))
     for (int q = 0; q < nf; q++) {
         if (t == 0 || t == h) {
             const int g = t == 0 ? nx : h;                  // src == g: the value itself
-            const double T = top(q, g), R = FD(s, f + q, cell(s, g, nyl - 1));
-            put(q, g, sgn * T, sgn * R);
+            const double T = TNE_TOP(q, g), R = FD(s, f + q, cell(s, g, nyl - 1));
+            { const double tv = sgn * T, gv = sgn * R; TNE_PUT(q, g, tv, gv); }
         } else {
             const int ga = t, gb = nx - t;                   // ga in 1..h-1, gb in h+1..nx-1
-            const double Ta = top(q, ga), Tb = top(q, gb);
+            const double Ta = TNE_TOP(q, ga), Tb = TNE_TOP(q, gb);
             const double Ra = FD(s, f + q, cell(s, ga, nyl - 1)), Rb = FD(s, f + q, cell(s, gb, nyl - 1));
             // column ga: src = gb >= h+1:  v = sgn*(0.5*(B2[nx-src] + sgn*B2[src]));  column gb: src = ga:  v = 0.5*(B2[src] + sgn*B2[nx-src])
             const double va = sgn * (0.5 * (Ta + sgn * Tb));
             const double vb = 0.5 * (Ta + sgn * Tb);
-            put(q, ga, sgn * va, sgn * Rb);
-            put(q, gb, sgn * vb, sgn * Ra);
+            { const double tv = sgn * va, gv = sgn * Rb; TNE_PUT(q, ga, tv, gv); }
+            { const double tv = sgn * vb, gv = sgn * Ra; TNE_PUT(q, gb, tv, gv); }
         }
     }
+#undef TNE_PUT
+#undef TNE_TOP
 }
 
 __global__ void k_halo_ew_local(Slab s, int f, int nf, int cyclic, double fill) {
@@ -2268,8 +2285,8 @@ template __global__ void k_subcycle2p<true, false, true, true>(SubArgs);
 // same column / ghost-zone / tripole-band (jmax) rules, same arithmetic in the same order: bit-identical to k_subcycle2.
 // LDS: two arrays of [waves][4][64] doubles (the first one serves phases A and C).
 // ------------------------------------------------------------------------------------
-template <bool REVP, bool LAST2, bool XM = false>
-__global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
+template <bool REVP, bool LAST2, bool XM>
+__device__ __forceinline__ void subcycle2t_body(const SubArgs &a) {
     extern __shared__ double tl[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2451,12 +2468,24 @@ __global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) {
     if (w == 0 && !mir) dbg_stamp(a, wg, 1);
 }
 
+// Workgroups of up to sixteen waves (tile heights up to 13): 128 VGPRs.  The LAST2 variants -- one launch per evp, with the ridging
+// diagnostics -- need a dozen more and spilled them to scratch memory; for workgroups of up to eight waves (the tuner's tile height 5)
+// they are compiled for 256 VGPRs instead (k_subcycle2t8): NO kernel on the default evp path uses scratch memory since round 5.
+// (Both unexplained one-plane differences, rounds 4 and 5, were zeros in a stress plane after the FIRST evp of a context on a small
+// grid: the one launch of this kernel's LAST2 variant, the only spilling kernel on that path -- docs/NOTEBOOK.md R5.11.)
+template <bool REVP, bool LAST2, bool XM = false>
+__global__ __launch_bounds__(1024) void k_subcycle2t(SubArgs a) { subcycle2t_body<REVP, LAST2, XM>(a); }
+template <bool REVP>
+__global__ __launch_bounds__(512) void k_subcycle2t8(SubArgs a) { subcycle2t_body<REVP, true, false>(a); }
+
 template __global__ void k_subcycle2t<false, false>(SubArgs);
 template __global__ void k_subcycle2t<true, false>(SubArgs);
 template __global__ void k_subcycle2t<false, true>(SubArgs);
 template __global__ void k_subcycle2t<true, true>(SubArgs);
 template __global__ void k_subcycle2t<false, false, true>(SubArgs);
 template __global__ void k_subcycle2t<true, false, true>(SubArgs);
+template __global__ void k_subcycle2t8<false>(SubArgs);
+template __global__ void k_subcycle2t8<true>(SubArgs);
 
 // ------------------------------------------------------------------------------------
 // k_subcycle2r (round 5): k_subcycle2t that ROLLS north -- the one-row-per-wave tile WITHOUT its redundant rows.
