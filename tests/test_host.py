@@ -210,6 +210,8 @@ def test_hot_kernels_keep_their_register_budget():
         m = re.search(r"k_subcycle2tILb[01]ELb([01])ELb[01]E", k)              # <REVP, LAST2, XM>
         if m and m.group(1) == "0":                                          # (one row per wave, compiled for 128 VGPRs; the LAST2
             assert v["ScratchSize"] <= 64, (k, v)                            #  variants, once per evp, spill)
+        if "k_subcycle2t8" in k or "k_halo_tripole_ne1" in k or "k_ice_strengthILi5" in k:      # round 5: no scratch memory on the default evp path
+            assert v["ScratchSize"] == 0 and v["VGPRs Spill"] == 0, (k, v)
         if "k_eap_subILb0" in k:
             assert v["VGPRs"] <= 128 and v["ScratchSize"] <= 64, (k, v)
 
