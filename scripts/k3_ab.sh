@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the three-subcycle pipeline kernel (k_subcycle3w) against the pair kernel on the bench workload, open N-S
+export EVPK_LIB=${EVPK_LIB:-cice5_amd/libevpk_exp.so}      # k_subcycle3w lives in the experimental build only (make -C cice5_amd/csrc exp)
 out=gpurun_out/${1:-k3}
 mkdir -p $out
 run() { # label, env...

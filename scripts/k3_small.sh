@@ -1,6 +1,7 @@
 #!/bin/bash
 # k_subcycle3w on small slabs (one rank, open N-S) against the tile / marching pair kernels: is the pipeline a better use of a chip
 # that has more SIMDs than strips?
+export EVPK_LIB=${EVPK_LIB:-cice5_amd/libevpk_exp.so}      # k_subcycle3w lives in the experimental build only (make -C cice5_amd/csrc exp)
 run() { env "$@" python3 bench.py --steps 5 --warmup 2 --cpu-subcycles 0 --no-variants $G 2>/dev/null | python3 -c "
 import json,sys
 o=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=o['roofline']

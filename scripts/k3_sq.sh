@@ -1,5 +1,6 @@
 #!/bin/bash
 # SQ counters of the pair kernel and of the three-subcycle pipeline kernel on the bench workload (open N-S), two passes of <= 8 counters
+export EVPK_LIB=${EVPK_LIB:-cice5_amd/libevpk_exp.so}      # k_subcycle3w lives in the experimental build only (make -C cice5_amd/csrc exp)
 out=gpurun_out/${1:-k3_sq}
 mkdir -p $out
 export TMPDIR=/tmp
