@@ -1,6 +1,6 @@
 """where does k_subcycle3w differ from k_subcycle?  (debugging aid)"""
-import os
-os.environ.setdefault("EVPK_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cice5_amd", "libevpk_exp.so"))      # k_subcycle3w: experimental build only, sys
+import os, sys
+os.environ.setdefault("EVPK_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cice5_amd", "libevpk_exp.so"))      # k_subcycle3w: experimental build only
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cice5_amd import blocks, constants as C, dyn, synth
